@@ -1,0 +1,281 @@
+"""ctypes front end of the CPU oracle (oracle/vslam_oracle.c).
+
+TEST INFRASTRUCTURE ONLY -- parity unpinned (see vslam_oracle.h).  Only tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg may import this package; the
+product package ``visualslam_amd`` never does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libvslam_oracle.so")
+
+NUM_LEVELS = 6
+NUM_DOGS = 5
+MAX_OCTAVES = 16
+
+
+def build(force: bool = False) -> str:
+    """Compile the C restatement with gcc (Makefile next to this file)."""
+    src = os.path.join(_HERE, "vslam_oracle.c")
+    hdr = os.path.join(_HERE, "vslam_oracle.h")
+    stale = (
+        force
+        or not os.path.exists(_LIB_PATH)
+        or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(src), os.path.getmtime(hdr))
+    )
+    if stale:
+        subprocess.run(["make", "-C", _HERE, "-B", "libvslam_oracle.so"], check=True, capture_output=True)
+    return _LIB_PATH
+
+
+class _Point(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("row", "col", "value", "padding", "octave", "level")]
+
+
+class _Kp(C.Structure):
+    _fields_ = [("row", C.c_int32), ("col", C.c_int32), ("response", C.c_float)]
+
+
+class _Pyr(C.Structure):
+    _fields_ = [
+        ("n_octaves", C.c_int),
+        ("sigma0", C.c_double),
+        ("rows", C.c_int * MAX_OCTAVES),
+        ("cols", C.c_int * MAX_OCTAVES),
+        ("sigma", (C.c_double * NUM_LEVELS) * MAX_OCTAVES),
+        ("ksize", (C.c_int * NUM_LEVELS) * MAX_OCTAVES),
+        ("base", C.POINTER(C.c_uint8) * MAX_OCTAVES),
+        ("gauss", (C.POINTER(C.c_uint8) * NUM_LEVELS) * MAX_OCTAVES),
+        ("dog", (C.POINTER(C.c_uint8) * NUM_DOGS) * MAX_OCTAVES),
+    ]
+
+
+POINT_DTYPE = np.dtype(
+    [(n, "<i4") for n in ("row", "col", "value", "padding", "octave", "level")], align=True
+)
+KP_DTYPE = np.dtype([("row", "<i4"), ("col", "<i4"), ("response", "<f4")], align=True)
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        L.vo_reflect101.restype = C.c_int
+        L.vo_gauss_ksize_u8.argtypes = [C.c_double]
+        L.vo_gauss_taps_q8.argtypes = [C.c_int, C.c_double, C.c_void_p]
+        L.vo_gaussian_blur_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_double, C.c_void_p, C.c_size_t]
+        L.vo_sobel_k1_u8_f32.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+        L.vo_resize_linear2x_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t]
+        L.vo_half_size.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.vo_half_size.restype = None
+        L.vo_resize_nearest_half_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t]
+        L.vo_convert_scale_abs_f32.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t]
+        L.vo_harris_from_grad_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_float, C.c_int, C.c_void_p, C.c_size_t]
+        L.vo_harris_response_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_float, C.c_int, C.c_void_p, C.c_size_t]
+        L.vo_nms_strict_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t]
+        L.vo_nms_strict_f32.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t]
+        L.vo_nms2_f32.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_float)]
+        L.vo_harris_keypoints.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t]
+        L.vo_harris_keypoints.restype = C.c_size_t
+        L.vo_auto_num_octaves.argtypes = [C.c_int, C.c_int]
+        L.vo_sigma.argtypes = [C.c_double, C.c_int, C.c_int]
+        L.vo_sigma.restype = C.c_double
+        L.vo_pyramid_build_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_double]
+        L.vo_pyramid_build_u8.restype = C.POINTER(_Pyr)
+        L.vo_pyramid_free.argtypes = [C.POINTER(_Pyr)]
+        L.vo_pyramid_free.restype = None
+        L.vo_extrema_lattice.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.vo_extrema_lattice.restype = None
+        L.vo_dog_extrema.argtypes = [C.POINTER(_Pyr), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
+        L.vo_dog_extrema.restype = C.c_size_t
+        _lib = L
+    return _lib
+
+
+def _u8(a):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    assert a.ndim == 2
+    return a
+
+
+def _f32(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    assert a.ndim == 2
+    return a
+
+
+def _chk(rc, what):
+    if rc != 0:
+        raise ValueError(f"oracle {what} rejected its arguments (rc={rc})")
+
+
+def reflect101(p: int, n: int) -> int:
+    return lib().vo_reflect101(int(p), int(n))
+
+
+def gauss_ksize_u8(sigma: float) -> int:
+    return lib().vo_gauss_ksize_u8(float(sigma))
+
+
+def gauss_taps_q8(n: int, sigma: float) -> np.ndarray:
+    t = np.zeros(n, np.uint16)
+    _chk(lib().vo_gauss_taps_q8(n, float(sigma), t.ctypes.data), "gauss_taps_q8")
+    return t
+
+
+def gaussian_blur_u8(img, ksize: int, sigma: float) -> np.ndarray:
+    img = _u8(img)
+    out = np.empty_like(img)
+    _chk(lib().vo_gaussian_blur_u8(img.ctypes.data, *img.shape, img.strides[0], ksize, float(sigma), out.ctypes.data, out.strides[0]), "gaussian_blur_u8")
+    return out
+
+
+def sobel_k1(img, dx: int, dy: int) -> np.ndarray:
+    img = _u8(img)
+    out = np.empty(img.shape, np.float32)
+    _chk(lib().vo_sobel_k1_u8_f32(img.ctypes.data, *img.shape, img.strides[0], dx, dy, out.ctypes.data, out.strides[0]), "sobel_k1")
+    return out
+
+
+def resize_linear2x(img) -> np.ndarray:
+    img = _u8(img)
+    out = np.empty((img.shape[0] * 2, img.shape[1] * 2), np.uint8)
+    _chk(lib().vo_resize_linear2x_u8(img.ctypes.data, *img.shape, img.strides[0], out.ctypes.data, out.strides[0]), "resize_linear2x")
+    return out
+
+
+def half_size(rows: int, cols: int):
+    r, c = C.c_int(), C.c_int()
+    lib().vo_half_size(rows, cols, C.byref(r), C.byref(c))
+    return r.value, c.value
+
+
+def resize_nearest_half(img) -> np.ndarray:
+    img = _u8(img)
+    out = np.empty(half_size(*img.shape), np.uint8)
+    _chk(lib().vo_resize_nearest_half_u8(img.ctypes.data, *img.shape, img.strides[0], out.ctypes.data, out.strides[0]), "resize_nearest_half")
+    return out
+
+
+def convert_scale_abs(x) -> np.ndarray:
+    x = _f32(x)
+    out = np.empty(x.shape, np.uint8)
+    _chk(lib().vo_convert_scale_abs_f32(x.ctypes.data, *x.shape, x.strides[0], out.ctypes.data, out.strides[0]), "convert_scale_abs")
+    return out
+
+
+def harris_from_grad(ix, iy, k: float = 0.04, window: int = 3) -> np.ndarray:
+    ix, iy = _f32(ix), _f32(iy)
+    assert ix.shape == iy.shape
+    out = np.empty(ix.shape, np.float32)
+    _chk(lib().vo_harris_from_grad_f32(ix.ctypes.data, iy.ctypes.data, *ix.shape, ix.strides[0], k, window, out.ctypes.data, out.strides[0]), "harris_from_grad")
+    return out
+
+
+def harris_response(img, k: float = 0.04, window: int = 3) -> np.ndarray:
+    img = _u8(img)
+    out = np.empty(img.shape, np.float32)
+    _chk(lib().vo_harris_response_u8(img.ctypes.data, *img.shape, img.strides[0], k, window, out.ctypes.data, out.strides[0]), "harris_response")
+    return out
+
+
+def nms_strict(x, window: int = 3) -> np.ndarray:
+    x = np.asarray(x)
+    out = np.empty(x.shape, np.uint8)
+    if x.dtype == np.uint8:
+        x = _u8(x)
+        rc = lib().vo_nms_strict_u8(x.ctypes.data, *x.shape, x.strides[0], window, out.ctypes.data, out.strides[0])
+    else:
+        x = _f32(x)
+        rc = lib().vo_nms_strict_f32(x.ctypes.data, *x.shape, x.strides[0], window, out.ctypes.data, out.strides[0])
+    _chk(rc, "nms_strict")
+    return out
+
+
+def nms2(resp, window: int = 5):
+    resp = _f32(resp)
+    out = np.empty(resp.shape, np.float32)
+    tm = C.c_float()
+    _chk(lib().vo_nms2_f32(resp.ctypes.data, *resp.shape, resp.strides[0], window, out.ctypes.data, out.strides[0], C.byref(tm)), "nms2")
+    return out, tm.value
+
+
+def harris_keypoints(nms2_map) -> np.ndarray:
+    m = _f32(nms2_map)
+    n = lib().vo_harris_keypoints(m.ctypes.data, *m.shape, m.strides[0], None, 0)
+    out = np.zeros(n, KP_DTYPE)
+    if n:
+        lib().vo_harris_keypoints(m.ctypes.data, *m.shape, m.strides[0], out.ctypes.data, n)
+    return out
+
+
+def auto_num_octaves(rows: int, cols: int) -> int:
+    return lib().vo_auto_num_octaves(rows, cols)
+
+
+def sigma_at(sigma0: float, octave: int, level: int) -> float:
+    return lib().vo_sigma(float(sigma0), octave, level)
+
+
+def extrema_lattice(rows: int, cols: int, window: int = 3):
+    r, c = C.c_int(), C.c_int()
+    lib().vo_extrema_lattice(rows, cols, window, C.byref(r), C.byref(c))
+    return r.value, c.value
+
+
+class Pyramid:
+    """Owns a vo_pyramid; exposes numpy copies of its images."""
+
+    def __init__(self, img, n_octaves: int = 4, sigma0: float = 1.6):
+        img = _u8(img)
+        self._p = lib().vo_pyramid_build_u8(img.ctypes.data, *img.shape, img.strides[0], n_octaves, float(sigma0))
+        if not self._p:
+            raise ValueError("oracle pyramid_build rejected its arguments")
+        s = self._p.contents
+        self.n_octaves = s.n_octaves
+        self.sizes = [(s.rows[o], s.cols[o]) for o in range(self.n_octaves)]
+        self.sigmas = [[s.sigma[o][l] for l in range(NUM_LEVELS)] for o in range(self.n_octaves)]
+        self.ksizes = [[s.ksize[o][l] for l in range(NUM_LEVELS)] for o in range(self.n_octaves)]
+
+    def _img(self, ptr, o):
+        r, c = self.sizes[o]
+        return np.ctypeslib.as_array(ptr, shape=(r, c)).copy()
+
+    def base(self, o):
+        return self._img(self._p.contents.base[o], o)
+
+    def gauss(self, o, l):
+        return self._img(self._p.contents.gauss[o][l], o)
+
+    def dog(self, o, l):
+        return self._img(self._p.contents.dog[o][l], o)
+
+    def extrema(self, octave: int, window: int = 3, min_contrast: int = 8):
+        """(mask[3, lat_rows, lat_cols] u8, points[POINT_DTYPE]) for one octave."""
+        lr, lc = extrema_lattice(*self.sizes[octave], window)
+        mask = np.zeros((3, lr, lc), np.uint8)
+        n = lib().vo_dog_extrema(self._p, octave, window, min_contrast, mask.ctypes.data, None, 0)
+        pts = np.zeros(n, POINT_DTYPE)
+        if n:
+            lib().vo_dog_extrema(self._p, octave, window, min_contrast, None, pts.ctypes.data, n)
+        return mask, pts
+
+    def close(self):
+        if self._p:
+            lib().vo_pyramid_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

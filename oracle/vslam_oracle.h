@@ -1,0 +1,143 @@
+/*
+ * vslam_oracle.h -- CPU restatement of the reference keypoint-detection hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library, and there only as the checker / the timed CPU baseline.  The product
+ * path (visualslam_amd/) never links, imports or falls back to it.
+ *
+ * PARITY UNPINNED: the arithmetic of the reference lives in OpenCV (un-vendored,
+ * un-pinned: KeyPointDetection/CMakeLists.txt:3, README.md:31), OpenCV is absent
+ * from this image and the reference holds no golden vectors or asserting tests
+ * (SURVEY.md section 8c).  The functions below restate the reference's own loops
+ * literally and OpenCV 4.x's published 8-bit fixed-point algorithms from memory;
+ * they are pinned only by analytic known answers (tests/test_oracle_kat.py).
+ *
+ * All citations are relative to /root/reference/KeyPointDetection/.
+ */
+#ifndef VSLAM_ORACLE_H
+#define VSLAM_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VO_MAX_OCTAVES 16
+#define VO_NUM_LEVELS 6 /* scaleSamples_ + 3, GaussPyramid.hpp:65-66 */
+#define VO_NUM_DOGS 5   /* GaussPyramid.cpp:193 */
+
+/* SLAM::point, Diff_of_Gauss.cpp:27-35 (six ints, 24 bytes). */
+typedef struct {
+    int32_t row, col, value, padding, octave, level;
+} vo_point;
+
+/* Harris keypoint: NMS2 survivor whose 8-bit view is > 253 (Harris_corners.cpp:139). */
+typedef struct {
+    int32_t row, col;
+    float response;
+} vo_kp;
+
+/* ---- OpenCV primitive semantics ---- */
+
+/* A1: BORDER_REFLECT_101 index map, repeated until inside [0,len). */
+int vo_reflect101(int p, int len);
+
+/* A2-i: automatic kernel width for 8-bit input: cvRound(sigma*3*2+1)|1. */
+int vo_gauss_ksize_u8(double sigma);
+
+/* A2-ii/iii: Gaussian taps quantised to unsigned 8.8 fixed point with error
+ * diffusion; taps[n]; sum is exactly 256.  sigma<=0 uses the fixed small tables /
+ * the n-derived sigma.  Returns 0, or -1 for invalid n. */
+int vo_gauss_taps_q8(int n, double sigma, uint16_t* taps);
+
+/* A2-iv: GaussianBlur on CV_8U: exact 2-D integer sum, (acc + 32768) >> 16,
+ * BORDER_REFLECT_101.  ksize 0 => from sigma.  Square kernels only (both
+ * reference call sites: Harris_corners.cpp:158, GaussPyramid.cpp:177). */
+int vo_gaussian_blur_u8(const uint8_t* src, int rows, int cols, size_t step, int ksize, double sigma,
+                        uint8_t* dst, size_t dst_step);
+
+/* A3: Sobel(ddepth=CV_32F, ksize=1): [-1 0 1] along x (dx=1) or y (dy=1). */
+int vo_sobel_k1_u8_f32(const uint8_t* src, int rows, int cols, size_t step, int dx, int dy, float* dst,
+                       size_t dst_step_bytes);
+
+/* A4: resize x2 INTER_LINEAR (8-bit fixed point) and x0.5 INTER_NEAREST. */
+int vo_resize_linear2x_u8(const uint8_t* src, int rows, int cols, size_t step, uint8_t* dst, size_t dst_step);
+void vo_half_size(int rows, int cols, int* out_rows, int* out_cols);
+int vo_resize_nearest_half_u8(const uint8_t* src, int rows, int cols, size_t step, uint8_t* dst,
+                              size_t dst_step);
+
+/* A7: convertScaleAbs f32 -> u8: saturate(round_half_even(|x|)). */
+int vo_convert_scale_abs_f32(const float* src, int rows, int cols, size_t step_bytes, uint8_t* dst,
+                             size_t dst_step);
+
+/* ---- Harris path ---- */
+
+/* HarrisCorner, Harris_corners.cpp:31-68 with StructureMatrix :10-29.  Literal
+ * f32 accumulation order, double determinant, three separately rounded f32 ops.
+ * Intended (rows x cols) indexing, Appendix B-1.  window odd >= 1. */
+int vo_harris_from_grad_f32(const float* ix, const float* iy, int rows, int cols, size_t step_bytes, float k,
+                            int window, float* resp, size_t resp_step_bytes);
+
+/* Front end of main(): GaussianBlur 3x3 -> Sobel x/y -> HarrisCorner
+ * (Harris_corners.cpp:158-172). */
+int vo_harris_response_u8(const uint8_t* img, int rows, int cols, size_t step, float k, int window,
+                          float* resp, size_t resp_step_bytes);
+
+/* NonMaximumSuppression, Harris_corners.cpp:70-81: mask = v > max(neighbours in
+ * window, centre excluded, out-of-image ignored); 255/0. */
+int vo_nms_strict_u8(const uint8_t* src, int rows, int cols, size_t step, int window, uint8_t* mask,
+                     size_t mask_step);
+int vo_nms_strict_f32(const float* src, int rows, int cols, size_t step_bytes, int window, uint8_t* mask,
+                      size_t mask_step);
+
+/* NMS2, Harris_corners.cpp:83-129: half-open window [i-p,i+p) x [j-p,j+p),
+ * >= test, f32 map (Appendix B-3/B-4).  true_max may be NULL. */
+int vo_nms2_f32(const float* resp, int rows, int cols, size_t step_bytes, int window, float* out,
+                size_t out_step_bytes, float* true_max);
+
+/* H8: row-major list of pixels whose NMS2 map value converts to an 8-bit value
+ * > 253 (i.e. >= 253.5).  Returns total count; writes at most cap. */
+size_t vo_harris_keypoints(const float* nms2, int rows, int cols, size_t step_bytes, vo_kp* out, size_t cap);
+
+/* ---- DoG pyramid path ---- */
+
+typedef struct {
+    int n_octaves;
+    double sigma0;
+    int rows[VO_MAX_OCTAVES], cols[VO_MAX_OCTAVES];
+    double sigma[VO_MAX_OCTAVES][VO_NUM_LEVELS];
+    int ksize[VO_MAX_OCTAVES][VO_NUM_LEVELS];
+    uint8_t* base[VO_MAX_OCTAVES];                 /* img_pyramid, GaussPyramid.cpp:119 */
+    uint8_t* gauss[VO_MAX_OCTAVES][VO_NUM_LEVELS]; /* gauss_pyramid */
+    uint8_t* dog[VO_MAX_OCTAVES][VO_NUM_DOGS];     /* diff_pyramid */
+} vo_pyramid;
+
+/* calculateNumOctaves, GaussPyramid.cpp:150-152. */
+int vo_auto_num_octaves(int rows, int cols);
+/* calculateSigma(octave, level), GaussPyramid.cpp:160-162. */
+double vo_sigma(double sigma0, int octave, int level);
+
+/* GaussPyramid ctor + createPyramid, GaussPyramid.cpp:106-131 (gradients excluded). */
+vo_pyramid* vo_pyramid_build_u8(const uint8_t* img, int rows, int cols, size_t step, int n_octaves,
+                                double sigma0);
+void vo_pyramid_free(vo_pyramid* p);
+
+/* Lattice geometry of initialKeypointDetection, Diff_of_Gauss.cpp:267-268:
+ * sites i = pad, pad+ws, ... < rows. */
+void vo_extrema_lattice(int rows, int cols, int window, int* lat_rows, int* lat_cols);
+
+/* initialKeypointDetection, Diff_of_Gauss.cpp:254-297, up to (not including)
+ * FeaturePointLocalization.  For each level 1..3: a byte mask (1/0) per lattice
+ * site in mask[(level-1)*lat_rows*lat_cols + li*lat_cols + lj] (may be NULL), and
+ * the ordered list of candidates with value >= min_contrast (level, i, j order).
+ * Returns the total list length; writes at most cap points. */
+size_t vo_dog_extrema(const vo_pyramid* p, int octave, int window, int min_contrast, uint8_t* mask,
+                      vo_point* out, size_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,92 @@
+"""Independent numpy/scipy restatements used to cross-check the C oracle.
+
+These are written from SURVEY.md Appendix A in *integer* form (exact sums), not from
+oracle/vslam_oracle.c, so that an indexing or rounding slip in either shows up as a
+disagreement.  They are slow and only used on small inputs.
+"""
+import numpy as np
+from scipy import ndimage
+
+
+def blur_q8(img: np.ndarray, taps: np.ndarray) -> np.ndarray:
+    """Exact 2-D integer correlation with 8.8 taps, reflect-101, (acc+32768)>>16."""
+    t = taps.astype(np.int64)
+    a = img.astype(np.int64)
+    h = ndimage.correlate1d(a, t, axis=1, mode="mirror")
+    v = ndimage.correlate1d(h, t, axis=0, mode="mirror")
+    return ((v + 32768) >> 16).astype(np.uint8)
+
+
+def harris_int(img: np.ndarray, k=np.float32(0.04)) -> np.ndarray:
+    """Harris response for window 3 with all sums in exact integers (SURVEY section 7 recipe)."""
+    a = img.astype(np.int64)
+    p = np.pad(a, 1, mode="reflect")  # numpy 'reflect' == BORDER_REFLECT_101
+    s = (p[:-2, :-2] + 2 * p[:-2, 1:-1] + p[:-2, 2:]
+         + 2 * p[1:-1, :-2] + 4 * p[1:-1, 1:-1] + 2 * p[1:-1, 2:]
+         + p[2:, :-2] + 2 * p[2:, 1:-1] + p[2:, 2:])
+    b = (s + 8) >> 4
+    bp = np.pad(b, 1, mode="reflect")
+    ix = bp[1:-1, 2:] - bp[1:-1, :-2]
+    iy = bp[2:, 1:-1] - bp[:-2, 1:-1]
+
+    def box(x):
+        q = np.pad(x, 1, mode="edge")  # BORDER_REPLICATE
+        h, w = x.shape
+        return sum(q[i:i + h, j:j + w] for i in range(3) for j in range(3))
+
+    sxx, syy, sxy = box(ix * ix), box(iy * iy), box(ix * iy)
+    det = (sxx * syy - sxy * sxy).astype(np.float32)  # int64 -> f32, round to nearest even
+    tr = (sxx + syy).astype(np.float32)
+    r = det - np.float32(k) * (tr * tr)
+    return np.where(r > 0, r, np.float32(0)).astype(np.float32)
+
+
+def resize2x(img: np.ndarray) -> np.ndarray:
+    """INTER_LINEAR x2 with the 11-bit fixed-point steps of SURVEY A4."""
+    h, w = img.shape
+    a = img.astype(np.int64)
+
+    def coeff(n_dst, n_src):
+        d = np.arange(n_dst)
+        f = (d + 0.5) * 0.5 - 0.5
+        s = np.floor(f).astype(np.int64)
+        fr = f - s
+        return s, fr
+
+    sx, fx = coeff(2 * w, w)
+    lo = sx < 0
+    fx = np.where(lo, 0.0, fx)
+    sx = np.where(lo, 0, sx)
+    hi = sx >= w - 1
+    fx = np.where(hi, 0.0, fx)
+    sx = np.where(hi, w - 1, sx)
+    a0 = np.rint((1 - fx) * 2048).astype(np.int64)
+    a1 = np.rint(fx * 2048).astype(np.int64)
+    hrow = a[:, sx] * a0 + a[:, np.minimum(sx + 1, w - 1)] * a1
+    sy, fy = coeff(2 * h, h)
+    b0 = np.rint((1 - fy) * 2048).astype(np.int64)[:, None]
+    b1 = np.rint(fy * 2048).astype(np.int64)[:, None]
+    r0 = np.clip(sy, 0, h - 1)
+    r1 = np.clip(sy + 1, 0, h - 1)
+    v = (((b0 * (hrow[r0] >> 4)) >> 16) + ((b1 * (hrow[r1] >> 4)) >> 16) + 2) >> 2
+    return np.clip(v, 0, 255).astype(np.uint8)
+
+
+def extrema_mask(dogs, window=3):
+    """initialKeypointDetection candidate mask for levels 1..3, vectorised."""
+    pad = (window - 1) // 2
+    rows, cols = dogs[0].shape
+    P = [np.pad(d.astype(np.int64), pad, mode="edge") for d in dogs]
+    ii = np.arange(pad, rows, window)
+    jj = np.arange(pad, cols, window)
+    out = []
+    for level in (1, 2, 3):
+        vals = []
+        for l in (level - 1, level, level + 1):
+            for du in range(-pad, pad):
+                for dv in range(-pad, pad):
+                    vals.append(P[l][np.ix_(ii + du, jj + dv)])
+        vals = np.stack(vals)
+        this = P[level][np.ix_(ii, jj)]
+        out.append(((this == vals.min(0)) | (this == vals.max(0))).astype(np.uint8))
+    return np.stack(out), ii, jj

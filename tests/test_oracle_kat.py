@@ -1,0 +1,255 @@
+"""Known-answer tests that pin the CPU oracle (oracle/vslam_oracle.c).
+
+The reference holds no golden vectors and OpenCV is not
+available, so the oracle is pinned by: the analytic answers derivable from the reference
+sources, closed-form images (constant, impulse,
+checkerboard), and an independent integer restatement in numpy (tests/npref.py).
+"""
+import numpy as np
+import pytest
+
+import oracle
+from tests import npref
+from visualslam_amd import synth
+
+K3 = 2.0 ** (1.0 / 3.0)
+
+
+def test_reflect101():
+    assert [oracle.reflect101(p, 5) for p in (-1, -2, 5, 6, 0, 4)] == [1, 2, 3, 2, 0, 4]
+    assert oracle.reflect101(-7, 1) == 0
+    # repeated reflection when the radius exceeds the image
+    assert [oracle.reflect101(p, 3) for p in (-3, -4, 5, 7)] == [1, 0, 1, 1]
+
+
+def test_sigma_and_ksize_tables():
+    # SURVEY section 4 known answers (tests/GaussPyramid_Test.cpp:99-106)
+    assert oracle.sigma_at(1.6, 0, 0) == 1.6
+    assert oracle.sigma_at(1.6, 0, 3) == pytest.approx(3.2, abs=1e-15)
+    assert oracle.sigma_at(1.6, 0, 5) == pytest.approx(5.079683366298239, abs=1e-14)
+    assert oracle.sigma_at(1.6, 3, 5) == pytest.approx(40.63746693038591, abs=1e-12)
+    # Appendix C kernel widths
+    want = [[11, 13, 17, 21, 25, 31], [21, 25, 31, 39, 49, 63], [39, 49, 63, 79, 99, 123], [79, 99, 123, 155, 195, 245]]
+    got = [[oracle.gauss_ksize_u8(oracle.sigma_at(1.6, o, l)) for l in range(6)] for o in range(4)]
+    assert got == want
+
+
+def test_gauss_taps_known():
+    assert oracle.gauss_taps_q8(3, 0).tolist() == [64, 128, 64]
+    assert oracle.gauss_taps_q8(5, 0).tolist() == [16, 64, 96, 64, 16]
+    assert oracle.gauss_taps_q8(7, 0).tolist() == [8, 28, 56, 72, 56, 28, 8]
+    assert oracle.gauss_taps_q8(1, 0).tolist() == [256]
+    # SURVEY Appendix A2 worked examples
+    assert oracle.gauss_taps_q8(11, 1.6).tolist() == [0, 3, 11, 30, 52, 64, 52, 30, 11, 3, 0]
+    assert oracle.gauss_taps_q8(13, 1.6 * K3).tolist() == [1, 2, 7, 17, 31, 45, 50, 45, 31, 17, 7, 2, 1]
+
+
+@pytest.mark.parametrize("o", range(4))
+def test_gauss_taps_sum_symmetry_close_to_gaussian(o):
+    for l in range(6):
+        s = oracle.sigma_at(1.6, o, l)
+        n = oracle.gauss_ksize_u8(s)
+        t = oracle.gauss_taps_q8(n, s).astype(np.int64)
+        assert t.sum() == 256 and (t == t[::-1]).all() and t.max() <= 64
+        x = np.arange(n) - n // 2
+        g = np.exp(-x * x / (2 * s * s))
+        g = g / g.sum() * 256
+        # error diffusion keeps the running error below one unit
+        assert np.abs(np.cumsum(t[: n // 2] - g[: n // 2])).max() <= 1.0
+
+
+def test_blur_constant_and_impulse():
+    c = np.full((40, 56), 173, np.uint8)
+    assert (oracle.gaussian_blur_u8(c, 0, 3.2) == 173).all()
+    imp = np.zeros((41, 41), np.uint8)
+    imp[20, 20] = 255
+    t = oracle.gauss_taps_q8(11, 1.6).astype(np.int64)
+    out = oracle.gaussian_blur_u8(imp, 0, 1.6)
+    want = (255 * np.outer(t, t) + 32768) >> 16
+    assert (out[15:26, 15:26] == want).all() and out.sum() == want.sum()
+
+
+@pytest.mark.parametrize("shape,sigma,ksize", [((48, 64), 1.6, 0), ((37, 53), 3.2, 0), ((20, 30), 12.8, 0), ((9, 7), 6.4, 0), ((33, 31), 0.0, 3), ((5, 1), 2.0, 0)])
+def test_blur_matches_independent_integer_form(shape, sigma, ksize):
+    img = synth.frame_np(*shape, kind="noise")
+    n = ksize or oracle.gauss_ksize_u8(sigma)
+    want = npref.blur_q8(img, oracle.gauss_taps_q8(n, sigma))
+    assert (oracle.gaussian_blur_u8(img, ksize, sigma) == want).all()
+
+
+def test_blur_close_to_float_gaussian():
+    # sanity vs an unrelated float implementation: 8.8 tap quantisation + one rounding stay within 2 grey levels
+    from scipy import ndimage
+
+    img = synth.frame_np(64, 96, kind="noise")
+    s = 2.5398416831491195
+    n = oracle.gauss_ksize_u8(s)
+    ref = ndimage.gaussian_filter(img.astype(np.float64), s, mode="mirror", truncate=(n // 2 + 0.5) / s)
+    got = oracle.gaussian_blur_u8(img, 0, s).astype(np.float64)
+    assert np.abs(got - ref).max() <= 2.0 and np.abs(got - ref).mean() < 0.5
+
+
+def test_sobel_k1():
+    img = synth.frame_np(17, 23, kind="noise")
+    gx, gy = oracle.sobel_k1(img, 1, 0), oracle.sobel_k1(img, 0, 1)
+    a = img.astype(np.int64)
+    assert (gx[:, 1:-1] == a[:, 2:] - a[:, :-2]).all() and (gy[1:-1] == a[2:] - a[:-2]).all()
+    # reflect-101 => zero on the outer ring
+    assert not gx[:, 0].any() and not gx[:, -1].any() and not gy[0].any() and not gy[-1].any()
+
+
+def test_resize_linear2x():
+    c = np.full((9, 13), 200, np.uint8)
+    assert (oracle.resize_linear2x(c) == 200).all()
+    img = synth.frame_np(21, 34, kind="noise")
+    got = oracle.resize_linear2x(img)
+    assert got.shape == (42, 68)
+    assert (got == npref.resize2x(img)).all()
+    # within one grey level of true bilinear with OpenCV's half-pixel centres
+    a = img.astype(np.float64)
+    ys = np.clip((np.arange(42) + 0.5) / 2 - 0.5, 0, 20)
+    xs = np.clip((np.arange(68) + 0.5) / 2 - 0.5, 0, 33)
+    y0, x0 = np.floor(ys).astype(int), np.floor(xs).astype(int)
+    y1, x1 = np.minimum(y0 + 1, 20), np.minimum(x0 + 1, 33)
+    fy, fx = (ys - y0)[:, None], (xs - x0)[None, :]
+    ref = (a[y0][:, x0] * (1 - fx) + a[y0][:, x1] * fx) * (1 - fy) + (a[y1][:, x0] * (1 - fx) + a[y1][:, x1] * fx) * fy
+    assert np.abs(got - ref).max() <= 1.0
+    one = np.array([[7]], np.uint8)
+    assert (oracle.resize_linear2x(one) == 7).all()
+
+
+def test_resize_nearest_half_sizes():
+    # round-half-even sizes (chessboard 877x620 -> 438x310)
+    assert oracle.half_size(620, 877) == (310, 438)
+    assert oracle.half_size(150, 217) == (75, 108)
+    img = synth.frame_np(15, 21, kind="noise")
+    got = oracle.resize_nearest_half(img)
+    assert got.shape == oracle.half_size(15, 21) == (8, 10)
+    yy = np.minimum(2 * np.arange(8), 14)
+    xx = np.minimum(2 * np.arange(10), 20)
+    assert (got == img[np.ix_(yy, xx)]).all()
+
+
+def test_convert_scale_abs_rounding():
+    x = np.array([[0.5, 1.5, 2.5, -3.5, 253.5, 254.5, 255.4, 255.5, 1e12, -1e12, 253.49]], np.float32)
+    assert oracle.convert_scale_abs(x).tolist() == [[0, 2, 2, 4, 254, 254, 255, 255, 255, 255, 253]]
+
+
+def test_pyramid_shape_known_answers():
+    # building.jpg is 868x600 (cols x rows): tests/GaussPyramid_Test.cpp:88-110, SURVEY section 4
+    img = synth.frame_np(600, 868, kind="noise")[:150, :217]  # geometry only needs the size chain
+    assert oracle.auto_num_octaves(600, 868) == 5
+    assert oracle.auto_num_octaves(256, 256) == 4 and oracle.auto_num_octaves(384, 512) == 4
+    assert oracle.auto_num_octaves(1240, 1754) == 6 and oracle.auto_num_octaves(1080, 1920) == 6
+    p = oracle.Pyramid(img, 4, 1.6)
+    assert p.n_octaves == 4 and p.sizes == [(300, 434), (150, 217), (75, 108), (38, 54)]
+    assert len(p.sigmas[3]) == 6 and p.sigmas[0][0] == 1.6
+    r, c = 1200, 1736
+    chain = []
+    for _ in range(4):
+        chain.append((c, r))
+        r, c = oracle.half_size(r, c)
+    assert chain == [(1736, 1200), (868, 600), (434, 300), (217, 150)]
+    assert oracle.extrema_lattice(2160, 3840) == (720, 1280)
+    lat = [oracle.extrema_lattice(2160 >> o, 3840 >> o) for o in range(4)]
+    assert sum(3 * a * b for a, b in lat) == 3_672_000
+
+
+def test_pyramid_structure_small():
+    img = synth.frame_np(45, 61)
+    p = oracle.Pyramid(img, 3, 1.6)
+    assert (p.base(0) == oracle.resize_linear2x(img)).all()
+    for o in range(3):
+        for l in range(6):
+            assert (p.gauss(o, l) == oracle.gaussian_blur_u8(p.base(o), 0, p.sigmas[o][l])).all()
+        for l in range(5):
+            a, b = p.gauss(o, l + 1).astype(int), p.gauss(o, l).astype(int)
+            assert (p.dog(o, l) == np.maximum(a - b, 0)).all()  # saturating, SURVEY D4
+        if o:
+            assert (p.base(o) == oracle.resize_nearest_half(p.gauss(o - 1, 3))).all()
+
+
+def test_constant_image_everything_zero_and_all_sites_candidates():
+    img = synth.frame_np(60, 80, kind="constant")
+    assert not oracle.harris_response(img).any()
+    p = oracle.Pyramid(img, 4, 1.6)
+    total = 0
+    for o in range(4):
+        for l in range(5):
+            assert not p.dog(o, l).any()
+        mask, pts = p.extrema(o, 3, 8)
+        assert mask.all() and len(pts) == 0
+        mask0, pts0 = p.extrema(o, 3, 0)
+        assert len(pts0) == mask0.size
+        total += mask0.size
+    lat = [oracle.extrema_lattice(*s) for s in p.sizes]
+    assert total == sum(3 * a * b for a, b in lat)
+
+
+def test_extrema_matches_vectorised_restatement_and_order():
+    img = synth.frame_np(50, 70)
+    p = oracle.Pyramid(img, 3, 1.6)
+    for o in range(3):
+        dogs = [p.dog(o, l) for l in range(5)]
+        want, ii, jj = npref.extrema_mask(dogs)
+        mask, pts = p.extrema(o, 3, 8)
+        assert (mask == want).all()
+        # list = candidates with value >= 8 in (level, i, j) order, padded coordinates
+        exp = []
+        for lv in (1, 2, 3):
+            for a, i in enumerate(ii):
+                for b, j in enumerate(jj):
+                    v = int(dogs[lv][i - 1, j - 1])
+                    if want[lv - 1, a, b] and v >= 8:
+                        exp.append((i, j, v, 1, o, lv))
+        assert [tuple(int(x) for x in q) for q in pts.tolist()] == exp
+
+
+@pytest.mark.parametrize("kind,shape", [("checker", (70, 90)), ("noise", (33, 47)), ("checker", (64, 64))])
+def test_harris_literal_equals_integer_form(kind, shape):
+    # the literal f32/f64 order of the reference == exact-integer evaluation
+    img = synth.frame_np(*shape, kind=kind)
+    assert (oracle.harris_response(img) == npref.harris_int(img)).all()
+
+
+def test_harris_checkerboard_maxima_at_intersections():
+    rows, cols = 96, 128
+    r = np.arange(rows)[:, None] // 32
+    c = np.arange(cols)[None, :] // 32
+    img = np.where(((r + c) & 1) == 1, 200, 56).astype(np.uint8)
+    R = oracle.harris_response(img)
+    n2, tmax = oracle.nms2(R, 5)
+    kps = oracle.harris_keypoints(n2)
+    assert len(kps) > 0 and tmax > 0
+    # every keypoint sits within 2 px of an interior cell corner
+    for k in kps:
+        dr = min(abs(k["row"] - y) for y in (32, 64))
+        dc = min(abs(k["col"] - x) for x in (32, 64, 96))
+        assert dr <= 2 and dc <= 2
+    strongest = np.unravel_index(np.argmax(R), R.shape)
+    assert min(abs(strongest[0] - y) for y in (32, 64)) <= 1 and min(abs(strongest[1] - x) for x in (32, 64, 96)) <= 1
+
+
+def test_nms_strict_and_nms2_semantics():
+    x = np.array([[5, 1, 5], [1, 1, 1], [9, 1, 9]], np.uint8)
+    m = oracle.nms_strict(x, 3)
+    assert m.tolist() == [[255, 0, 255], [0, 0, 0], [255, 0, 255]]
+    flat = np.full((4, 4), 3, np.uint8)
+    assert not oracle.nms_strict(flat, 3).any()  # strict > : plateaus are suppressed
+    assert (oracle.nms_strict(np.array([[4]], np.uint8), 3) == 255).all()
+    assert (oracle.nms_strict(np.array([[0]], np.uint8), 3) == 0).all()
+    f = np.zeros((7, 8), np.float32)
+    f[3, 3] = 10.0
+    f[3, 5] = 7.0  # outside the half-open 4x4 window of (3,3); (3,3) inside the window of (3,5)
+    f[5, 4] = 2.0
+    out, tmax = oracle.nms2(f, 5)
+    assert out[3, 3] == 10.0 and out[3, 5] == 0.0 and tmax == 10.0
+    assert out[5, 4] == 0.0  # window rows 3..6, cols 2..5 contains 10
+    assert out[2, 2] == 0.0 and not out[:2].any() and not out[-2:].any() and not out[:, :2].any() and not out[:, -2:].any()
+
+
+def test_synth_generators_agree():
+    a = synth.frames_np(2, 40, 72, stream_id=3, first_frame=5)
+    b = synth.frames_torch(2, 40, 72, stream_id=3, first_frame=5).numpy()
+    assert (a == b).all()
+    assert a.min() >= 40 and a.max() <= 215 and abs(int(a[0, 0, 0]) - 56) <= 16
