@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Harris + DoG keypoint detection on 1920x1080 frames (BASELINE.json).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--frames F]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the fused hot path (vslam_detect_batch_dev) over one batch of F
+synthetic 1080p frames per GPU (BASELINE config 4: F = 256).  Frames are generated on the
+device and are resident in HBM before the timed region.  Frames shard across ranks (one
+camera stream per GPU, weak scaling); the only collective is the RCCL all-gather of the
+per-rank keypoint counts.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s achievable
+
+# Algorithmic HBM bytes per frame attributed to each kernel of the batch (DESIGN.md
+# "Kernels"): the API-contract bytes the kernel is the one to read/write:
+# inputs read once, every returned image written once, intermediates not counted.  The
+# entries sum to 6N + 11*sumP = 133,617,600 B per 1080p frame.
+def kernel_algorithmic_bytes(L, rows, cols):
+    N = rows * cols
+    P = [L.rows[o] * L.cols[o] for o in range(L.n_octaves)]
+    return {
+        "k_harris_fused": 5 * N,          # u8 frame in, f32 response out
+        "k_harris_post": N,               # u8 NMS mask out
+        "k_resize_linear2x": N,           # DoG path's read of the frame
+        "k_blur_v_generic": 6 * sum(P),   # the six Gaussian images of every octave
+        "k_dog5": 5 * sum(P),             # the five DoG images of every octave
+    }
+
+
+def cpu_baseline(rows, cols, n_oct, sample_frames):
+    """Time the CPU oracle (single thread, like the reference) on a bounded sample."""
+    import numpy as np
+
+    import oracle
+    from visualslam_amd import synth
+
+    oracle.build()
+    frames = synth.frames_np(sample_frames, rows, cols, stream_id=0)
+    kp = 0
+    t0 = time.perf_counter()
+    for f in range(sample_frames):
+        R = oracle.harris_response(frames[f])
+        oracle.nms_strict(oracle.convert_scale_abs(R), 3)
+        kp += len(oracle.harris_keypoints(oracle.nms2(R, 5)[0]))
+        p = oracle.Pyramid(frames[f], n_oct, 1.6)
+        for o in range(n_oct):
+            kp += len(p.extrema(o, 3, 8)[1])
+        p.close()
+    dt = time.perf_counter() - t0
+    return {
+        "value": sample_frames / dt,
+        "unit": "frames/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"{sample_frames} synthetic {cols}x{rows} frames, Harris+NMS+DoG pyramid+extrema, oracle/vslam_oracle.c -O2, 1 thread",
+        "keypoints_per_sec": kp / dt,
+        "host_cpus": os.cpu_count(),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=256, help="frames per GPU per step (BASELINE config 4: 256)")
+    ap.add_argument("--rows", type=int, default=1080)
+    ap.add_argument("--cols", type=int, default=1920)
+    ap.add_argument("--octaves", type=int, default=4)
+    ap.add_argument("--kernel", default=None, help="kernel to time with HIP events for the roofline object")
+    ap.add_argument("--cpu-sample", type=int, default=6, help="frames in the CPU baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from visualslam_amd import capi, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if args.gpus != world and rank == 0:
+        print(f"note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+
+    capi.build()
+    rows, cols, n = args.rows, args.cols, args.frames
+    ctx = capi.Context(local_rank, torch.cuda.current_stream().cuda_stream)
+    p = capi.default_params(rows, cols, n_octaves=args.octaves)
+    L = capi.batch_layout(p)
+
+    # one camera stream per GPU: stream_id = rank
+    frames = synth.frames_torch(n, rows, cols, stream_id=rank, device=dev)
+    out = dict(
+        response=torch.empty((n, rows, cols), dtype=torch.float32, device=dev),
+        nms_mask=torch.empty((n, rows, cols), dtype=torch.uint8, device=dev),
+        harris_kps=torch.empty((n, p.harris_cap, 3), dtype=torch.int32, device=dev),
+        harris_counts=torch.zeros(n, dtype=torch.int32, device=dev),
+        pyramid=torch.empty((n, L.pyramid_frame_bytes), dtype=torch.uint8, device=dev),
+        extrema_bits=torch.empty((n, L.bits_frame_words), dtype=torch.int64, device=dev),
+        dog_points=torch.empty((n, p.dog_cap, 6), dtype=torch.int32, device=dev),
+        dog_counts=torch.zeros(n, dtype=torch.int32, device=dev),
+    )
+    counts_local = torch.zeros(2, dtype=torch.int64, device=dev)
+    counts_all = torch.zeros((world, 2), dtype=torch.int64, device=dev)
+
+    def step():
+        ctx.detect_batch(p, frames, **out)
+        counts_local[0] = out["harris_counts"].sum()
+        counts_local[1] = out["dog_counts"].sum()
+        if world > 1:  # the one collective of the path: 16 B per rank over RCCL
+            dist.all_gather_into_tensor(counts_all.view(-1), counts_local)
+        else:
+            counts_all[0] = counts_local
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    algo = kernel_algorithmic_bytes(L, rows, cols)
+    kname = args.kernel or "k_blur_v_generic"
+    fence()
+    ctx.kernel_timing_enable(kname)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    launches, kms = ctx.kernel_timing_read()
+    ctx.kernel_timing_enable(None)
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    totals = counts_all.sum(0).tolist()
+    overflow = bool((out["harris_counts"] > p.harris_cap).any() or (out["dog_counts"] > p.dog_cap).any())
+
+    if rank == 0:
+        total_frames = n * world * args.steps
+        fps = total_frames / dt
+        kp_per_step = totals[0] + totals[1]
+        bytes_frame = L.algorithmic_bytes_harris + L.algorithmic_bytes_dog - rows * cols  # fused: input counted once
+        roof = None
+        if launches and kms > 0:
+            ach = algo.get(kname, 0) * n * args.steps / (kms * 1e-3) / 1e9
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tpath):
+                traffic = json.load(open(tpath)).get(kname)
+            roof = {
+                "kernel": kname, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": ach / HBM_PEAK_GBPS, "traffic": traffic,
+                "launches": launches, "avg_launch_ms": kms / launches,
+                "algorithmic_bytes_per_frame": algo.get(kname, 0),
+            }
+        line = {
+            "metric": "frames/sec @1080p (Harris + DoG keypoint detection)",
+            "value": fps,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {
+                "workload": f"batch of {n} synthetic {cols}x{rows} frames per GPU, Harris(k=0.04)+NMS and DoG pyramid "
+                            f"{args.octaves} octaves x (6 Gaussian, 5 DoG) + extrema, fused (BASELINE config 4)",
+                "frames_per_gpu": n, "rows": rows, "cols": cols, "octaves": args.octaves,
+                "parallelism": f"frames sharded 1 stream/GPU x{world}; RCCL all-gather of counts only",
+            },
+            "keypoints_per_sec": kp_per_step * args.steps / dt,
+            "keypoints_per_step": {"harris": totals[0], "dog": totals[1], "list_overflow": overflow},
+            "pipeline_hbm": {
+                "algorithmic_bytes_per_frame": bytes_frame,
+                "achieved_GBps": bytes_frame * fps / world / 1e9,
+                "frac_of_peak": bytes_frame * fps / world / 1e9 / HBM_PEAK_GBPS,
+            },
+            "roofline": roof,
+            "cpu_baseline": cpu_baseline(rows, cols, args.octaves, args.cpu_sample) if (world == 1 and args.cpu_sample > 0) else None,
+        }
+        print(json.dumps(line))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,247 @@
+/*
+ * vslam.h -- C ABI of the MI355X-native keypoint-detection front end.
+ *
+ * The reference (JacobYoung115/VisualSLAM, KeyPointDetection/) has no FFI layer: its hot
+ * path is plain C++ functions over cv::Mat.  This header is the
+ * drop-in boundary a maintainer binds instead: every entry point names the reference
+ * function / OpenCV call site it replaces (paths relative to KeyPointDetection/).
+ * The C++ mirror of the reference signatures (HarrisCorner, NMS2, GaussPyramid,
+ * initialKeypointDetection ...) sits on top of this ABI in visualslam_amd/cxx/.
+ *
+ * Conventions
+ *   - extern "C", plain pointers + sizes, int status return (0 = VSLAM_OK, negative =
+ *     error); no exceptions cross the ABI; vslam_last_error(ctx) gives the message.
+ *   - Images are row-major, `step` = bytes between rows (cv::Mat::step).
+ *   - "host" entry points take host pointers, copy in/out and are synchronous.
+ *     "_dev" entry points take DEVICE pointers, are asynchronous on the context's HIP
+ *     stream and never synchronise: they are the path bench.py measures.
+ *   - One context per GPU/stream.  A context is not thread-safe; distinct contexts are
+ *     independent.  All kernels are hand-written HIP for gfx950; there is no CPU
+ *     fallback: without a GPU every compute entry point fails with VSLAM_ERR_HIP.
+ *   - Semantics ("intended" vs "literal" for the reference's defects) follow SURVEY.md
+ *     Appendix B and are restated per function below.
+ */
+#ifndef VSLAM_H
+#define VSLAM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VSLAM_VERSION 100 /* 0.1.0 */
+
+enum {
+    VSLAM_OK = 0,
+    VSLAM_ERR_INVALID = -1,     /* bad argument (null pointer, non-positive size, even window ...) */
+    VSLAM_ERR_HIP = -2,         /* a HIP runtime call or kernel launch failed (incl. no GPU) */
+    VSLAM_ERR_NOMEM = -3,       /* device or host allocation failed */
+    VSLAM_ERR_UNSUPPORTED = -4, /* parameter combination not implemented */
+    VSLAM_ERR_RANGE = -5        /* octave / level index out of range */
+};
+
+#define VSLAM_MAX_OCTAVES 16
+#define VSLAM_NUM_LEVELS 6 /* scaleSamples_ + 3, include/src/GaussPyramid/GaussPyramid.hpp:65-66 */
+#define VSLAM_NUM_DOGS 5   /* include/src/GaussPyramid/GaussPyramid.cpp:193 */
+
+typedef struct vslam_ctx vslam_ctx;
+typedef struct vslam_pyramid vslam_pyramid;
+
+/* Binary-compatible with SLAM::point (Diff_of_Gauss.cpp:27-35): six ints, 24 bytes.
+ * row/col are in 1-padded coordinates exactly as the reference produces them (:289). */
+typedef struct {
+    int32_t row, col, value, padding, octave, level;
+} vslam_point;
+
+/* Harris keypoint: NMS2 survivor whose 8-bit view exceeds 253 (Harris_corners.cpp:139,181). */
+typedef struct {
+    int32_t row, col;
+    float response;
+} vslam_kp;
+
+/* ---------------------------------------------------------------- lifecycle */
+
+int vslam_version(void);
+const char* vslam_status_string(int status);
+
+/* device: HIP device ordinal.  stream: an existing hipStream_t to launch on (e.g.
+ * torch.cuda.current_stream().cuda_stream) or NULL to let the context own one. */
+int vslam_ctx_create(int device, void* stream, vslam_ctx** out);
+int vslam_ctx_destroy(vslam_ctx* ctx);
+int vslam_ctx_sync(vslam_ctx* ctx);
+const char* vslam_last_error(const vslam_ctx* ctx);
+
+/* ------------------------------------------ host-side parameter helpers (no GPU) */
+
+/* Kernel width cv::GaussianBlur derives for CV_8U when ksize = Size(0,0):
+ * cvRound(sigma*6+1)|1  (call site GaussPyramid.cpp:177). */
+int vslam_gauss_ksize_u8(double sigma);
+/* The 8.8 fixed-point taps cv::GaussianBlur uses on CV_8U (sum == 256); taps[n]. */
+int vslam_gauss_taps_q8(int n, double sigma, uint16_t* taps);
+/* GaussPyramid::calculateSigma(octave, level), GaussPyramid.cpp:160-162. */
+double vslam_sigma_at(double sigma0, int octave, int level);
+/* GaussPyramid::calculateNumOctaves, GaussPyramid.cpp:150-152. */
+int vslam_auto_num_octaves(int rows, int cols);
+/* Size cv::resize(..., 0.5, 0.5, INTER_NEAREST) produces (GaussPyramid.cpp:126). */
+void vslam_half_size(int rows, int cols, int* out_rows, int* out_cols);
+/* Lattice of initialKeypointDetection (Diff_of_Gauss.cpp:267-268): sites
+ * i = pad, pad+window, ... < rows (likewise cols). */
+void vslam_extrema_lattice(int rows, int cols, int window, int* lat_rows, int* lat_cols);
+
+/* ------------------------------------------------- host-buffer primitives (GPU) */
+
+/* cv::GaussianBlur(src, dst, Size(ksize,ksize) or Size(0,0), sigma, 0, BORDER_DEFAULT)
+ * on CV_8U: Harris_corners.cpp:158, GaussPyramid.cpp:177. */
+int vslam_gaussian_blur_u8(vslam_ctx* ctx, const uint8_t* src, int rows, int cols, size_t step, int ksize,
+                           double sigma, uint8_t* dst, size_t dst_step);
+/* cv::Sobel(src, dst, CV_32F, dx, dy, ksize=1, 1, 0, BORDER_DEFAULT):
+ * Harris_corners.cpp:163-164, GaussPyramid.cpp:87,90.  (dx,dy) = (1,0) or (0,1). */
+int vslam_sobel_k1_u8_f32(vslam_ctx* ctx, const uint8_t* src, int rows, int cols, size_t step, int dx, int dy,
+                          float* dst, size_t dst_step);
+/* cv::resize(src, dst, Size(), 2, 2, INTER_LINEAR), GaussPyramid.cpp:110. */
+int vslam_resize_linear2x_u8(vslam_ctx* ctx, const uint8_t* src, int rows, int cols, size_t step, uint8_t* dst,
+                             size_t dst_step);
+/* cv::resize(src, dst, Size(), 0.5, 0.5, INTER_NEAREST), GaussPyramid.cpp:126. */
+int vslam_resize_nearest_half_u8(vslam_ctx* ctx, const uint8_t* src, int rows, int cols, size_t step,
+                                 uint8_t* dst, size_t dst_step);
+/* cv::convertScaleAbs(src f32, dst u8), Harris_corners.cpp:176,181.  Saturating. */
+int vslam_convert_scale_abs_f32(vslam_ctx* ctx, const float* src, int rows, int cols, size_t step, uint8_t* dst,
+                                size_t dst_step);
+
+/* --------------------------------------------------------------- Harris (host) */
+
+/* Mat HarrisCorner(Mat& Ix, Mat& Iy), Harris_corners.cpp:31-68 (with StructureMatrix
+ * :10-29): arbitrary f32 gradients, literal f32 accumulation order, double determinant.
+ * Intended rows x cols output (Appendix B-1).  Reference literals: k=0.04f, window=3. */
+int vslam_harris_from_grad_f32(vslam_ctx* ctx, const float* ix, const float* iy, int rows, int cols,
+                               size_t step, float k, int window, float* resp, size_t resp_step);
+/* Front end of Harris main(): GaussianBlur 3x3 -> Sobel x,y -> HarrisCorner
+ * (Harris_corners.cpp:158-172) as ONE fused kernel over the 8-bit frame. window must be 3. */
+int vslam_harris_response_u8(vslam_ctx* ctx, const uint8_t* img, int rows, int cols, size_t step, float k,
+                             int window, float* resp, size_t resp_step);
+/* Mat NonMaximumSuppression(Mat& response, int windowSize), Harris_corners.cpp:70-81:
+ * mask(255/0) = response > max(neighbours, centre excluded).  windowSize odd. */
+int vslam_nms_strict_u8(vslam_ctx* ctx, const uint8_t* src, int rows, int cols, size_t step, int window,
+                        uint8_t* mask, size_t mask_step);
+int vslam_nms_strict_f32(vslam_ctx* ctx, const float* src, int rows, int cols, size_t step, int window,
+                         uint8_t* mask, size_t mask_step);
+/* Mat NMS2(Mat& response, int windowSize), Harris_corners.cpp:83-129: half-open window
+ * (literal, Appendix B-4), f32 map out (intended, B-3).  true_max (may be NULL) receives
+ * the value the reference prints at :127. */
+int vslam_nms2_f32(vslam_ctx* ctx, const float* resp, int rows, int cols, size_t step, int window, float* out,
+                   size_t out_step, float* true_max);
+/* Whole Harris executable minus display: response -> NMS2(5) -> 8-bit view > 253
+ * (Harris_corners.cpp:158-182).  Row-major keypoint list; *count = total found (may
+ * exceed cap; only cap entries are written). */
+int vslam_harris_keypoints_u8(vslam_ctx* ctx, const uint8_t* img, int rows, int cols, size_t step, float k,
+                              vslam_kp* out, size_t cap, size_t* count);
+
+/* ------------------------------------------------------------ DoG pyramid (host) */
+
+typedef struct {
+    int n_octaves;
+    int n_levels; /* 6 */
+    int n_dogs;   /* 5 */
+    double sigma0;
+    int rows[VSLAM_MAX_OCTAVES], cols[VSLAM_MAX_OCTAVES];
+    double sigma[VSLAM_MAX_OCTAVES][VSLAM_NUM_LEVELS];
+    int ksize[VSLAM_MAX_OCTAVES][VSLAM_NUM_LEVELS];
+} vslam_pyramid_info;
+
+/* GaussPyramid(Mat& img, int numOctaves, double sigma) -> createPyramid
+ * (GaussPyramid.hpp:17, GaussPyramid.cpp:106-131): 2x bilinear base, per octave 6
+ * Gaussians (each blurred from the octave base, :166-185) and 5 saturating DoGs
+ * (:191-200), next base = Gaussian[3] decimated (:123-126).  The images stay in HBM;
+ * the getters copy one image to the host.  n_octaves <= 0 selects the automatic count
+ * of the second constructor (GaussPyramid.hpp:18-21). */
+int vslam_pyramid_build_u8(vslam_ctx* ctx, const uint8_t* img, int rows, int cols, size_t step, int n_octaves,
+                           double sigma0, vslam_pyramid** out);
+int vslam_pyramid_destroy(vslam_pyramid* pyr);
+int vslam_pyramid_get_info(const vslam_pyramid* pyr, vslam_pyramid_info* out);
+/* octaveImage / octaveBlur / octaveDiff (GaussPyramid.hpp:29,31,32). */
+int vslam_pyramid_get_base(const vslam_pyramid* pyr, int octave, uint8_t* dst, size_t dst_step);
+int vslam_pyramid_get_gauss(const vslam_pyramid* pyr, int octave, int level, uint8_t* dst, size_t dst_step);
+int vslam_pyramid_get_dog(const vslam_pyramid* pyr, int octave, int level, uint8_t* dst, size_t dst_step);
+
+/* void initialKeypointDetection(vector<SLAM::point>&, GaussPyramid&, int octave, int
+ * windowSize), Diff_of_Gauss.cpp:254-297, up to the FeaturePointLocalization call.
+ * Literal stride-`window` lattice and half-open window (Appendix B-7), padded
+ * coordinates (B-8).
+ *   bits (may be NULL): candidate bitmask, 3 levels x lat_rows x words_per_row uint64
+ *     words, words_per_row = (lat_cols+63)/64, bit (lj & 63) of word
+ *     [((level-1)*lat_rows + li)*words_per_row + lj/64].
+ *   out/cap/count: candidates with value >= min_contrast in the reference's loop order
+ *     (level, i, j); *count = total (may exceed cap). */
+int vslam_dog_extrema(vslam_ctx* ctx, const vslam_pyramid* pyr, int octave, int window, int min_contrast,
+                      uint64_t* bits, vslam_point* out, size_t cap, size_t* count);
+
+/* ------------------------------------------- device-resident batched detection */
+
+typedef struct {
+    int rows, cols;      /* frame size */
+    int n_octaves;       /* DoG octaves (reference literal 4, Diff_of_Gauss.cpp:742); 0 = no DoG */
+    double sigma0;       /* 1.6, Diff_of_Gauss.cpp:743 */
+    float harris_k;      /* 0.04f, Harris_corners.cpp:36 */
+    int do_harris;       /* run the Harris path */
+    int extrema_window;  /* 3, Diff_of_Gauss.cpp:772 */
+    int min_contrast;    /* list threshold on the 8-bit DoG value; 8 */
+    uint32_t harris_cap; /* per-frame capacity of the Harris keypoint list */
+    uint32_t dog_cap;    /* per-frame capacity of the DoG point list */
+} vslam_params;
+
+/* Byte layout of the per-frame output blocks, so that a caller can allocate them. */
+typedef struct {
+    int n_octaves;
+    int rows[VSLAM_MAX_OCTAVES], cols[VSLAM_MAX_OCTAVES];
+    int lat_rows[VSLAM_MAX_OCTAVES], lat_cols[VSLAM_MAX_OCTAVES], lat_words[VSLAM_MAX_OCTAVES];
+    /* pyramid block of one frame: for octave o, Gaussian l at octave_offset[o] + l*P_o and
+     * DoG l at octave_offset[o] + (6+l)*P_o, P_o = rows[o]*cols[o], dense rows. */
+    size_t octave_offset[VSLAM_MAX_OCTAVES];
+    size_t pyramid_frame_bytes;
+    /* candidate bitmask block of one frame: octave o starts at word bits_offset[o] */
+    size_t bits_offset[VSLAM_MAX_OCTAVES];
+    size_t bits_frame_words;
+    /* algorithmic HBM bytes per frame: input + response + mask +
+     * Gaussian and DoG stacks */
+    size_t algorithmic_bytes_harris, algorithmic_bytes_dog;
+} vslam_batch_layout;
+
+/* Device pointers; any may be NULL to skip that output (it is then neither computed
+ * for its own sake nor written). */
+typedef struct {
+    float* response;         /* [n][rows][cols]  HarrisCorner output */
+    uint8_t* nms_mask;       /* [n][rows][cols]  NonMaximumSuppression(8-bit view, 3) */
+    float* nms2;             /* [n][rows][cols]  NMS2(response, 5) map (optional) */
+    vslam_kp* harris_kps;    /* [n][harris_cap] */
+    uint32_t* harris_counts; /* [n] totals (may exceed cap) */
+    uint8_t* pyramid;        /* [n][pyramid_frame_bytes] */
+    uint64_t* extrema_bits;  /* [n][bits_frame_words] */
+    vslam_point* dog_points; /* [n][dog_cap], order (octave, level, i, j) */
+    uint32_t* dog_counts;    /* [n] totals (may exceed cap) */
+} vslam_batch_out;
+
+void vslam_params_default(vslam_params* p, int rows, int cols);
+/* Pure host computation (no GPU needed). */
+int vslam_batch_layout_query(const vslam_params* p, vslam_batch_layout* out);
+/* Harris + DoG over n frames already resident in HBM (frame f at d_frames +
+ * f*frame_stride, dense rows).  Asynchronous on the context stream.  This is the fused
+ * path of BASELINE config 4: every frame is read from HBM once per path and every
+ * output written once; frames are independent, so a multi-GPU job shards frames across
+ * ranks with no data-path collective. */
+int vslam_detect_batch_dev(vslam_ctx* ctx, const vslam_params* p, const uint8_t* d_frames, size_t frame_stride,
+                           int n_frames, const vslam_batch_out* out);
+
+/* Timing hook for bench.py: when enabled, the context brackets every launch of the
+ * named kernel with HIP events on its stream; vslam_kernel_timing_read synchronises and
+ * returns launches and total milliseconds since the last reset. */
+int vslam_kernel_timing_enable(vslam_ctx* ctx, const char* kernel_name);
+int vslam_kernel_timing_read(vslam_ctx* ctx, int* launches, double* total_ms);
+/* Names of the kernels a batch launches, '\n'-separated (for profiles and the hook). */
+const char* vslam_kernel_names(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

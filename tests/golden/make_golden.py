@@ -1,0 +1,55 @@
+"""Generate the committed golden vectors from the CPU oracle.
+
+The reference has no golden data and cannot be built here (no OpenCV), so these vectors are
+outputs of oracle/vslam_oracle.c on seeded synthetic inputs.
+They pin the oracle against accidental change and give the GPU parity tests fixed targets.
+
+    python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+import oracle  # noqa: E402
+from visualslam_amd import synth  # noqa: E402
+
+CASES = {
+    # name: (rows, cols, kind, stream_id, octaves)
+    "checker_48x64": (48, 64, "checker", 1, 3),
+    "noise_40x56": (40, 56, "noise", 2, 3),
+    "checker_33x47": (33, 47, "checker", 3, 2),  # odd sizes: ragged tiles, half-even size chain
+}
+
+
+def make(name):
+    rows, cols, kind, sid, n_oct = CASES[name]
+    img = synth.frame_np(rows, cols, 0, sid, kind)
+    d = {"img": img}
+    R = oracle.harris_response(img)
+    d["response"] = R
+    d["nms_mask"] = oracle.nms_strict(oracle.convert_scale_abs(R), 3)
+    n2, tmax = oracle.nms2(R, 5)
+    d["nms2"] = n2
+    d["nms2_true_max"] = np.float32(tmax)
+    d["harris_kps"] = oracle.harris_keypoints(n2)
+    p = oracle.Pyramid(img, n_oct, 1.6)
+    d["n_octaves"] = np.int32(n_oct)
+    for o in range(n_oct):
+        d[f"base_{o}"] = p.base(o)
+        d[f"gauss_{o}"] = np.stack([p.gauss(o, l) for l in range(6)])
+        d[f"dog_{o}"] = np.stack([p.dog(o, l) for l in range(5)])
+        m, pts = p.extrema(o, 3, 8)
+        d[f"ext_mask_{o}"] = m
+        d[f"ext_pts_{o}"] = pts
+    return d
+
+
+if __name__ == "__main__":
+    here = os.path.dirname(os.path.abspath(__file__))
+    for name in CASES:
+        np.savez_compressed(os.path.join(here, name + ".npz"), **make(name))
+        print("wrote", name)

@@ -1,0 +1,97 @@
+"""C-ABI checks that need no GPU: the library loads, exports every symbol include/vslam.h
+declares, its host-side parameter helpers agree with the oracle, and compute entry points
+fail loudly (no CPU fallback) when there is no HIP device."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle
+from visualslam_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    capi.build()
+    return capi.lib()
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "vslam.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(vslam_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    names = declared_symbols()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/vslam.h but not exported"
+    assert set(names) == set(capi.SIGNATURES), "capi.SIGNATURES out of sync with include/vslam.h"
+    assert lib.vslam_version() == 100
+    assert b"k_harris_fused" in lib.vslam_kernel_names()
+
+
+def test_struct_sizes_match_reference_types():
+    assert capi.POINT_DTYPE.itemsize == 24 == oracle.POINT_DTYPE.itemsize  # SLAM::point, six ints
+    assert capi.KP_DTYPE.itemsize == 12
+
+
+def test_host_helpers_match_oracle(lib):
+    for o in range(5):
+        for l in range(6):
+            s = capi.sigma_at(1.6, o, l)
+            assert s == oracle.sigma_at(1.6, o, l)
+            n = capi.gauss_ksize_u8(s)
+            assert n == oracle.gauss_ksize_u8(s)
+            assert (capi.gauss_taps_q8(n, s) == oracle.gauss_taps_q8(n, s)).all()
+    for n in (1, 3, 5, 7, 9):
+        assert (capi.gauss_taps_q8(n, 0.0) == oracle.gauss_taps_q8(n, 0.0)).all()
+    with pytest.raises(capi.VslamError):
+        capi.gauss_taps_q8(4, 1.0)
+    for r, c in [(1080, 1920), (620, 877), (150, 217), (3, 5), (1, 1)]:
+        assert capi.half_size(r, c) == oracle.half_size(r, c)
+        assert capi.extrema_lattice(r, c, 3) == oracle.extrema_lattice(r, c, 3)
+        assert capi.extrema_lattice(r, c, 5) == oracle.extrema_lattice(r, c, 5)
+    for r, c in [(256, 256), (384, 512), (600, 868), (1240, 1754), (1080, 1920)]:
+        assert capi.auto_num_octaves(r, c) == oracle.auto_num_octaves(r, c)
+
+
+def test_batch_layout_1080p(lib):
+    p = capi.default_params(1080, 1920)
+    assert (p.n_octaves, p.sigma0, p.extrema_window, p.min_contrast) == (4, 1.6, 3, 8)
+    assert abs(p.harris_k - 0.04) < 1e-9
+    L = capi.batch_layout(p)
+    assert [(L.rows[o], L.cols[o]) for o in range(4)] == [(2160, 3840), (1080, 1920), (540, 960), (270, 480)]
+    # SURVEY section 8d algorithmic bytes
+    assert L.algorithmic_bytes_harris == 12_441_600
+    assert L.algorithmic_bytes_dog == 123_249_600
+    assert L.pyramid_frame_bytes >= 11 * 11_016_000 and L.pyramid_frame_bytes % 256 == 0
+    assert sum(3 * L.lat_rows[o] * L.lat_cols[o] for o in range(4)) == 3_672_000
+    assert L.octave_offset[1] == 11 * 2160 * 3840
+    bad = capi.default_params(0, 10)
+    with pytest.raises(capi.VslamError):
+        capi.batch_layout(bad)
+
+
+def test_no_gpu_means_loud_failure(lib):
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(capi.VslamError) as e:
+        capi.Context(0)
+    assert e.value.status == -2  # VSLAM_ERR_HIP: there is no CPU fallback
+
+
+def test_null_arguments_are_rejected_without_touching_the_gpu(lib):
+    assert lib.vslam_ctx_create(0, None, None) == -1
+    assert lib.vslam_ctx_destroy(None) == -1
+    assert lib.vslam_gauss_taps_q8(3, 0.0, None) == -1
+    assert lib.vslam_pyramid_destroy(None) == -1
+    assert lib.vslam_batch_layout_query(None, None) == -1
+    assert lib.vslam_last_error(None) == b"null context"

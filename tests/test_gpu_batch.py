@@ -1,0 +1,169 @@
+"""Parity of the device-resident batched path (vslam_detect_batch_dev) -- the path bench.py
+measures -- against the CPU oracle, frame by frame, plus size-independent properties at the
+full BASELINE sizes."""
+import numpy as np
+import pytest
+
+import oracle
+from visualslam_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+
+    capi.build()
+    ctx = capi.Context(0, torch.cuda.current_stream().cuda_stream)
+    yield ctx, torch
+    ctx.close()
+
+
+def run_batch(ctx, torch, frames_np, with_nms2=True, **pkw):
+    n, rows, cols = frames_np.shape
+    p = capi.default_params(rows, cols, **pkw)
+    L = capi.batch_layout(p)
+    dev = "cuda:0"
+    frames = torch.from_numpy(frames_np).to(dev)
+    o = dict(
+        response=torch.empty((n, rows, cols), dtype=torch.float32, device=dev),
+        nms_mask=torch.empty((n, rows, cols), dtype=torch.uint8, device=dev),
+        nms2=torch.empty((n, rows, cols), dtype=torch.float32, device=dev) if with_nms2 else None,
+        harris_kps=torch.zeros((n, p.harris_cap, 3), dtype=torch.int32, device=dev),
+        harris_counts=torch.zeros(n, dtype=torch.int32, device=dev),
+        pyramid=torch.empty((n, L.pyramid_frame_bytes), dtype=torch.uint8, device=dev),
+        extrema_bits=torch.zeros((n, max(L.bits_frame_words, 1)), dtype=torch.int64, device=dev),
+        dog_points=torch.zeros((n, p.dog_cap, 6), dtype=torch.int32, device=dev),
+        dog_counts=torch.zeros(n, dtype=torch.int32, device=dev),
+    )
+    ctx.detect_batch(p, frames, **o)
+    torch.cuda.synchronize()
+    return p, L, {k: (v.cpu().numpy() if v is not None else None) for k, v in o.items()}
+
+
+def check_frame(p, L, out, f, img, n_oct):
+    R = oracle.harris_response(img)
+    assert out["response"][f].tobytes() == R.tobytes()
+    assert (out["nms_mask"][f] == oracle.nms_strict(oracle.convert_scale_abs(R), 3)).all()
+    n2, _ = oracle.nms2(R, 5)
+    if out["nms2"] is not None:
+        assert out["nms2"][f].tobytes() == n2.tobytes()
+    kps = oracle.harris_keypoints(n2)
+    assert out["harris_counts"][f] == len(kps)
+    m = min(len(kps), p.harris_cap)
+    got = out["harris_kps"][f][:m].copy().view(capi.KP_DTYPE).reshape(-1)
+    assert got.tobytes() == kps[:m].tobytes()
+    want = oracle.Pyramid(img, n_oct, p.sigma0)
+    block = out["pyramid"][f]
+    all_pts = []
+    for o in range(n_oct):
+        r, c = want.sizes[o]
+        assert (L.rows[o], L.cols[o]) == (r, c)
+        P = r * c
+        off = L.octave_offset[o]
+        for l in range(6):
+            assert (block[off + l * P: off + (l + 1) * P].reshape(r, c) == want.gauss(o, l)).all(), ("gauss", o, l)
+        for l in range(5):
+            assert (block[off + (6 + l) * P: off + (7 + l) * P].reshape(r, c) == want.dog(o, l)).all(), ("dog", o, l)
+        wm, wp = want.extrema(o, p.extrema_window, p.min_contrast)
+        lr, lc, wpr = L.lat_rows[o], L.lat_cols[o], L.lat_words[o]
+        words = out["extrema_bits"][f][L.bits_offset[o]: L.bits_offset[o] + 3 * lr * wpr].view(np.uint64)
+        gm = np.unpackbits(words.view(np.uint8).reshape(3, lr, wpr * 8), axis=-1, bitorder="little")[..., :lc]
+        assert (gm == wm).all(), ("mask", o)
+        all_pts.append(wp)
+    allp = np.concatenate(all_pts)
+    assert out["dog_counts"][f] == len(allp)
+    m = min(len(allp), p.dog_cap)
+    got = out["dog_points"][f][:m].copy().view(capi.POINT_DTYPE).reshape(-1)
+    assert got.tobytes() == allp[:m].tobytes()
+    want.close()
+
+
+def test_batch_small_frames_all_outputs(env):
+    ctx, torch = env
+    frames = synth.frames_np(11, 96, 160, stream_id=7)  # 11 > chunk of 8: exercises chunking
+    frames[3] = synth.frame_np(96, 160, kind="noise")
+    frames[5] = synth.frame_np(96, 160, kind="constant")
+    p, L, out = run_batch(ctx, torch, frames, n_octaves=3)
+    for f in range(frames.shape[0]):
+        check_frame(p, L, out, f, frames[f], 3)
+
+
+def test_batch_ragged_size_and_small_caps(env):
+    ctx, torch = env
+    frames = synth.frames_np(2, 75, 131, stream_id=9)
+    p, L, out = run_batch(ctx, torch, frames, n_octaves=2, harris_cap=5, dog_cap=7, min_contrast=0)
+    for f in range(2):
+        check_frame(p, L, out, f, frames[f], 2)
+
+
+def test_config1_640x480_plumbing(env):
+    # BASELINE config 1: 640x480 grayscale frame, Harris k=0.04 (synthetic, seed 0x5EED0001)
+    ctx, torch = env
+    frames = synth.frames_np(1, 480, 640, stream_id=1)
+    p, L, out = run_batch(ctx, torch, frames)
+    check_frame(p, L, out, 0, frames[0], 4)
+
+
+def test_config2_and_3_full_1080p_frame(env):
+    # BASELINE configs 2+3: one 1920x1080 frame, Harris+NMS indices and the 4x(6,5) pyramid +
+    # extrema, bit-exact against the oracle
+    ctx, torch = env
+    frames = synth.frames_np(1, 1080, 1920, stream_id=0)
+    p, L, out = run_batch(ctx, torch, frames, with_nms2=False)
+    check_frame(p, L, out, 0, frames[0], 4)
+
+
+def test_full_size_batch_properties(env):
+    # size-independent properties on a 1080p batch (no oracle run per frame):
+    #  - identical frames give identical outputs wherever they sit in the batch (chunking,
+    #    frame strides); constant frames give zero response / zero DoG / all-candidate masks
+    #    (3,672,000 sites) and empty lists
+    ctx, torch = env
+    n = 10
+    base = synth.frames_np(2, 1080, 1920, stream_id=2)
+    frames = np.empty((n, 1080, 1920), np.uint8)
+    frames[0::3] = base[0]
+    frames[1::3] = base[1]
+    frames[2::3] = 128
+    p, L, out = run_batch(ctx, torch, frames, with_nms2=False)
+    for f in range(3, n):
+        for k in ("response", "nms_mask", "pyramid", "extrema_bits"):
+            assert out[k][f].tobytes() == out[k][f % 3].tobytes(), (k, f)
+        assert out["harris_counts"][f] == out["harris_counts"][f % 3]
+        assert out["dog_counts"][f] == out["dog_counts"][f % 3]
+        m = out["dog_counts"][f]
+        assert out["dog_points"][f][:m].tobytes() == out["dog_points"][f % 3][:m].tobytes()
+    c = 2
+    assert not out["response"][c].any() and not out["nms_mask"][c].any()
+    assert out["harris_counts"][c] == 0 and out["dog_counts"][c] == 0
+    sites = 0
+    for o in range(4):
+        P = L.rows[o] * L.cols[o]
+        off = L.octave_offset[o]
+        assert (out["pyramid"][c][off: off + 6 * P] == 128).all()
+        assert not out["pyramid"][c][off + 6 * P: off + 11 * P].any()
+        lr, lc, wpr = L.lat_rows[o], L.lat_cols[o], L.lat_words[o]
+        w = out["extrema_bits"][c][L.bits_offset[o]: L.bits_offset[o] + 3 * lr * wpr].view(np.uint64)
+        sites += int(np.unpackbits(w.view(np.uint8)).sum())
+    assert sites == 3_672_000
+    # DoG is the saturating difference of adjacent Gaussians, everywhere
+    blk = out["pyramid"][0]
+    for o in range(4):
+        P = L.rows[o] * L.cols[o]
+        off = L.octave_offset[o]
+        g = blk[off: off + 6 * P].reshape(6, P).astype(np.int16)
+        d = blk[off + 6 * P: off + 11 * P].reshape(5, P)
+        assert (d == np.maximum(g[1:] - g[:-1], 0)).all()
+
+
+def test_batch_argument_errors(env):
+    ctx, torch = env
+    frames = torch.zeros((1, 32, 32), dtype=torch.uint8, device="cuda:0")
+    p = capi.default_params(32, 32)
+    with pytest.raises(capi.VslamError):
+        ctx.detect_batch(p, frames)  # DoG requested but no pyramid buffer
+    bad = capi.default_params(32, 32, extrema_window=4)
+    with pytest.raises(capi.VslamError):
+        ctx.detect_batch(bad, frames, pyramid=torch.zeros(1 << 20, dtype=torch.uint8, device="cuda:0"))

@@ -1,0 +1,393 @@
+"""ctypes binding of the C ABI in include/vslam.h (visualslam_amd/lib/libvslam.so).
+
+This is plumbing only: argument marshalling for numpy (host entry points) and for torch
+CUDA tensors (device entry points).  All compute happens in the hand-written HIP kernels
+behind the ABI; there is no fallback -- if the library is missing or HIP cannot run, the
+calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvslam.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+MAX_OCTAVES = 16
+NUM_LEVELS = 6
+NUM_DOGS = 5
+
+POINT_DTYPE = np.dtype([(n, "<i4") for n in ("row", "col", "value", "padding", "octave", "level")], align=True)
+KP_DTYPE = np.dtype([("row", "<i4"), ("col", "<i4"), ("response", "<f4")], align=True)
+
+
+class VslamError(RuntimeError):
+    def __init__(self, status: int, what: str, detail: str = ""):
+        self.status = status
+        super().__init__(f"{what}: status {status} ({_status_string(status)}){': ' + detail if detail else ''}")
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("rows", C.c_int), ("cols", C.c_int), ("n_octaves", C.c_int), ("sigma0", C.c_double),
+        ("harris_k", C.c_float), ("do_harris", C.c_int), ("extrema_window", C.c_int),
+        ("min_contrast", C.c_int), ("harris_cap", C.c_uint32), ("dog_cap", C.c_uint32),
+    ]
+
+
+class BatchLayout(C.Structure):
+    _fields_ = [
+        ("n_octaves", C.c_int),
+        ("rows", C.c_int * MAX_OCTAVES), ("cols", C.c_int * MAX_OCTAVES),
+        ("lat_rows", C.c_int * MAX_OCTAVES), ("lat_cols", C.c_int * MAX_OCTAVES), ("lat_words", C.c_int * MAX_OCTAVES),
+        ("octave_offset", C.c_size_t * MAX_OCTAVES), ("pyramid_frame_bytes", C.c_size_t),
+        ("bits_offset", C.c_size_t * MAX_OCTAVES), ("bits_frame_words", C.c_size_t),
+        ("algorithmic_bytes_harris", C.c_size_t), ("algorithmic_bytes_dog", C.c_size_t),
+    ]
+
+
+class BatchOut(C.Structure):
+    _fields_ = [
+        ("response", C.c_void_p), ("nms_mask", C.c_void_p), ("nms2", C.c_void_p),
+        ("harris_kps", C.c_void_p), ("harris_counts", C.c_void_p),
+        ("pyramid", C.c_void_p), ("extrema_bits", C.c_void_p),
+        ("dog_points", C.c_void_p), ("dog_counts", C.c_void_p),
+    ]
+
+
+class PyramidInfo(C.Structure):
+    _fields_ = [
+        ("n_octaves", C.c_int), ("n_levels", C.c_int), ("n_dogs", C.c_int), ("sigma0", C.c_double),
+        ("rows", C.c_int * MAX_OCTAVES), ("cols", C.c_int * MAX_OCTAVES),
+        ("sigma", (C.c_double * NUM_LEVELS) * MAX_OCTAVES), ("ksize", (C.c_int * NUM_LEVELS) * MAX_OCTAVES),
+    ]
+
+
+# name -> (restype, argtypes); mirrors include/vslam.h one to one
+_P, _I, _Z, _D, _F = C.c_void_p, C.c_int, C.c_size_t, C.c_double, C.c_float
+SIGNATURES = {
+    "vslam_version": (_I, []),
+    "vslam_status_string": (C.c_char_p, [_I]),
+    "vslam_ctx_create": (_I, [_I, _P, C.POINTER(_P)]),
+    "vslam_ctx_destroy": (_I, [_P]),
+    "vslam_ctx_sync": (_I, [_P]),
+    "vslam_last_error": (C.c_char_p, [_P]),
+    "vslam_gauss_ksize_u8": (_I, [_D]),
+    "vslam_gauss_taps_q8": (_I, [_I, _D, _P]),
+    "vslam_sigma_at": (_D, [_D, _I, _I]),
+    "vslam_auto_num_octaves": (_I, [_I, _I]),
+    "vslam_half_size": (None, [_I, _I, C.POINTER(_I), C.POINTER(_I)]),
+    "vslam_extrema_lattice": (None, [_I, _I, _I, C.POINTER(_I), C.POINTER(_I)]),
+    "vslam_gaussian_blur_u8": (_I, [_P, _P, _I, _I, _Z, _I, _D, _P, _Z]),
+    "vslam_sobel_k1_u8_f32": (_I, [_P, _P, _I, _I, _Z, _I, _I, _P, _Z]),
+    "vslam_resize_linear2x_u8": (_I, [_P, _P, _I, _I, _Z, _P, _Z]),
+    "vslam_resize_nearest_half_u8": (_I, [_P, _P, _I, _I, _Z, _P, _Z]),
+    "vslam_convert_scale_abs_f32": (_I, [_P, _P, _I, _I, _Z, _P, _Z]),
+    "vslam_harris_from_grad_f32": (_I, [_P, _P, _P, _I, _I, _Z, _F, _I, _P, _Z]),
+    "vslam_harris_response_u8": (_I, [_P, _P, _I, _I, _Z, _F, _I, _P, _Z]),
+    "vslam_nms_strict_u8": (_I, [_P, _P, _I, _I, _Z, _I, _P, _Z]),
+    "vslam_nms_strict_f32": (_I, [_P, _P, _I, _I, _Z, _I, _P, _Z]),
+    "vslam_nms2_f32": (_I, [_P, _P, _I, _I, _Z, _I, _P, _Z, C.POINTER(_F)]),
+    "vslam_harris_keypoints_u8": (_I, [_P, _P, _I, _I, _Z, _F, _P, _Z, C.POINTER(_Z)]),
+    "vslam_pyramid_build_u8": (_I, [_P, _P, _I, _I, _Z, _I, _D, C.POINTER(_P)]),
+    "vslam_pyramid_destroy": (_I, [_P]),
+    "vslam_pyramid_get_info": (_I, [_P, C.POINTER(PyramidInfo)]),
+    "vslam_pyramid_get_base": (_I, [_P, _I, _P, _Z]),
+    "vslam_pyramid_get_gauss": (_I, [_P, _I, _I, _P, _Z]),
+    "vslam_pyramid_get_dog": (_I, [_P, _I, _I, _P, _Z]),
+    "vslam_dog_extrema": (_I, [_P, _P, _I, _I, _I, _P, _P, _Z, C.POINTER(_Z)]),
+    "vslam_params_default": (None, [C.POINTER(Params), _I, _I]),
+    "vslam_batch_layout_query": (_I, [C.POINTER(Params), C.POINTER(BatchLayout)]),
+    "vslam_detect_batch_dev": (_I, [_P, C.POINTER(Params), _P, _Z, _I, C.POINTER(BatchOut)]),
+    "vslam_kernel_timing_enable": (_I, [_P, C.c_char_p]),
+    "vslam_kernel_timing_read": (_I, [_P, C.POINTER(_I), C.POINTER(_D)]),
+    "vslam_kernel_names": (C.c_char_p, []),
+}
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(_HERE, "..", "include", "vslam.h")]
+    stale = force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(s) for s in srcs)
+    if stale:
+        r = subprocess.run(["make", "-C", CSRC] + (["-B"] if force else []), capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("building libvslam.so failed:\n" + r.stdout + r.stderr)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load libvslam.so (raises if it has not been built: there is no fallback path)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing -- run __graft_entry__.build() (the product has no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _status_string(s: int) -> str:
+    try:
+        return lib().vslam_status_string(s).decode()
+    except Exception:
+        return "?"
+
+
+def gauss_ksize_u8(sigma: float) -> int:
+    return lib().vslam_gauss_ksize_u8(float(sigma))
+
+
+def gauss_taps_q8(n: int, sigma: float) -> np.ndarray:
+    t = np.zeros(max(n, 1), np.uint16)
+    rc = lib().vslam_gauss_taps_q8(n, float(sigma), t.ctypes.data)
+    if rc:
+        raise VslamError(rc, "vslam_gauss_taps_q8")
+    return t
+
+
+def sigma_at(sigma0: float, octave: int, level: int) -> float:
+    return lib().vslam_sigma_at(float(sigma0), octave, level)
+
+
+def auto_num_octaves(rows: int, cols: int) -> int:
+    return lib().vslam_auto_num_octaves(rows, cols)
+
+
+def half_size(rows: int, cols: int):
+    r, c = C.c_int(), C.c_int()
+    lib().vslam_half_size(rows, cols, C.byref(r), C.byref(c))
+    return r.value, c.value
+
+
+def extrema_lattice(rows: int, cols: int, window: int = 3):
+    r, c = C.c_int(), C.c_int()
+    lib().vslam_extrema_lattice(rows, cols, window, C.byref(r), C.byref(c))
+    return r.value, c.value
+
+
+def default_params(rows: int, cols: int, **kw) -> Params:
+    p = Params()
+    lib().vslam_params_default(C.byref(p), rows, cols)
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def batch_layout(p: Params) -> BatchLayout:
+    L = BatchLayout()
+    rc = lib().vslam_batch_layout_query(C.byref(p), C.byref(L))
+    if rc:
+        raise VslamError(rc, "vslam_batch_layout_query")
+    return L
+
+
+def _u8(a):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    if a.ndim != 2:
+        raise ValueError("expected a 2-D uint8 image")
+    return a
+
+
+def _f32(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if a.ndim != 2:
+        raise ValueError("expected a 2-D float32 image")
+    return a
+
+
+class Context:
+    """One vslam_ctx: one GPU, one HIP stream."""
+
+    def __init__(self, device: int = 0, stream: int | None = None):
+        h = C.c_void_p()
+        rc = lib().vslam_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(h))
+        if rc:
+            raise VslamError(rc, "vslam_ctx_create", "no usable HIP device" if rc == -2 else "")
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().vslam_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _chk(self, rc, what):
+        if rc:
+            raise VslamError(rc, what, lib().vslam_last_error(self._h).decode())
+
+    def sync(self):
+        self._chk(lib().vslam_ctx_sync(self._h), "vslam_ctx_sync")
+
+    # ---- host-buffer primitives
+    def gaussian_blur_u8(self, img, ksize: int, sigma: float):
+        img = _u8(img)
+        out = np.empty_like(img)
+        self._chk(lib().vslam_gaussian_blur_u8(self._h, img.ctypes.data, *img.shape, img.strides[0], ksize, float(sigma), out.ctypes.data, out.strides[0]), "vslam_gaussian_blur_u8")
+        return out
+
+    def sobel_k1(self, img, dx: int, dy: int):
+        img = _u8(img)
+        out = np.empty(img.shape, np.float32)
+        self._chk(lib().vslam_sobel_k1_u8_f32(self._h, img.ctypes.data, *img.shape, img.strides[0], dx, dy, out.ctypes.data, out.strides[0]), "vslam_sobel_k1_u8_f32")
+        return out
+
+    def resize_linear2x(self, img):
+        img = _u8(img)
+        out = np.empty((2 * img.shape[0], 2 * img.shape[1]), np.uint8)
+        self._chk(lib().vslam_resize_linear2x_u8(self._h, img.ctypes.data, *img.shape, img.strides[0], out.ctypes.data, out.strides[0]), "vslam_resize_linear2x_u8")
+        return out
+
+    def resize_nearest_half(self, img):
+        img = _u8(img)
+        out = np.empty(half_size(*img.shape), np.uint8)
+        self._chk(lib().vslam_resize_nearest_half_u8(self._h, img.ctypes.data, *img.shape, img.strides[0], out.ctypes.data, max(out.strides[0], 1)), "vslam_resize_nearest_half_u8")
+        return out
+
+    def convert_scale_abs(self, x):
+        x = _f32(x)
+        out = np.empty(x.shape, np.uint8)
+        self._chk(lib().vslam_convert_scale_abs_f32(self._h, x.ctypes.data, *x.shape, x.strides[0], out.ctypes.data, out.strides[0]), "vslam_convert_scale_abs_f32")
+        return out
+
+    # ---- Harris
+    def harris_from_grad(self, ix, iy, k: float = 0.04, window: int = 3):
+        ix, iy = _f32(ix), _f32(iy)
+        if ix.shape != iy.shape:
+            raise ValueError("Ix and Iy differ in shape")
+        out = np.empty(ix.shape, np.float32)
+        self._chk(lib().vslam_harris_from_grad_f32(self._h, ix.ctypes.data, iy.ctypes.data, *ix.shape, ix.strides[0], k, window, out.ctypes.data, out.strides[0]), "vslam_harris_from_grad_f32")
+        return out
+
+    def harris_response(self, img, k: float = 0.04, window: int = 3):
+        img = _u8(img)
+        out = np.empty(img.shape, np.float32)
+        self._chk(lib().vslam_harris_response_u8(self._h, img.ctypes.data, *img.shape, img.strides[0], k, window, out.ctypes.data, out.strides[0]), "vslam_harris_response_u8")
+        return out
+
+    def nms_strict(self, x, window: int = 3):
+        x = np.asarray(x)
+        out = np.empty(x.shape, np.uint8)
+        if x.dtype == np.uint8:
+            x = _u8(x)
+            rc = lib().vslam_nms_strict_u8(self._h, x.ctypes.data, *x.shape, x.strides[0], window, out.ctypes.data, out.strides[0])
+        else:
+            x = _f32(x)
+            rc = lib().vslam_nms_strict_f32(self._h, x.ctypes.data, *x.shape, x.strides[0], window, out.ctypes.data, out.strides[0])
+        self._chk(rc, "vslam_nms_strict")
+        return out
+
+    def nms2(self, resp, window: int = 5):
+        resp = _f32(resp)
+        out = np.empty(resp.shape, np.float32)
+        tm = C.c_float()
+        self._chk(lib().vslam_nms2_f32(self._h, resp.ctypes.data, *resp.shape, resp.strides[0], window, out.ctypes.data, out.strides[0], C.byref(tm)), "vslam_nms2_f32")
+        return out, tm.value
+
+    def harris_keypoints(self, img, k: float = 0.04, cap: int = 1 << 20):
+        img = _u8(img)
+        out = np.zeros(cap, KP_DTYPE)
+        n = C.c_size_t()
+        self._chk(lib().vslam_harris_keypoints_u8(self._h, img.ctypes.data, *img.shape, img.strides[0], k, out.ctypes.data, cap, C.byref(n)), "vslam_harris_keypoints_u8")
+        return out[: min(n.value, cap)], n.value
+
+    # ---- DoG
+    def pyramid(self, img, n_octaves: int = 4, sigma0: float = 1.6):
+        return Pyramid(self, img, n_octaves, sigma0)
+
+    # ---- device-resident batch (torch CUDA tensors)
+    def detect_batch(self, params: Params, frames, **outs):
+        """frames: uint8 CUDA tensor [n, rows, cols]; outs: CUDA tensors by BatchOut field name."""
+        n = frames.shape[0]
+        bo = BatchOut()
+        for k, t in outs.items():
+            if t is not None:
+                setattr(bo, k, t.data_ptr())
+        self._chk(lib().vslam_detect_batch_dev(self._h, C.byref(params), frames.data_ptr(), frames.stride(0), n, C.byref(bo)), "vslam_detect_batch_dev")
+
+    def kernel_timing_enable(self, name: str | None):
+        self._chk(lib().vslam_kernel_timing_enable(self._h, name.encode() if name else None), "vslam_kernel_timing_enable")
+
+    def kernel_timing_read(self):
+        n, ms = C.c_int(), C.c_double()
+        self._chk(lib().vslam_kernel_timing_read(self._h, C.byref(n), C.byref(ms)), "vslam_kernel_timing_read")
+        return n.value, ms.value
+
+
+class Pyramid:
+    """vslam_pyramid: the Gaussian / DoG stacks of one image, resident in HBM."""
+
+    def __init__(self, ctx: Context, img, n_octaves: int = 4, sigma0: float = 1.6):
+        img = _u8(img)
+        self.ctx = ctx
+        h = C.c_void_p()
+        ctx._chk(lib().vslam_pyramid_build_u8(ctx._h, img.ctypes.data, *img.shape, img.strides[0], n_octaves, float(sigma0), C.byref(h)), "vslam_pyramid_build_u8")
+        self._h = h
+        info = PyramidInfo()
+        lib().vslam_pyramid_get_info(h, C.byref(info))
+        self.n_octaves = info.n_octaves
+        self.sizes = [(info.rows[o], info.cols[o]) for o in range(info.n_octaves)]
+        self.sigmas = [[info.sigma[o][l] for l in range(NUM_LEVELS)] for o in range(info.n_octaves)]
+        self.ksizes = [[info.ksize[o][l] for l in range(NUM_LEVELS)] for o in range(info.n_octaves)]
+
+    def _get(self, fn, what, o, *lvl):
+        if not 0 <= o < self.n_octaves:
+            out = np.empty((1, 1), np.uint8)
+        else:
+            out = np.empty(self.sizes[o], np.uint8)
+        self.ctx._chk(fn(self._h, o, *lvl, out.ctypes.data, out.strides[0]), what)
+        return out
+
+    def base(self, o):
+        return self._get(lib().vslam_pyramid_get_base, "vslam_pyramid_get_base", o)
+
+    def gauss(self, o, l):
+        return self._get(lib().vslam_pyramid_get_gauss, "vslam_pyramid_get_gauss", o, l)
+
+    def dog(self, o, l):
+        return self._get(lib().vslam_pyramid_get_dog, "vslam_pyramid_get_dog", o, l)
+
+    def extrema(self, octave: int, window: int = 3, min_contrast: int = 8, cap: int = 1 << 22):
+        """(mask[3, lat_rows, lat_cols] u8 unpacked from the bitmask, points, total count)."""
+        lr, lc = extrema_lattice(*self.sizes[octave], window) if 0 <= octave < self.n_octaves else (0, 0)
+        wpr = (lc + 63) // 64
+        bits = np.zeros((3, lr, max(wpr, 1)), np.uint64)
+        pts = np.zeros(cap, POINT_DTYPE)
+        n = C.c_size_t()
+        self.ctx._chk(lib().vslam_dog_extrema(self.ctx._h, self._h, octave, window, min_contrast, bits.ctypes.data, pts.ctypes.data, cap, C.byref(n)), "vslam_dog_extrema")
+        mask = np.unpackbits(bits.view(np.uint8), axis=-1, bitorder="little")[..., :lc] if lc else np.zeros((3, lr, 0), np.uint8)
+        return mask, pts[: min(n.value, cap)], n.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().vslam_pyramid_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,424 @@
+// Generic (any size / any window / any kernel width) HIP kernels for gfx950.
+// They back the host-buffer primitives of include/vslam.h for arbitrary parameters and
+// are the fallback of the batched path for parameter sets the specialised kernels
+// (kernels_harris.hip.h, kernels_pyramid.hip.h) do not cover.  One thread per output
+// element, coalesced row accesses, caches do the rest.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cstdint>
+
+namespace vslam {
+
+// cv::borderInterpolate(p, len, BORDER_REFLECT_101), repeated until inside.
+__device__ __forceinline__ int reflect101(int p, int len) {
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) p = p < 0 ? -p : 2 * (len - 1) - p;
+    return p;
+}
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// cv::convertScaleAbs element: saturate_cast<uchar>(round_half_even(|x|)), NaN -> 0.
+__device__ __forceinline__ int cvt_abs_u8(float x) {
+    const float a = fabsf(x);
+    if (!(a < 255.5f)) return a != a ? 0 : 255;
+    return __float2int_rn(a);
+}
+
+// ---- GaussianBlur CV_8U, separable, exact integer -------------
+
+// h(y,x) = sum_k taps[k] * src(y, reflect101(x - r + k)); <= 255*256, fits u16.
+__global__ __launch_bounds__(256) void k_blur_h_generic(const uint8_t* __restrict__ src, size_t sstep,
+                                                         size_t sframe, uint16_t* __restrict__ h, size_t hframe,
+                                                         int rows, int cols, const uint16_t* __restrict__ taps,
+                                                         int n) {
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= cols) return;
+    const uint8_t* s = src + blockIdx.z * sframe + (size_t)y * sstep;
+    const int r = n >> 1;
+    uint32_t acc = 0;
+    if (x - r >= 0 && x + r < cols) {
+        for (int k = 0; k < n; ++k) acc += (uint32_t)taps[k] * s[x - r + k];
+    } else {
+        for (int k = 0; k < n; ++k) acc += (uint32_t)taps[k] * s[reflect101(x - r + k, cols)];
+    }
+    h[blockIdx.z * hframe + (size_t)y * cols + x] = (uint16_t)acc;
+}
+
+// dst(y,x) = (sum_k taps[k] * h(reflect101(y - r + k), x) + 32768) >> 16.
+__global__ __launch_bounds__(256) void k_blur_v_generic(const uint16_t* __restrict__ h, size_t hframe,
+                                                         uint8_t* __restrict__ dst, size_t dstep, size_t dframe,
+                                                         int rows, int cols, const uint16_t* __restrict__ taps,
+                                                         int n) {
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= cols) return;
+    const uint16_t* hp = h + blockIdx.z * hframe + x;
+    const int r = n >> 1;
+    uint32_t acc = 32768u;
+    if (y - r >= 0 && y + r < rows) {
+        for (int k = 0; k < n; ++k) acc += (uint32_t)taps[k] * hp[(size_t)(y - r + k) * cols];
+    } else {
+        for (int k = 0; k < n; ++k) acc += (uint32_t)taps[k] * hp[(size_t)reflect101(y - r + k, rows) * cols];
+    }
+    dst[blockIdx.z * dframe + (size_t)y * dstep + x] = (uint8_t)(acc >> 16);
+}
+
+// D_l = saturate_u8(G_{l+1} - G_l), l = 0..4 (GaussPyramid.cpp:191-200).  gauss: 6
+// images P bytes apart, dog: 5 images P bytes apart; dense rows.
+__global__ __launch_bounds__(256) void k_dog5(const uint8_t* __restrict__ gauss, uint8_t* __restrict__ dog,
+                                               size_t P, size_t frame) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const uint8_t* g = gauss + blockIdx.z * frame + i;
+    uint8_t* d = dog + blockIdx.z * frame + i;
+    int prev = g[0];
+#pragma unroll
+    for (int l = 0; l < 5; ++l) {
+        const int cur = g[(size_t)(l + 1) * P];
+        d[(size_t)l * P] = (uint8_t)(cur > prev ? cur - prev : 0);
+        prev = cur;
+    }
+}
+
+// ---- resize --------------------------------------------------------
+
+// Coefficients of cv::resize INTER_LINEAR x2 along one axis: source index and the
+// 11-bit weight of the SECOND sample (0, 512 or 1536); the first weight is 2048 - w1.
+__device__ __forceinline__ void lin2x_coeff_x(int d, int n_src, int& s, int& w1) {
+    // f = (d + 0.5)/2 - 0.5 ; even d: floor = d/2 - 1, frac .75 ; odd d: floor = d/2, frac .25
+    s = (d >> 1) - 1 + (d & 1);
+    w1 = (d & 1) ? 512 : 1536;
+    if (s < 0) s = 0, w1 = 0;
+    if (s >= n_src - 1) s = n_src - 1, w1 = 0;
+}
+
+__global__ __launch_bounds__(256) void k_resize_linear2x(const uint8_t* __restrict__ src, size_t sstep,
+                                                          size_t sframe, uint8_t* __restrict__ dst, size_t dstep,
+                                                          size_t dframe, int rows, int cols) {
+    const int dx = blockIdx.x * 256 + threadIdx.x;
+    const int dy = blockIdx.y;
+    if (dx >= 2 * cols) return;
+    int sx, a1;
+    lin2x_coeff_x(dx, cols, sx, a1);
+    const int a0 = 2048 - a1;
+    const int sx1 = sx + 1 < cols ? sx + 1 : sx;
+    // vertical: no coefficient clamping, rows are clipped instead (resizeGeneric_Invoker)
+    const int sy = (dy >> 1) - 1 + (dy & 1);
+    const int b1 = (dy & 1) ? 512 : 1536, b0 = 2048 - b1;
+    const uint8_t* s0 = src + blockIdx.z * sframe + (size_t)clampi(sy, 0, rows - 1) * sstep;
+    const uint8_t* s1 = src + blockIdx.z * sframe + (size_t)clampi(sy + 1, 0, rows - 1) * sstep;
+    const int h0 = s0[sx] * a0 + s0[sx1] * a1;
+    const int h1 = s1[sx] * a0 + s1[sx1] * a1;
+    const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+    dst[blockIdx.z * dframe + (size_t)dy * dstep + dx] = (uint8_t)clampi(v, 0, 255);
+}
+
+__global__ __launch_bounds__(256) void k_resize_nearest_half(const uint8_t* __restrict__ src, size_t sstep,
+                                                              size_t sframe, uint8_t* __restrict__ dst,
+                                                              size_t dstep, size_t dframe, int rows, int cols,
+                                                              int drows, int dcols) {
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= dcols) return;
+    const int sy = min(2 * y, rows - 1), sx = min(2 * x, cols - 1);
+    dst[blockIdx.z * dframe + (size_t)y * dstep + x] = src[blockIdx.z * sframe + (size_t)sy * sstep + sx];
+}
+
+// ---- Sobel ksize=1, convertScaleAbs -----------------------------------------------------
+
+__global__ __launch_bounds__(256) void k_sobel_k1(const uint8_t* __restrict__ src, size_t sstep,
+                                                   float* __restrict__ dst, size_t dstep_elems, int rows,
+                                                   int cols, int dx) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int r = blockIdx.y;
+    if (c >= cols) return;
+    int a, b;
+    if (dx) {
+        a = src[(size_t)r * sstep + reflect101(c + 1, cols)];
+        b = src[(size_t)r * sstep + reflect101(c - 1, cols)];
+    } else {
+        a = src[(size_t)reflect101(r + 1, rows) * sstep + c];
+        b = src[(size_t)reflect101(r - 1, rows) * sstep + c];
+    }
+    dst[(size_t)r * dstep_elems + c] = (float)(a - b);
+}
+
+__global__ __launch_bounds__(256) void k_convert_scale_abs(const float* __restrict__ src, size_t sstep_elems,
+                                                            uint8_t* __restrict__ dst, size_t dstep, int rows,
+                                                            int cols) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int r = blockIdx.y;
+    if (c >= cols) return;
+    dst[(size_t)r * dstep + c] = (uint8_t)cvt_abs_u8(src[(size_t)r * sstep_elems + c]);
+}
+
+// ---- HarrisCorner(Mat& Ix, Mat& Iy), literal op order (Harris_corners.cpp:10-68) ---------
+// This TU is compiled with -ffp-contract=off, so every f32/f64 operation below is
+// individually rounded exactly like the reference's SSE2 code.
+__global__ __launch_bounds__(256) void k_harris_from_grad(const float* __restrict__ ix,
+                                                           const float* __restrict__ iy, size_t step_elems,
+                                                           int rows, int cols, float k, int pad,
+                                                           float* __restrict__ resp, size_t rstep_elems) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int r = blockIdx.y;
+    if (c >= cols) return;
+    float Ix2 = 0.0f, Iy2 = 0.0f, IxIy = 0.0f;
+    for (int u = r - pad; u <= r + pad; ++u) {
+        const size_t ro = (size_t)clampi(u, 0, rows - 1) * step_elems;
+        for (int v = c - pad; v <= c + pad; ++v) {
+            const int vv = clampi(v, 0, cols - 1);
+            const float a = ix[ro + vv], b = iy[ro + vv];
+            Ix2 += a * a;
+            Iy2 += b * b;
+            IxIy += a * b;
+        }
+    }
+    const float det = (float)((double)Ix2 * (double)Iy2 - (double)IxIy * (double)IxIy);
+    const float tr = (float)((double)Ix2 + (double)Iy2);
+    const float trtr = tr * tr;
+    const float ktr = k * trtr;
+    const float response = det - ktr;
+    resp[(size_t)r * rstep_elems + c] = response > 0 ? response : 0.0f;
+}
+
+// ---- NonMaximumSuppression / NMS2, any window --------------------------------------------
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_nms_strict_generic(const T* __restrict__ src, size_t sstep_elems,
+                                                             int rows, int cols, int p,
+                                                             uint8_t* __restrict__ mask, size_t mstep) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int r = blockIdx.y;
+    if (c >= cols) return;
+    // dilate's constant border never wins: minimum of the type
+    float m = sizeof(T) == 1 ? 0.0f : -FLT_MAX;
+    for (int u = max(r - p, 0); u <= min(r + p, rows - 1); ++u)
+        for (int v = max(c - p, 0); v <= min(c + p, cols - 1); ++v) {
+            if (u == r && v == c) continue;
+            const float t = (float)src[(size_t)u * sstep_elems + v];
+            if (t > m) m = t;
+        }
+    mask[(size_t)r * mstep + c] = (float)src[(size_t)r * sstep_elems + c] > m ? 255 : 0;
+}
+
+// NMS2: half-open window [i-p, i+p) x [j-p, j+p), '>=' (Harris_corners.cpp:94-119).
+// true_max_bits accumulates the :107-109 running maximum as the bit pattern of a
+// non-negative float (monotone under unsigned compare).
+__global__ __launch_bounds__(256) void k_nms2_generic(const float* __restrict__ resp, size_t sstep_elems,
+                                                       int rows, int cols, int p, float* __restrict__ out,
+                                                       size_t ostep_elems, unsigned int* true_max_bits) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.y;
+    float wmax = 0.0f;
+    const bool inside = j < cols && i >= p && i < rows - p && j >= p && j < cols - p;
+    if (inside) {
+        for (int u = i - p; u < i + p; ++u)
+            for (int v = j - p; v < j + p; ++v) {
+                const float t = resp[(size_t)u * sstep_elems + v];
+                if (t > wmax) wmax = t;
+            }
+    }
+    if (j < cols) {
+        float o = 0.0f;
+        if (inside && resp[(size_t)i * sstep_elems + j] >= wmax) o = wmax;
+        out[(size_t)i * ostep_elems + j] = o;
+    }
+    if (true_max_bits) {
+        float m = wmax;
+        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+        if ((threadIdx.x & 63) == 0 && m > 0.0f) atomicMax(true_max_bits, __float_as_uint(m));
+    }
+}
+
+// ---- Harris post-processing for the default windows (3 and 5) ----------------------------
+// One pass over the response map: NonMaximumSuppression on the 8-bit view (window 3,
+// Harris_corners.cpp:176-178), NMS2 window 5 (:179) and the keypoint criterion (:139,181).
+// A wave covers 64 consecutive pixels of one row; its keypoint flags leave as one ballot word.
+__global__ __launch_bounds__(256) void k_harris_post(const float* __restrict__ resp, size_t rstep_elems,
+                                                      size_t rframe, int rows, int cols,
+                                                      uint8_t* __restrict__ mask, size_t mstep, size_t mframe,
+                                                      float* __restrict__ nms2, size_t nstep_elems, size_t nframe,
+                                                      unsigned long long* __restrict__ flags, int wpr,
+                                                      size_t fframe) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.y;
+    const float* R = resp + blockIdx.z * rframe;
+    bool kp = false;
+    if (j < cols) {
+        const float c = R[(size_t)i * rstep_elems + j];
+        if (mask) {
+            int m = 0;
+            for (int u = max(i - 1, 0); u <= min(i + 1, rows - 1); ++u)
+                for (int v = max(j - 1, 0); v <= min(j + 1, cols - 1); ++v)
+                    if (u != i || v != j) m = max(m, cvt_abs_u8(R[(size_t)u * rstep_elems + v]));
+            mask[blockIdx.z * mframe + (size_t)i * mstep + j] = cvt_abs_u8(c) > m ? 255 : 0;
+        }
+        float o = 0.0f;
+        if (i >= 2 && i < rows - 2 && j >= 2 && j < cols - 2) {
+            float wmax = 0.0f;
+            for (int u = i - 2; u < i + 2; ++u)
+                for (int v = j - 2; v < j + 2; ++v) wmax = fmaxf(wmax, R[(size_t)u * rstep_elems + v]);
+            if (c >= wmax) o = wmax;
+        }
+        if (nms2) nms2[blockIdx.z * nframe + (size_t)i * nstep_elems + j] = o;
+        kp = cvt_abs_u8(o) > 253;
+    }
+    const unsigned long long w = __ballot(kp);
+    if (flags && (threadIdx.x & 63) == 0 && (j >> 6) < wpr) flags[blockIdx.z * fframe + (size_t)i * wpr + (j >> 6)] = w;
+}
+
+// ---- scale-space extrema (initialKeypointDetection, Diff_of_Gauss.cpp:254-297) ------------
+
+struct ExtGeom {
+    int n_oct, window, pad, min_contrast;
+    int rows[VSLAM_MAX_OCTAVES], cols[VSLAM_MAX_OCTAVES];
+    int lat_rows[VSLAM_MAX_OCTAVES], lat_cols[VSLAM_MAX_OCTAVES], wpr[VSLAM_MAX_OCTAVES];
+    unsigned long long oct_off[VSLAM_MAX_OCTAVES];   // byte offset of the octave in a pyramid frame block
+    unsigned long long bits_off[VSLAM_MAX_OCTAVES];  // word offset of the octave in a bits frame block
+};
+
+// One thread per lattice site; a wave's 64 candidate flags leave as one ballot word, which
+// IS the bitmask layout of include/vslam.h.  blockIdx.z = frame*3 + (level-1).
+__global__ __launch_bounds__(256) void k_extrema(const uint8_t* __restrict__ pyr, size_t pframe, ExtGeom g,
+                                                  int o, unsigned long long* __restrict__ bits,
+                                                  unsigned long long* __restrict__ lflags, size_t bframe) {
+    const int lj = blockIdx.x * 256 + threadIdx.x;
+    const int li = blockIdx.y;
+    const int f = blockIdx.z / 3, level = blockIdx.z % 3 + 1;
+    const int rows = g.rows[o], cols = g.cols[o], pad = g.pad;
+    const size_t P = (size_t)rows * cols;
+    const uint8_t* dog = pyr + f * pframe + g.oct_off[o] + (size_t)VSLAM_NUM_LEVELS * P;
+    bool cand = false, listed = false;
+    if (lj < g.lat_cols[o]) {
+        const int i = pad + li * g.window, j = pad + lj * g.window;  // padded coordinates
+        int mn = 256, mx = -1;
+        for (int u = i - pad; u < i + pad; ++u) {
+            const size_t ro = (size_t)clampi(u - pad, 0, rows - 1) * cols;
+            for (int v = j - pad; v < j + pad; ++v) {
+                const size_t idx = ro + clampi(v - pad, 0, cols - 1);
+#pragma unroll
+                for (int l = -1; l <= 1; ++l) {
+                    const int t = dog[(size_t)(level + l) * P + idx];
+                    mn = min(mn, t);
+                    mx = max(mx, t);
+                }
+            }
+        }
+        const int self = dog[(size_t)level * P + (size_t)(i - pad) * cols + (j - pad)];
+        cand = self == mn || self == mx;
+        listed = cand && self >= g.min_contrast;
+    }
+    const unsigned long long wc = __ballot(cand), wl = __ballot(listed);
+    if ((threadIdx.x & 63) == 0 && (lj >> 6) < g.wpr[o]) {
+        const size_t w = f * bframe + g.bits_off[o] + ((size_t)(level - 1) * g.lat_rows[o] + li) * g.wpr[o] + (lj >> 6);
+        if (bits) bits[w] = wc;
+        lflags[w] = wl;
+    }
+}
+
+// ---- deterministic ordered compaction: popcount -> block scan -> scatter ------------------
+
+// Exclusive scan of one value per thread over a 1024-thread block; returns the block total
+// through `total`.  Wave scan by shuffles, wave totals through LDS.
+__device__ __forceinline__ unsigned int block_excl_scan_1024(unsigned int v, unsigned int* wsum,
+                                                             unsigned int& total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned int inc = v;
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned int t = __shfl_up(inc, off);
+        if (lane >= off) inc += t;
+    }
+    __syncthreads();  // wsum reuse across calls
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    unsigned int base = 0, tot = 0;
+    for (int w = 0; w < 16; ++w) {
+        const unsigned int s = wsum[w];
+        if (w < wave) base += s;
+        tot += s;
+    }
+    total = tot;
+    return base + inc - v;
+}
+
+// One 1024-thread block per frame walks the frame's flag words in list order.
+__global__ __launch_bounds__(1024) void k_compact_harris(const unsigned long long* __restrict__ flags, int wpr,
+                                                          size_t fframe, int rows, int cols,
+                                                          const float* __restrict__ resp, size_t rstep_elems,
+                                                          size_t rframe, vslam_kp* __restrict__ out,
+                                                          unsigned int cap, unsigned int* __restrict__ counts) {
+    __shared__ unsigned int wsum[16];
+    const int f = blockIdx.x;
+    const unsigned long long* F = flags + f * fframe;
+    const size_t nwords = (size_t)rows * wpr;
+    unsigned int running = 0;
+    for (size_t base = 0; base < nwords; base += 1024) {
+        const size_t w = base + threadIdx.x;
+        unsigned long long bitsw = w < nwords ? F[w] : 0ull;
+        unsigned int total;
+        unsigned int pos = running + block_excl_scan_1024((unsigned int)__popcll(bitsw), wsum, total);
+        const int r = (int)(w / wpr), c0 = (int)(w % wpr) * 64;
+        while (bitsw) {
+            const int b = __ffsll((long long)bitsw) - 1;
+            bitsw &= bitsw - 1;
+            if (pos < cap) {
+                vslam_kp kp;
+                kp.row = r;
+                kp.col = c0 + b;
+                kp.response = resp[f * rframe + (size_t)r * rstep_elems + c0 + b];
+                out[(size_t)f * cap + pos] = kp;
+            }
+            ++pos;
+        }
+        running += total;
+    }
+    if (threadIdx.x == 0) counts[f] = running;
+}
+
+__global__ __launch_bounds__(1024) void k_compact_dog(const unsigned long long* __restrict__ lflags, size_t bframe,
+                                                       const uint8_t* __restrict__ pyr, size_t pframe, ExtGeom g,
+                                                       int o_begin, int o_end, vslam_point* __restrict__ out,
+                                                       unsigned int cap, unsigned int* __restrict__ counts) {
+    __shared__ unsigned int wsum[16];
+    const int f = blockIdx.x;
+    unsigned int running = 0;
+    for (int o = o_begin; o < o_end; ++o) {
+        const unsigned long long* F = lflags + f * bframe + g.bits_off[o];
+        const int wpr = g.wpr[o], lr = g.lat_rows[o];
+        const size_t nwords = (size_t)3 * lr * wpr;
+        const size_t P = (size_t)g.rows[o] * g.cols[o];
+        const uint8_t* dog = pyr + f * pframe + g.oct_off[o] + (size_t)VSLAM_NUM_LEVELS * P;
+        for (size_t base = 0; base < nwords; base += 1024) {
+            const size_t w = base + threadIdx.x;
+            unsigned long long bitsw = w < nwords ? F[w] : 0ull;
+            unsigned int total;
+            unsigned int pos = running + block_excl_scan_1024((unsigned int)__popcll(bitsw), wsum, total);
+            const int level = (int)(w / ((size_t)lr * wpr)) + 1;
+            const int li = (int)((w / wpr) % lr), lj0 = (int)(w % wpr) * 64;
+            while (bitsw) {
+                const int b = __ffsll((long long)bitsw) - 1;
+                bitsw &= bitsw - 1;
+                if (pos < cap) {
+                    const int i = g.pad + li * g.window, j = g.pad + (lj0 + b) * g.window;
+                    vslam_point pt;
+                    pt.row = i;
+                    pt.col = j;
+                    pt.value = dog[(size_t)level * P + (size_t)(i - g.pad) * g.cols[o] + (j - g.pad)];
+                    pt.padding = g.pad;
+                    pt.octave = o;
+                    pt.level = level;
+                    out[(size_t)f * cap + pos] = pt;
+                }
+                ++pos;
+            }
+            running += total;
+        }
+    }
+    if (threadIdx.x == 0) counts[f] = running;
+}
+
+}  // namespace vslam

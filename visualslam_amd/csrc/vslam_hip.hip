@@ -1,0 +1,737 @@
+// C ABI (include/vslam.h) over the hand-written gfx950 kernels.  Host code here only
+// validates arguments, sizes the workspace and enqueues kernels on the context's stream;
+// there is no CPU compute path: if HIP is unavailable every compute entry point fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/vslam.h"
+#include "kernels_generic.hip.h"
+#include "kernels_harris.hip.h"
+#include "vslam_internal.h"
+
+using namespace vslam;
+
+// ------------------------------------------------------------------------- context
+
+struct vslam_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    // bump workspace in HBM, grown between calls only (never inside a launch sequence)
+    char* ws = nullptr;
+    size_t ws_cap = 0, ws_off = 0;
+    std::map<std::pair<int, uint64_t>, uint16_t*> taps;  // device copies of quantised taps
+    // bench timing hook
+    std::string timing_name;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> timing_ev;
+    size_t timing_used = 0;
+};
+
+struct vslam_pyramid {
+    vslam_ctx* ctx = nullptr;
+    vslam_params params{};
+    vslam_batch_layout layout{};
+    vslam_pyramid_info info{};
+    uint8_t* d_block = nullptr;  // one pyramid frame block (layout.pyramid_frame_bytes)
+    uint8_t* d_bases = nullptr;  // octave bases, octave o at base_off[o]
+    size_t base_off[VSLAM_MAX_OCTAVES] = {};
+};
+
+static int fail(vslam_ctx* c, int code, const std::string& msg) {
+    if (c) c->err = msg;
+    return code;
+}
+
+#define HIPCHK(ctx, expr)                                                                        \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return fail(ctx, e_ == hipErrorOutOfMemory ? VSLAM_ERR_NOMEM : VSLAM_ERR_HIP,        \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                     \
+    } while (0)
+
+static const char* const kKernelNames =
+    "k_harris_fused\nk_harris_post\nk_compact_harris\nk_resize_linear2x\nk_blur_h_generic\nk_blur_v_generic\n"
+    "k_dog5\nk_resize_nearest_half\nk_extrema\nk_compact_dog";
+
+// Launch on the context stream; bracket with events when the bench hook names this kernel.
+#define LAUNCH(ctx, name, kern, grid, block, ...)                                                \
+    do {                                                                                         \
+        const bool timed_ = !(ctx)->timing_name.empty() && (ctx)->timing_name == (name);        \
+        std::pair<hipEvent_t, hipEvent_t>* ev_ = timed_ ? timing_slot(ctx) : nullptr;           \
+        if (ev_) (void)hipEventRecord(ev_->first, (ctx)->stream);                                \
+        hipLaunchKernelGGL(kern, grid, block, 0, (ctx)->stream, __VA_ARGS__);                    \
+        if (ev_) (void)hipEventRecord(ev_->second, (ctx)->stream);                               \
+        HIPCHK(ctx, hipGetLastError());                                                          \
+    } while (0)
+
+static std::pair<hipEvent_t, hipEvent_t>* timing_slot(vslam_ctx* c) {
+    if (c->timing_used == c->timing_ev.size()) {
+        if (c->timing_ev.size() >= 65536) return nullptr;
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess) return nullptr;
+        if (hipEventCreate(&b) != hipSuccess) {
+            (void)hipEventDestroy(a);
+            return nullptr;
+        }
+        c->timing_ev.emplace_back(a, b);
+    }
+    return &c->timing_ev[c->timing_used++];
+}
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static int ws_reserve(vslam_ctx* c, size_t bytes) {
+    c->ws_off = 0;
+    if (bytes <= c->ws_cap) return VSLAM_OK;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->ws) (void)hipFree(c->ws);
+    c->ws = nullptr;
+    c->ws_cap = 0;
+    const size_t want = align_up(bytes + bytes / 8, 1 << 20);
+    HIPCHK(c, hipMalloc((void**)&c->ws, want));
+    c->ws_cap = want;
+    return VSLAM_OK;
+}
+
+template <typename T>
+static T* ws_take(vslam_ctx* c, size_t count) {
+    char* p = c->ws + c->ws_off;
+    c->ws_off += align_up(count * sizeof(T), 256);
+    return c->ws_off <= c->ws_cap ? (T*)p : nullptr;  // sized by ws_reserve; nullptr = sizing bug
+}
+static inline size_t ws_need(size_t bytes) { return align_up(bytes, 256); }
+
+static int get_taps(vslam_ctx* c, int n, double sigma, const uint16_t** out) {
+    uint64_t sb;
+    std::memcpy(&sb, &sigma, 8);
+    auto key = std::make_pair(n, sb);
+    auto it = c->taps.find(key);
+    if (it == c->taps.end()) {
+        std::vector<uint16_t> h((size_t)n);
+        if (!gauss_taps_q8(n, sigma, h.data())) return fail(c, VSLAM_ERR_INVALID, "invalid Gaussian kernel size");
+        uint16_t* d = nullptr;
+        HIPCHK(c, hipMalloc((void**)&d, sizeof(uint16_t) * (size_t)n));
+        HIPCHK(c, hipMemcpy(d, h.data(), sizeof(uint16_t) * (size_t)n, hipMemcpyHostToDevice));
+        it = c->taps.emplace(key, d).first;
+    }
+    *out = it->second;
+    return VSLAM_OK;
+}
+
+static inline dim3 grid_rows(int cols, int rows, int frames = 1) { return dim3((cols + 255) / 256, rows, frames); }
+
+// ---------------------------------------------------------------- enqueue helpers (device)
+
+// GaussianBlur CV_8U on nf dense images; h = u16 scratch of nf*rows*cols elements.
+static int enqueue_blur(vslam_ctx* c, const uint8_t* src, size_t sstep, size_t sframe, uint8_t* dst, size_t dstep,
+                        size_t dframe, uint16_t* h, int rows, int cols, int nf, int n, double sigma) {
+    const uint16_t* taps;
+    int rc = get_taps(c, n, sigma, &taps);
+    if (rc) return rc;
+    const size_t P = (size_t)rows * cols;
+    LAUNCH(c, "k_blur_h_generic", k_blur_h_generic, grid_rows(cols, rows, nf), dim3(256), src, sstep, sframe, h, P,
+           rows, cols, taps, n);
+    LAUNCH(c, "k_blur_v_generic", k_blur_v_generic, grid_rows(cols, rows, nf), dim3(256), h, P, dst, dstep, dframe,
+           rows, cols, taps, n);
+    return VSLAM_OK;
+}
+
+static void fill_geom(const vslam_params& p, const vslam_batch_layout& L, ExtGeom& g) {
+    std::memset(&g, 0, sizeof(g));
+    g.n_oct = L.n_octaves;
+    g.window = p.extrema_window;
+    g.pad = (p.extrema_window - 1) / 2;
+    g.min_contrast = p.min_contrast;
+    for (int o = 0; o < L.n_octaves; ++o) {
+        g.rows[o] = L.rows[o];
+        g.cols[o] = L.cols[o];
+        g.lat_rows[o] = L.lat_rows[o];
+        g.lat_cols[o] = L.lat_cols[o];
+        g.wpr[o] = L.lat_words[o];
+        g.oct_off[o] = L.octave_offset[o];
+        g.bits_off[o] = L.bits_offset[o];
+    }
+}
+
+struct DogScratch {
+    uint8_t* bases = nullptr;  // nf * sum_P
+    size_t bases_frame = 0;
+    size_t base_off[VSLAM_MAX_OCTAVES] = {};
+    uint16_t* h = nullptr;  // nf * P0 u16
+    unsigned long long* lflags = nullptr;
+};
+
+static size_t dog_scratch_bytes(const vslam_batch_layout& L, int nf) {
+    size_t sum_p = 0;
+    for (int o = 0; o < L.n_octaves; ++o) sum_p += (size_t)L.rows[o] * L.cols[o];
+    const size_t P0 = L.n_octaves ? (size_t)L.rows[0] * L.cols[0] : 0;
+    return ws_need((size_t)nf * sum_p) + ws_need((size_t)nf * P0 * 2) + ws_need((size_t)nf * L.bits_frame_words * 8);
+}
+
+static int dog_scratch_take(vslam_ctx* c, const vslam_batch_layout& L, int nf, DogScratch& s) {
+    size_t sum_p = 0;
+    for (int o = 0; o < L.n_octaves; ++o) {
+        s.base_off[o] = sum_p;
+        sum_p += (size_t)L.rows[o] * L.cols[o];
+    }
+    s.bases_frame = sum_p;
+    s.bases = ws_take<uint8_t>(c, (size_t)nf * sum_p);
+    s.h = ws_take<uint16_t>(c, (size_t)nf * L.rows[0] * L.cols[0]);
+    s.lflags = ws_take<unsigned long long>(c, (size_t)nf * L.bits_frame_words);
+    if (!s.bases || !s.h || !s.lflags) return fail(c, VSLAM_ERR_NOMEM, "workspace sizing error (dog)");
+    return VSLAM_OK;
+}
+
+// createPyramid (GaussPyramid.cpp:106-131) + initialKeypointDetection (Diff_of_Gauss.cpp:254)
+// for nf frames; pyr/bits/points are per-frame blocks with the given strides.
+static int enqueue_dog(vslam_ctx* c, const vslam_params& p, const vslam_batch_layout& L, const uint8_t* frames,
+                       size_t fstep, size_t fframe, int nf, uint8_t* pyr, size_t pframe, DogScratch& s,
+                       unsigned long long* bits, bool do_extrema, vslam_point* points, unsigned int* counts) {
+    ExtGeom g;
+    fill_geom(p, L, g);
+    LAUNCH(c, "k_resize_linear2x", k_resize_linear2x, grid_rows(2 * p.cols, 2 * p.rows, nf), dim3(256), frames, fstep,
+           fframe, s.bases + s.base_off[0], (size_t)L.cols[0], s.bases_frame, p.rows, p.cols);
+    for (int o = 0; o < L.n_octaves; ++o) {
+        const int rows = L.rows[o], cols = L.cols[o];
+        const size_t P = (size_t)rows * cols;
+        const uint8_t* base = s.bases + s.base_off[o];
+        uint8_t* oct = pyr + L.octave_offset[o];
+        for (int l = 0; l < VSLAM_NUM_LEVELS; ++l) {
+            const double sg = sigma_at(p.sigma0, o, l);
+            int rc = enqueue_blur(c, base, (size_t)cols, s.bases_frame, oct + (size_t)l * P, (size_t)cols, pframe, s.h,
+                                  rows, cols, nf, gauss_ksize_u8(sg), sg);
+            if (rc) return rc;
+        }
+        LAUNCH(c, "k_dog5", k_dog5, dim3((unsigned)((P + 255) / 256), 1, nf), dim3(256), oct,
+               oct + (size_t)VSLAM_NUM_LEVELS * P, P, pframe);
+        if (o + 1 < L.n_octaves)
+            LAUNCH(c, "k_resize_nearest_half", k_resize_nearest_half, grid_rows(L.cols[o + 1], L.rows[o + 1], nf),
+                   dim3(256), oct + (size_t)3 * P, (size_t)cols, pframe, s.bases + s.base_off[o + 1],
+                   (size_t)L.cols[o + 1], s.bases_frame, rows, cols, L.rows[o + 1], L.cols[o + 1]);
+        if (do_extrema && L.lat_rows[o] > 0 && L.lat_cols[o] > 0)
+            LAUNCH(c, "k_extrema", k_extrema, dim3((L.lat_cols[o] + 255) / 256, L.lat_rows[o], nf * 3), dim3(256), pyr,
+                   pframe, g, o, bits, s.lflags, L.bits_frame_words);
+    }
+    if (do_extrema && points && counts)
+        LAUNCH(c, "k_compact_dog", k_compact_dog, dim3(nf), dim3(1024), s.lflags, L.bits_frame_words, pyr, pframe, g, 0,
+               L.n_octaves, points, p.dog_cap, counts);
+    return VSLAM_OK;
+}
+
+// Harris chain on nf device frames: response (required buffer), optional mask / nms2 /
+// keypoint list.
+static int enqueue_harris(vslam_ctx* c, const uint8_t* frames, size_t fstep, size_t fframe, int rows, int cols,
+                          int nf, float k, float* resp, uint8_t* mask, float* nms2, unsigned long long* hflags,
+                          vslam_kp* kps, unsigned int cap, unsigned int* counts) {
+    const size_t N = (size_t)rows * cols;
+    LAUNCH(c, "k_harris_fused", k_harris_fused, dim3((cols + HT_W - 1) / HT_W, (rows + HT_H - 1) / HT_H, nf),
+           dim3(256), frames, fstep, fframe, rows, cols, k, resp, (size_t)cols, N);
+    if (mask || nms2 || hflags) {
+        const int wpr = (cols + 63) / 64;
+        LAUNCH(c, "k_harris_post", k_harris_post, grid_rows(cols, rows, nf), dim3(256), resp, (size_t)cols, N, rows, cols,
+               mask, (size_t)cols, N, nms2, (size_t)cols, N, hflags, wpr, (size_t)rows * wpr);
+        if (hflags && kps && counts)
+            LAUNCH(c, "k_compact_harris", k_compact_harris, dim3(nf), dim3(1024), hflags, wpr, (size_t)rows * wpr, rows,
+                   cols, resp, (size_t)cols, N, kps, cap, counts);
+    }
+    return VSLAM_OK;
+}
+
+// ------------------------------------------------------------------- host <-> device copies
+
+static int h2d(vslam_ctx* c, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width_bytes,
+               size_t rows) {
+    HIPCHK(c, hipMemcpy2DAsync(dst, dpitch, src, spitch, width_bytes, rows, hipMemcpyHostToDevice, c->stream));
+    return VSLAM_OK;
+}
+static int d2h(vslam_ctx* c, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width_bytes,
+               size_t rows) {
+    HIPCHK(c, hipMemcpy2DAsync(dst, dpitch, src, spitch, width_bytes, rows, hipMemcpyDeviceToHost, c->stream));
+    return VSLAM_OK;
+}
+
+#define ARGCHK(ctx, cond, msg) \
+    if (!(cond)) return fail(ctx, VSLAM_ERR_INVALID, msg)
+#define TRY(expr)              \
+    do {                       \
+        int rc_ = (expr);      \
+        if (rc_) return rc_;   \
+    } while (0)
+
+static int bind_device(vslam_ctx* c) {
+    if (!c) return VSLAM_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    return VSLAM_OK;
+}
+
+extern "C" {
+
+// ------------------------------------------------------------------------------ lifecycle
+
+int vslam_ctx_create(int device, void* stream, vslam_ctx** out) {
+    if (!out || device < 0) return VSLAM_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device >= n) return VSLAM_ERR_HIP;
+    if (hipSetDevice(device) != hipSuccess) return VSLAM_ERR_HIP;
+    vslam_ctx* c = new (std::nothrow) vslam_ctx();
+    if (!c) return VSLAM_ERR_NOMEM;
+    c->device = device;
+    if (stream) {
+        c->stream = (hipStream_t)stream;
+    } else {
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete c;
+            return VSLAM_ERR_HIP;
+        }
+        c->own_stream = true;
+    }
+    *out = c;
+    return VSLAM_OK;
+}
+
+int vslam_ctx_destroy(vslam_ctx* c) {
+    if (!c) return VSLAM_ERR_INVALID;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& kv : c->taps) (void)hipFree(kv.second);
+    for (auto& ev : c->timing_ev) {
+        (void)hipEventDestroy(ev.first);
+        (void)hipEventDestroy(ev.second);
+    }
+    if (c->ws) (void)hipFree(c->ws);
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return VSLAM_OK;
+}
+
+int vslam_ctx_sync(vslam_ctx* c) {
+    TRY(bind_device(c));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VSLAM_OK;
+}
+
+const char* vslam_last_error(const vslam_ctx* c) { return c ? c->err.c_str() : "null context"; }
+const char* vslam_kernel_names(void) { return kKernelNames; }
+
+int vslam_kernel_timing_enable(vslam_ctx* c, const char* name) {
+    if (!c) return VSLAM_ERR_INVALID;
+    c->timing_name = name ? name : "";
+    c->timing_used = 0;
+    return VSLAM_OK;
+}
+
+int vslam_kernel_timing_read(vslam_ctx* c, int* launches, double* total_ms) {
+    TRY(bind_device(c));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    double tot = 0;
+    for (size_t i = 0; i < c->timing_used; ++i) {
+        float ms = 0;
+        HIPCHK(c, hipEventElapsedTime(&ms, c->timing_ev[i].first, c->timing_ev[i].second));
+        tot += ms;
+    }
+    if (launches) *launches = (int)c->timing_used;
+    if (total_ms) *total_ms = tot;
+    c->timing_used = 0;
+    return VSLAM_OK;
+}
+
+// ------------------------------------------------------------------- host-buffer primitives
+
+int vslam_gaussian_blur_u8(vslam_ctx* c, const uint8_t* src, int rows, int cols, size_t step, int ksize,
+                           double sigma, uint8_t* dst, size_t dst_step) {
+    TRY(bind_device(c));
+    ARGCHK(c, src && dst && rows > 0 && cols > 0 && step >= (size_t)cols && dst_step >= (size_t)cols, "blur: bad image");
+    const int n = ksize > 0 ? ksize : (sigma > 0 ? gauss_ksize_u8(sigma) : -1);
+    ARGCHK(c, n > 0 && (n & 1) && n <= VSLAM_MAX_KSIZE, "blur: kernel size must be odd (or 0 with sigma > 0)");
+    const size_t P = (size_t)rows * cols;
+    TRY(ws_reserve(c, 2 * ws_need(P) + ws_need(2 * P)));
+    uint8_t* d_src = ws_take<uint8_t>(c, P);
+    uint8_t* d_dst = ws_take<uint8_t>(c, P);
+    uint16_t* d_h = ws_take<uint16_t>(c, P);
+    TRY(h2d(c, d_src, cols, src, step, cols, rows));
+    TRY(enqueue_blur(c, d_src, cols, P, d_dst, cols, P, d_h, rows, cols, 1, n, sigma));
+    TRY(d2h(c, dst, dst_step, d_dst, cols, cols, rows));
+    return vslam_ctx_sync(c);
+}
+
+int vslam_sobel_k1_u8_f32(vslam_ctx* c, const uint8_t* src, int rows, int cols, size_t step, int dx, int dy,
+                          float* dst, size_t dst_step) {
+    TRY(bind_device(c));
+    ARGCHK(c, src && dst && rows > 0 && cols > 0 && step >= (size_t)cols && dst_step >= 4 * (size_t)cols, "sobel: bad image");
+    ARGCHK(c, (dx == 1 && dy == 0) || (dx == 0 && dy == 1), "sobel: (dx,dy) must be (1,0) or (0,1)");
+    const size_t P = (size_t)rows * cols;
+    TRY(ws_reserve(c, ws_need(P) + ws_need(4 * P)));
+    uint8_t* d_src = ws_take<uint8_t>(c, P);
+    float* d_dst = ws_take<float>(c, P);
+    TRY(h2d(c, d_src, cols, src, step, cols, rows));
+    LAUNCH(c, "k_sobel_k1", k_sobel_k1, grid_rows(cols, rows), dim3(256), d_src, (size_t)cols, d_dst, (size_t)cols, rows,
+           cols, dx);
+    TRY(d2h(c, dst, dst_step, d_dst, 4 * (size_t)cols, 4 * (size_t)cols, rows));
+    return vslam_ctx_sync(c);
+}
+
+int vslam_resize_linear2x_u8(vslam_ctx* c, const uint8_t* src, int rows, int cols, size_t step, uint8_t* dst,
+                             size_t dst_step) {
+    TRY(bind_device(c));
+    ARGCHK(c, src && dst && rows > 0 && cols > 0 && step >= (size_t)cols && dst_step >= 2 * (size_t)cols, "resize2x: bad image");
+    const size_t P = (size_t)rows * cols;
+    TRY(ws_reserve(c, ws_need(P) + ws_need(4 * P)));
+    uint8_t* d_src = ws_take<uint8_t>(c, P);
+    uint8_t* d_dst = ws_take<uint8_t>(c, 4 * P);
+    TRY(h2d(c, d_src, cols, src, step, cols, rows));
+    LAUNCH(c, "k_resize_linear2x", k_resize_linear2x, grid_rows(2 * cols, 2 * rows), dim3(256), d_src, (size_t)cols, P,
+           d_dst, (size_t)2 * cols, 4 * P, rows, cols);
+    TRY(d2h(c, dst, dst_step, d_dst, 2 * (size_t)cols, 2 * (size_t)cols, 2 * (size_t)rows));
+    return vslam_ctx_sync(c);
+}
+
+int vslam_resize_nearest_half_u8(vslam_ctx* c, const uint8_t* src, int rows, int cols, size_t step, uint8_t* dst,
+                                 size_t dst_step) {
+    TRY(bind_device(c));
+    int dr, dc;
+    half_size(rows, cols, &dr, &dc);
+    ARGCHK(c, src && dst && rows > 0 && cols > 0 && dr > 0 && dc > 0 && step >= (size_t)cols && dst_step >= (size_t)dc,
+           "resize half: bad image");
+    const size_t P = (size_t)rows * cols, Q = (size_t)dr * dc;
+    TRY(ws_reserve(c, ws_need(P) + ws_need(Q)));
+    uint8_t* d_src = ws_take<uint8_t>(c, P);
+    uint8_t* d_dst = ws_take<uint8_t>(c, Q);
+    TRY(h2d(c, d_src, cols, src, step, cols, rows));
+    LAUNCH(c, "k_resize_nearest_half", k_resize_nearest_half, grid_rows(dc, dr), dim3(256), d_src, (size_t)cols, P, d_dst,
+           (size_t)dc, Q, rows, cols, dr, dc);
+    TRY(d2h(c, dst, dst_step, d_dst, dc, dc, dr));
+    return vslam_ctx_sync(c);
+}
+
+int vslam_convert_scale_abs_f32(vslam_ctx* c, const float* src, int rows, int cols, size_t step, uint8_t* dst,
+                                size_t dst_step) {
+    TRY(bind_device(c));
+    ARGCHK(c, src && dst && rows > 0 && cols > 0 && step >= 4 * (size_t)cols && dst_step >= (size_t)cols, "convertScaleAbs: bad image");
+    const size_t P = (size_t)rows * cols;
+    TRY(ws_reserve(c, ws_need(4 * P) + ws_need(P)));
+    float* d_src = ws_take<float>(c, P);
+    uint8_t* d_dst = ws_take<uint8_t>(c, P);
+    TRY(h2d(c, d_src, 4 * (size_t)cols, src, step, 4 * (size_t)cols, rows));
+    LAUNCH(c, "k_convert_scale_abs", k_convert_scale_abs, grid_rows(cols, rows), dim3(256), d_src, (size_t)cols, d_dst,
+           (size_t)cols, rows, cols);
+    TRY(d2h(c, dst, dst_step, d_dst, cols, cols, rows));
+    return vslam_ctx_sync(c);
+}
+
+// -------------------------------------------------------------------------------- Harris
+
+int vslam_harris_from_grad_f32(vslam_ctx* c, const float* ix, const float* iy, int rows, int cols, size_t step,
+                               float k, int window, float* resp, size_t resp_step) {
+    TRY(bind_device(c));
+    ARGCHK(c, ix && iy && resp && rows > 0 && cols > 0 && step >= 4 * (size_t)cols && resp_step >= 4 * (size_t)cols,
+           "HarrisCorner: bad image");
+    ARGCHK(c, window >= 1 && (window & 1), "HarrisCorner: window must be odd");
+    const size_t P = (size_t)rows * cols, rb = 4 * (size_t)cols;
+    TRY(ws_reserve(c, 3 * ws_need(4 * P)));
+    float* d_ix = ws_take<float>(c, P);
+    float* d_iy = ws_take<float>(c, P);
+    float* d_r = ws_take<float>(c, P);
+    TRY(h2d(c, d_ix, rb, ix, step, rb, rows));
+    TRY(h2d(c, d_iy, rb, iy, step, rb, rows));
+    LAUNCH(c, "k_harris_from_grad", k_harris_from_grad, grid_rows(cols, rows), dim3(256), d_ix, d_iy, (size_t)cols, rows,
+           cols, k, (window - 1) / 2, d_r, (size_t)cols);
+    TRY(d2h(c, resp, resp_step, d_r, rb, rb, rows));
+    return vslam_ctx_sync(c);
+}
+
+int vslam_harris_response_u8(vslam_ctx* c, const uint8_t* img, int rows, int cols, size_t step, float k, int window,
+                             float* resp, size_t resp_step) {
+    TRY(bind_device(c));
+    ARGCHK(c, img && resp && rows > 0 && cols > 0 && step >= (size_t)cols && resp_step >= 4 * (size_t)cols,
+           "harris_response: bad image");
+    if (window != 3) return fail(c, VSLAM_ERR_UNSUPPORTED, "harris_response: fused kernel implements windowSize 3 (Harris_corners.cpp:34); use the per-stage entry points for other windows");
+    const size_t P = (size_t)rows * cols;
+    TRY(ws_reserve(c, ws_need(P) + ws_need(4 * P)));
+    uint8_t* d_img = ws_take<uint8_t>(c, P);
+    float* d_r = ws_take<float>(c, P);
+    TRY(h2d(c, d_img, cols, img, step, cols, rows));
+    TRY(enqueue_harris(c, d_img, cols, P, rows, cols, 1, k, d_r, nullptr, nullptr, nullptr, nullptr, 0, nullptr));
+    TRY(d2h(c, resp, resp_step, d_r, 4 * (size_t)cols, 4 * (size_t)cols, rows));
+    return vslam_ctx_sync(c);
+}
+
+static int nms_strict_common(vslam_ctx* c, const void* src, int elem, int rows, int cols, size_t step, int window,
+                             uint8_t* mask, size_t mask_step) {
+    TRY(bind_device(c));
+    ARGCHK(c, src && mask && rows > 0 && cols > 0 && step >= (size_t)elem * cols && mask_step >= (size_t)cols, "NonMaximumSuppression: bad image");
+    ARGCHK(c, window >= 1 && (window & 1), "NonMaximumSuppression: windowSize must be odd");
+    const size_t P = (size_t)rows * cols, rb = (size_t)elem * cols;
+    TRY(ws_reserve(c, ws_need(elem * P) + ws_need(P)));
+    char* d_src = ws_take<char>(c, elem * P);
+    uint8_t* d_m = ws_take<uint8_t>(c, P);
+    TRY(h2d(c, d_src, rb, src, step, rb, rows));
+    const int p = (window - 1) / 2;
+    if (elem == 1)
+        LAUNCH(c, "k_nms_strict_generic", k_nms_strict_generic<uint8_t>, grid_rows(cols, rows), dim3(256),
+               (const uint8_t*)d_src, (size_t)cols, rows, cols, p, d_m, (size_t)cols);
+    else
+        LAUNCH(c, "k_nms_strict_generic", k_nms_strict_generic<float>, grid_rows(cols, rows), dim3(256),
+               (const float*)d_src, (size_t)cols, rows, cols, p, d_m, (size_t)cols);
+    TRY(d2h(c, mask, mask_step, d_m, cols, cols, rows));
+    return vslam_ctx_sync(c);
+}
+
+int vslam_nms_strict_u8(vslam_ctx* c, const uint8_t* src, int rows, int cols, size_t step, int window, uint8_t* mask,
+                        size_t mask_step) {
+    return nms_strict_common(c, src, 1, rows, cols, step, window, mask, mask_step);
+}
+int vslam_nms_strict_f32(vslam_ctx* c, const float* src, int rows, int cols, size_t step, int window, uint8_t* mask,
+                         size_t mask_step) {
+    return nms_strict_common(c, src, 4, rows, cols, step, window, mask, mask_step);
+}
+
+int vslam_nms2_f32(vslam_ctx* c, const float* resp, int rows, int cols, size_t step, int window, float* out,
+                   size_t out_step, float* true_max) {
+    TRY(bind_device(c));
+    ARGCHK(c, resp && out && rows > 0 && cols > 0 && step >= 4 * (size_t)cols && out_step >= 4 * (size_t)cols && window >= 1,
+           "NMS2: bad arguments");
+    const size_t P = (size_t)rows * cols, rb = 4 * (size_t)cols;
+    TRY(ws_reserve(c, 2 * ws_need(4 * P) + 256));
+    float* d_r = ws_take<float>(c, P);
+    float* d_o = ws_take<float>(c, P);
+    unsigned int* d_max = ws_take<unsigned int>(c, 1);
+    TRY(h2d(c, d_r, rb, resp, step, rb, rows));
+    HIPCHK(c, hipMemsetAsync(d_max, 0, 4, c->stream));
+    LAUNCH(c, "k_nms2_generic", k_nms2_generic, grid_rows(cols, rows), dim3(256), d_r, (size_t)cols, rows, cols,
+           (window - 1) / 2, d_o, (size_t)cols, d_max);
+    TRY(d2h(c, out, out_step, d_o, rb, rb, rows));
+    unsigned int bits = 0;
+    HIPCHK(c, hipMemcpyAsync(&bits, d_max, 4, hipMemcpyDeviceToHost, c->stream));
+    TRY(vslam_ctx_sync(c));
+    if (true_max) std::memcpy(true_max, &bits, 4);
+    return VSLAM_OK;
+}
+
+int vslam_harris_keypoints_u8(vslam_ctx* c, const uint8_t* img, int rows, int cols, size_t step, float k,
+                              vslam_kp* out, size_t cap, size_t* count) {
+    TRY(bind_device(c));
+    ARGCHK(c, img && count && rows > 0 && cols > 0 && step >= (size_t)cols && (out || cap == 0), "harris_keypoints: bad arguments");
+    const size_t P = (size_t)rows * cols;
+    const int wpr = (cols + 63) / 64;
+    const unsigned int dcap = (unsigned int)std::min<size_t>(cap, 0x7fffffff);
+    TRY(ws_reserve(c, ws_need(P) + ws_need(4 * P) + ws_need((size_t)rows * wpr * 8) + ws_need(sizeof(vslam_kp) * (size_t)dcap) + 256));
+    uint8_t* d_img = ws_take<uint8_t>(c, P);
+    float* d_r = ws_take<float>(c, P);
+    unsigned long long* d_f = ws_take<unsigned long long>(c, (size_t)rows * wpr);
+    vslam_kp* d_k = ws_take<vslam_kp>(c, dcap);
+    unsigned int* d_n = ws_take<unsigned int>(c, 1);
+    TRY(h2d(c, d_img, cols, img, step, cols, rows));
+    TRY(enqueue_harris(c, d_img, cols, P, rows, cols, 1, k, d_r, nullptr, nullptr, d_f, d_k, dcap, d_n));
+    unsigned int n = 0;
+    HIPCHK(c, hipMemcpyAsync(&n, d_n, 4, hipMemcpyDeviceToHost, c->stream));
+    TRY(vslam_ctx_sync(c));
+    *count = n;
+    const size_t m = std::min<size_t>(n, dcap);
+    if (m) HIPCHK(c, hipMemcpy(out, d_k, m * sizeof(vslam_kp), hipMemcpyDeviceToHost));
+    return VSLAM_OK;
+}
+
+// ------------------------------------------------------------------------------ DoG pyramid
+
+int vslam_pyramid_build_u8(vslam_ctx* c, const uint8_t* img, int rows, int cols, size_t step, int n_octaves,
+                           double sigma0, vslam_pyramid** out) {
+    TRY(bind_device(c));
+    ARGCHK(c, img && out && rows > 0 && cols > 0 && step >= (size_t)cols && sigma0 > 0, "GaussPyramid: bad arguments");
+    *out = nullptr;
+    if (n_octaves <= 0) n_octaves = auto_num_octaves(rows, cols);  // GaussPyramid.hpp:18-21
+    ARGCHK(c, n_octaves >= 1 && n_octaves <= VSLAM_MAX_OCTAVES, "GaussPyramid: octave count out of range");
+    vslam_params p;
+    vslam_params_default(&p, rows, cols);
+    p.n_octaves = n_octaves;
+    p.sigma0 = sigma0;
+    vslam_batch_layout L;
+    if (make_layout(&p, &L) != VSLAM_OK) return fail(c, VSLAM_ERR_INVALID, "GaussPyramid: image too small for the octave count");
+    vslam_pyramid* py = new (std::nothrow) vslam_pyramid();
+    if (!py) return fail(c, VSLAM_ERR_NOMEM, "host allocation failed");
+    py->ctx = c;
+    py->params = p;
+    py->layout = L;
+    py->info.n_octaves = n_octaves;
+    py->info.n_levels = VSLAM_NUM_LEVELS;
+    py->info.n_dogs = VSLAM_NUM_DOGS;
+    py->info.sigma0 = sigma0;
+    size_t sum_p = 0;
+    for (int o = 0; o < n_octaves; ++o) {
+        py->info.rows[o] = L.rows[o];
+        py->info.cols[o] = L.cols[o];
+        py->base_off[o] = sum_p;
+        sum_p += (size_t)L.rows[o] * L.cols[o];
+        for (int l = 0; l < VSLAM_NUM_LEVELS; ++l) {
+            py->info.sigma[o][l] = sigma_at(sigma0, o, l);
+            py->info.ksize[o][l] = gauss_ksize_u8(py->info.sigma[o][l]);
+        }
+    }
+    auto cleanup = [&](int rc) {
+        vslam_pyramid_destroy(py);
+        return rc;
+    };
+    if (hipMalloc((void**)&py->d_block, L.pyramid_frame_bytes) != hipSuccess ||
+        hipMalloc((void**)&py->d_bases, sum_p) != hipSuccess)
+        return cleanup(fail(c, VSLAM_ERR_NOMEM, "device allocation failed (pyramid)"));
+    const size_t N = (size_t)rows * cols;
+    int rc = ws_reserve(c, ws_need(N) + dog_scratch_bytes(L, 1));
+    if (rc) return cleanup(rc);
+    uint8_t* d_img = ws_take<uint8_t>(c, N);
+    DogScratch s;
+    if ((rc = dog_scratch_take(c, L, 1, s))) return cleanup(rc);
+    if ((rc = h2d(c, d_img, cols, img, step, cols, rows))) return cleanup(rc);
+    if ((rc = enqueue_dog(c, p, L, d_img, cols, N, 1, py->d_block, L.pyramid_frame_bytes, s, nullptr, false, nullptr,
+                          nullptr)))
+        return cleanup(rc);
+    if (hipMemcpyAsync(py->d_bases, s.bases, sum_p, hipMemcpyDeviceToDevice, c->stream) != hipSuccess)
+        return cleanup(fail(c, VSLAM_ERR_HIP, "device copy failed (bases)"));
+    if ((rc = vslam_ctx_sync(c))) return cleanup(rc);
+    *out = py;
+    return VSLAM_OK;
+}
+
+int vslam_pyramid_destroy(vslam_pyramid* py) {
+    if (!py) return VSLAM_ERR_INVALID;
+    if (py->ctx) (void)hipSetDevice(py->ctx->device);
+    if (py->d_block) (void)hipFree(py->d_block);
+    if (py->d_bases) (void)hipFree(py->d_bases);
+    delete py;
+    return VSLAM_OK;
+}
+
+int vslam_pyramid_get_info(const vslam_pyramid* py, vslam_pyramid_info* out) {
+    if (!py || !out) return VSLAM_ERR_INVALID;
+    *out = py->info;
+    return VSLAM_OK;
+}
+
+static int pyramid_fetch(const vslam_pyramid* py, int octave, const uint8_t* d_src, uint8_t* dst, size_t dst_step) {
+    vslam_ctx* c = py->ctx;
+    TRY(bind_device(c));
+    const int rows = py->layout.rows[octave], cols = py->layout.cols[octave];
+    ARGCHK(c, dst && dst_step >= (size_t)cols, "pyramid getter: bad destination");
+    TRY(d2h(c, dst, dst_step, d_src, cols, cols, rows));
+    return vslam_ctx_sync(c);
+}
+
+int vslam_pyramid_get_base(const vslam_pyramid* py, int octave, uint8_t* dst, size_t dst_step) {
+    if (!py) return VSLAM_ERR_INVALID;
+    if (octave < 0 || octave >= py->layout.n_octaves) return fail(py->ctx, VSLAM_ERR_RANGE, "octave out of range");
+    return pyramid_fetch(py, octave, py->d_bases + py->base_off[octave], dst, dst_step);
+}
+
+int vslam_pyramid_get_gauss(const vslam_pyramid* py, int octave, int level, uint8_t* dst, size_t dst_step) {
+    if (!py) return VSLAM_ERR_INVALID;
+    if (octave < 0 || octave >= py->layout.n_octaves || level < 0 || level >= VSLAM_NUM_LEVELS)
+        return fail(py->ctx, VSLAM_ERR_RANGE, "octave/level out of range");
+    const size_t P = (size_t)py->layout.rows[octave] * py->layout.cols[octave];
+    return pyramid_fetch(py, octave, py->d_block + py->layout.octave_offset[octave] + (size_t)level * P, dst, dst_step);
+}
+
+int vslam_pyramid_get_dog(const vslam_pyramid* py, int octave, int level, uint8_t* dst, size_t dst_step) {
+    if (!py) return VSLAM_ERR_INVALID;
+    if (octave < 0 || octave >= py->layout.n_octaves || level < 0 || level >= VSLAM_NUM_DOGS)
+        return fail(py->ctx, VSLAM_ERR_RANGE, "octave/level out of range");
+    const size_t P = (size_t)py->layout.rows[octave] * py->layout.cols[octave];
+    return pyramid_fetch(py, octave,
+                         py->d_block + py->layout.octave_offset[octave] + (size_t)(VSLAM_NUM_LEVELS + level) * P, dst,
+                         dst_step);
+}
+
+int vslam_dog_extrema(vslam_ctx* c, const vslam_pyramid* py, int octave, int window, int min_contrast, uint64_t* bits,
+                      vslam_point* out, size_t cap, size_t* count) {
+    TRY(bind_device(c));
+    ARGCHK(c, py && py->ctx == c && count && (out || cap == 0), "initialKeypointDetection: bad arguments");
+    if (octave < 0 || octave >= py->layout.n_octaves) return fail(c, VSLAM_ERR_RANGE, "octave out of range");
+    ARGCHK(c, window >= 3 && (window & 1), "initialKeypointDetection: windowSize must be odd and >= 3");
+    vslam_params p = py->params;
+    p.extrema_window = window;
+    p.min_contrast = min_contrast;
+    p.dog_cap = (uint32_t)std::min<size_t>(cap, 0x7fffffff);
+    vslam_batch_layout L;
+    if (make_layout(&p, &L) != VSLAM_OK) return fail(c, VSLAM_ERR_INVALID, "bad extrema parameters");
+    ExtGeom g;
+    fill_geom(p, L, g);
+    const size_t words = L.bits_frame_words;
+    TRY(ws_reserve(c, 2 * ws_need(words * 8) + ws_need(sizeof(vslam_point) * (size_t)p.dog_cap) + 256));
+    unsigned long long* d_bits = ws_take<unsigned long long>(c, words);
+    unsigned long long* d_lf = ws_take<unsigned long long>(c, words);
+    vslam_point* d_pts = ws_take<vslam_point>(c, p.dog_cap);
+    unsigned int* d_n = ws_take<unsigned int>(c, 1);
+    HIPCHK(c, hipMemsetAsync(d_n, 0, 4, c->stream));
+    const size_t ow = (size_t)3 * L.lat_rows[octave] * L.lat_words[octave];
+    if (ow) {
+        LAUNCH(c, "k_extrema", k_extrema, dim3((L.lat_cols[octave] + 255) / 256, L.lat_rows[octave], 3), dim3(256),
+               py->d_block, L.pyramid_frame_bytes, g, octave, d_bits, d_lf, words);
+        LAUNCH(c, "k_compact_dog", k_compact_dog, dim3(1), dim3(1024), d_lf, words, py->d_block, L.pyramid_frame_bytes, g,
+               octave, octave + 1, d_pts, p.dog_cap, d_n);
+    }
+    unsigned int n = 0;
+    HIPCHK(c, hipMemcpyAsync(&n, d_n, 4, hipMemcpyDeviceToHost, c->stream));
+    if (bits && ow)
+        HIPCHK(c, hipMemcpyAsync(bits, d_bits + L.bits_offset[octave], ow * 8, hipMemcpyDeviceToHost, c->stream));
+    TRY(vslam_ctx_sync(c));
+    *count = n;
+    const size_t m = std::min<size_t>(n, p.dog_cap);
+    if (m) HIPCHK(c, hipMemcpy(out, d_pts, m * sizeof(vslam_point), hipMemcpyDeviceToHost));
+    return VSLAM_OK;
+}
+
+// ------------------------------------------------------------- device-resident batched path
+
+int vslam_detect_batch_dev(vslam_ctx* c, const vslam_params* pp, const uint8_t* d_frames, size_t frame_stride,
+                           int n_frames, const vslam_batch_out* out) {
+    TRY(bind_device(c));
+    ARGCHK(c, pp && d_frames && out && n_frames > 0, "detect_batch: bad arguments");
+    const vslam_params p = *pp;
+    ARGCHK(c, p.rows > 0 && p.cols > 0 && frame_stride >= (size_t)p.rows * p.cols, "detect_batch: bad frame geometry");
+    vslam_batch_layout L;
+    if (make_layout(&p, &L) != VSLAM_OK) return fail(c, VSLAM_ERR_INVALID, "detect_batch: bad parameters");
+    const bool dog = p.n_octaves > 0;
+    const bool want_kps = out->harris_kps && out->harris_counts;
+    const bool harris = p.do_harris && (out->response || out->nms_mask || out->nms2 || want_kps);
+    ARGCHK(c, !dog || out->pyramid, "detect_batch: the DoG path needs out->pyramid");
+    const size_t N = (size_t)p.rows * p.cols;
+    const int wpr = (p.cols + 63) / 64;
+    const int chunk = std::min(n_frames, 8);  // bounds the scratch (octave bases + u16 row pass)
+    size_t need = 0;
+    if (dog) need += dog_scratch_bytes(L, chunk);
+    if (harris) need += (out->response ? 0 : ws_need((size_t)chunk * N * 4)) + ws_need((size_t)chunk * p.rows * wpr * 8);
+    TRY(ws_reserve(c, need));
+    DogScratch s;
+    if (dog) TRY(dog_scratch_take(c, L, chunk, s));
+    float* resp_ws = (harris && !out->response) ? ws_take<float>(c, (size_t)chunk * N) : nullptr;
+    unsigned long long* hflags = harris ? ws_take<unsigned long long>(c, (size_t)chunk * p.rows * wpr) : nullptr;
+    for (int f0 = 0; f0 < n_frames; f0 += chunk) {
+        const int nf = std::min(chunk, n_frames - f0);
+        const uint8_t* fr = d_frames + (size_t)f0 * frame_stride;
+        if (harris) {
+            float* resp = out->response ? out->response + (size_t)f0 * N : resp_ws;
+            TRY(enqueue_harris(c, fr, p.cols, frame_stride, p.rows, p.cols, nf, p.harris_k, resp,
+                               out->nms_mask ? out->nms_mask + (size_t)f0 * N : nullptr,
+                               out->nms2 ? out->nms2 + (size_t)f0 * N : nullptr, want_kps ? hflags : nullptr,
+                               want_kps ? out->harris_kps + (size_t)f0 * p.harris_cap : nullptr, p.harris_cap,
+                               want_kps ? out->harris_counts + f0 : nullptr));
+        }
+        if (dog) {
+            const bool ext = out->extrema_bits || (out->dog_points && out->dog_counts);
+            TRY(enqueue_dog(c, p, L, fr, p.cols, frame_stride, nf, out->pyramid + (size_t)f0 * L.pyramid_frame_bytes,
+                            L.pyramid_frame_bytes, s,
+                            out->extrema_bits ? (unsigned long long*)out->extrema_bits + (size_t)f0 * L.bits_frame_words : nullptr,
+                            ext, out->dog_points ? out->dog_points + (size_t)f0 * p.dog_cap : nullptr,
+                            out->dog_counts ? out->dog_counts + f0 : nullptr));
+        }
+    }
+    return VSLAM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,167 @@
+// Host-side parameter math of the C ABI (no GPU involved): Gaussian tap quantisation,
+// pyramid geometry and the batch output layout.  Each rule that restates OpenCV
+// behaviour is isolated in one function so it can be corrected if an OpenCV build ever
+// becomes available (SURVEY.md section 7 "No external truth").
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "../../include/vslam.h"
+#include "vslam_internal.h"
+
+namespace vslam {
+
+// cvRound(double): round half to even under the default rounding mode.
+static inline long cv_round(double v) { return std::lrint(v); }
+
+int gauss_ksize_u8(double sigma) { return (int)cv_round(sigma * 3 * 2 + 1) | 1; }
+
+// cv::getGaussianKernel as used by the CV_8U fixed-point GaussianBlur (OpenCV >= 4.5.1):
+// normalised double kernel, then 8.8 quantisation with error diffusion from the outermost
+// tap inwards; the centre tap takes the remainder so the taps sum to exactly 256.
+bool gauss_taps_q8(int n, double sigma, uint16_t* taps) {
+    if (n <= 0 || (n & 1) == 0 || n > VSLAM_MAX_KSIZE) return false;
+    std::vector<double> kf((size_t)n);
+    const int half = (n - 1) / 2;
+    static const double k3[] = {0.25, 0.5, 0.25};
+    static const double k5[] = {0.0625, 0.25, 0.375, 0.25, 0.0625};
+    static const double k7[] = {0.03125, 0.109375, 0.21875, 0.28125, 0.21875, 0.109375, 0.03125};
+    if (sigma <= 0 && n == 1) {
+        kf[0] = 1.0;
+    } else if (sigma <= 0 && n == 3) {
+        kf.assign(k3, k3 + 3);
+    } else if (sigma <= 0 && n == 5) {
+        kf.assign(k5, k5 + 5);
+    } else if (sigma <= 0 && n == 7) {
+        kf.assign(k7, k7 + 7);
+    } else {
+        const double s = sigma > 0 ? sigma : std::fma((double)n, 0.15, 0.35);
+        const double scale = -0.125 / (s * s);
+        double sum = 0.0;
+        for (int i = 0, x = 1 - n; i < half; ++i, x += 2) {
+            kf[i] = std::exp((double)(x * x) * scale);
+            sum += kf[i];
+        }
+        sum = sum * 2.0 + 1.0;
+        const double inv = 1.0 / sum;
+        for (int i = 0; i < half; ++i) kf[n - 1 - i] = kf[i] = kf[i] * inv;
+        kf[half] = inv;
+    }
+    double err = 0.0;
+    long acc = 0;
+    for (int i = 0; i < n / 2; ++i) {
+        const double adj = kf[i] * 256.0 + err;
+        const long q = cv_round(adj);
+        err = adj - (double)q;
+        taps[i] = taps[n - 1 - i] = (uint16_t)q;
+        acc += q;
+    }
+    taps[n / 2] = (uint16_t)(256 - 2 * acc);
+    return true;
+}
+
+double sigma_at(double sigma0, int octave, int level) {
+    const double k = std::pow(2.0f, 1.0f / (double)3);  // GaussPyramid.hpp:69
+    return std::pow(2, octave) * sigma0 * std::pow(k, level);
+}
+
+int auto_num_octaves(int rows, int cols) {
+    const int m = rows < cols ? rows : cols;
+    return (int)std::floor(std::log2((double)m)) - 4;
+}
+
+void half_size(int rows, int cols, int* r, int* c) {
+    *r = (int)cv_round(rows * 0.5);
+    *c = (int)cv_round(cols * 0.5);
+}
+
+void extrema_lattice(int rows, int cols, int window, int* lr, int* lc) {
+    const int pad = (window - 1) / 2;
+    *lr = rows > pad ? (rows - pad + window - 1) / window : 0;
+    *lc = cols > pad ? (cols - pad + window - 1) / window : 0;
+}
+
+int make_layout(const vslam_params* p, vslam_batch_layout* L) {
+    if (!p || !L || p->rows <= 0 || p->cols <= 0 || p->n_octaves < 0 || p->n_octaves > VSLAM_MAX_OCTAVES)
+        return VSLAM_ERR_INVALID;
+    if (p->n_octaves > 0 && (!(p->sigma0 > 0) || p->extrema_window < 3 || (p->extrema_window & 1) == 0))
+        return VSLAM_ERR_INVALID;
+    std::memset(L, 0, sizeof(*L));
+    L->n_octaves = p->n_octaves;
+    int r = p->rows * 2, c = p->cols * 2;
+    size_t off = 0, woff = 0, sum_p = 0;
+    for (int o = 0; o < p->n_octaves; ++o) {
+        if (r <= 0 || c <= 0) return VSLAM_ERR_INVALID;
+        L->rows[o] = r;
+        L->cols[o] = c;
+        extrema_lattice(r, c, p->extrema_window, &L->lat_rows[o], &L->lat_cols[o]);
+        L->lat_words[o] = (L->lat_cols[o] + 63) / 64;
+        L->octave_offset[o] = off;
+        L->bits_offset[o] = woff;
+        const size_t P = (size_t)r * c;
+        sum_p += P;
+        off += (VSLAM_NUM_LEVELS + VSLAM_NUM_DOGS) * P;
+        woff += (size_t)3 * L->lat_rows[o] * L->lat_words[o];
+        half_size(r, c, &r, &c);
+    }
+    L->pyramid_frame_bytes = (off + 255) & ~(size_t)255;
+    L->bits_frame_words = woff;
+    const size_t N = (size_t)p->rows * p->cols;
+    L->algorithmic_bytes_harris = 6 * N;            // u8 in + f32 response + u8 mask
+    L->algorithmic_bytes_dog = N + 11 * sum_p;      // u8 in + 6 Gaussian + 5 DoG stacks
+    return VSLAM_OK;
+}
+
+}  // namespace vslam
+
+extern "C" {
+
+int vslam_version(void) { return VSLAM_VERSION; }
+
+const char* vslam_status_string(int s) {
+    switch (s) {
+        case VSLAM_OK: return "ok";
+        case VSLAM_ERR_INVALID: return "invalid argument";
+        case VSLAM_ERR_HIP: return "HIP runtime error";
+        case VSLAM_ERR_NOMEM: return "out of memory";
+        case VSLAM_ERR_UNSUPPORTED: return "unsupported parameter combination";
+        case VSLAM_ERR_RANGE: return "octave/level out of range";
+        default: return "unknown status";
+    }
+}
+
+int vslam_gauss_ksize_u8(double sigma) { return vslam::gauss_ksize_u8(sigma); }
+
+int vslam_gauss_taps_q8(int n, double sigma, uint16_t* taps) {
+    if (!taps) return VSLAM_ERR_INVALID;
+    return vslam::gauss_taps_q8(n, sigma, taps) ? VSLAM_OK : VSLAM_ERR_INVALID;
+}
+
+double vslam_sigma_at(double sigma0, int octave, int level) { return vslam::sigma_at(sigma0, octave, level); }
+int vslam_auto_num_octaves(int rows, int cols) { return vslam::auto_num_octaves(rows, cols); }
+
+void vslam_half_size(int rows, int cols, int* out_rows, int* out_cols) {
+    vslam::half_size(rows, cols, out_rows, out_cols);
+}
+
+void vslam_extrema_lattice(int rows, int cols, int window, int* lat_rows, int* lat_cols) {
+    vslam::extrema_lattice(rows, cols, window, lat_rows, lat_cols);
+}
+
+void vslam_params_default(vslam_params* p, int rows, int cols) {
+    if (!p) return;
+    p->rows = rows;
+    p->cols = cols;
+    p->n_octaves = 4;        // Diff_of_Gauss.cpp:742
+    p->sigma0 = 1.6;         // Diff_of_Gauss.cpp:743
+    p->harris_k = 0.04f;     // Harris_corners.cpp:36
+    p->do_harris = 1;
+    p->extrema_window = 3;   // Diff_of_Gauss.cpp:772
+    p->min_contrast = 8;
+    p->harris_cap = 1u << 18;
+    p->dog_cap = 1u << 18;
+}
+
+int vslam_batch_layout_query(const vslam_params* p, vslam_batch_layout* out) { return vslam::make_layout(p, out); }
+
+}  // extern "C"
