@@ -129,6 +129,15 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} is missing -- run __graft_entry__.build() (the product has no CPU fallback)")
+        # One HIP runtime per process: torch bundles its own libamdhip64.so.7 / libhsa-runtime64
+        # (same sonames as /opt/rocm).  If libvslam.so pulled in /opt/rocm's copy first, torch
+        # would later mix it with its bundled HSA runtime and HIP fails to initialise.  So in a
+        # Python process that has torch, let torch load its runtime first; libvslam.so then binds
+        # to that same copy.  (C++ callers without torch simply use /opt/rocm's runtime.)
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)
