@@ -167,3 +167,16 @@ def test_batch_argument_errors(env):
     bad = capi.default_params(32, 32, extrema_window=4)
     with pytest.raises(capi.VslamError):
         ctx.detect_batch(bad, frames, pyramid=torch.zeros(1 << 20, dtype=torch.uint8, device="cuda:0"))
+
+
+def test_fast_paths_are_the_ones_that_run(env):
+    # the specialised kernels must actually be dispatched for the reference configuration
+    # (a silent fall-back to the generic kernels would still pass parity)
+    ctx, torch = env
+    frames = synth.frames_np(1, 480, 640, stream_id=1)
+    for name, want in (("k_pyr_octave", 2), ("k_harris_fused", 1)):
+        ctx.kernel_timing_enable(name)
+        run_batch(ctx, torch, frames)
+        launches, ms = ctx.kernel_timing_read()
+        ctx.kernel_timing_enable(None)
+        assert launches >= want and ms > 0, (name, launches)

@@ -1,0 +1,259 @@
+// K-D1: fused scale-space octave for gfx950.
+//
+// One launch turns the octave base (u8) into the octave's six Gaussian images and five DoG
+// images -- GaussVector + Diff_of_Gauss of GaussPyramid.cpp:166-200 -- reading the base
+// once per tile (plus halo) and writing each of the 11 images exactly once.  Nothing
+// intermediate touches HBM: the separable passes live in LDS.
+//
+// Arithmetic: G = (sum_y sum_x ty*tx*p + 32768) >> 16 is an exact
+// integer expression, so any evaluation order gives the reference result.  Per level:
+//   pass 1 (vertical)   h(y,x) = sum_k t[k]*p(y-r+k, x)     u8 x u8 taps  -> v_dot4_u32_u8
+//   pass 2 (horizontal) acc    = sum_k t[k]*h(y, x-r+k)     u16 x u16 taps -> v_dot2_u32_u16
+// (all quantised taps are <= 64 for sigma >= 1.6, h <= 65280, acc < 2^24).  No MFMA.
+//
+// Data layout in LDS (one 256-thread workgroup = one TW x TH output tile):
+//   rp  [(TH+2R)/4][RWP]  dwords: the base tile with halo R, BYTE-TRANSPOSED so that one dword
+//        holds 4 vertically adjacent pixels of one column -- the operand shape of a vertical
+//        dot4.  Filled once per tile (v_perm 4x4 transposes); image borders are resolved at
+//        fill time by storing the BORDER_REFLECT_101 extension (valid for every level because
+//        the taps are symmetric).
+//   hp  [TH][HPP]         dwords: pass-1 output of the current level as u16 PAIRS of
+//        horizontally adjacent columns -- the operand shape of a horizontal dot2.
+// Taps come from the kernel-argument segment (scalar loads, SGPR operands): t4[l][o][m] =
+// 4 taps packed as bytes for window alignment o, tp[l][e] = taps (e-1, e) packed as u16.
+// Kernel widths are template parameters, so every loop is fully unrolled and all-zero tap
+// words are skipped at compile time.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "kernels_generic.hip.h"
+
+namespace vslam {
+
+typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t udot4(uint32_t a, uint32_t b, uint32_t c) {
+    return __builtin_amdgcn_udot4(a, b, c, false);
+}
+__device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t b, uint32_t c) {
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(us2_t, a), __builtin_bit_cast(us2_t, b), c, false);
+}
+// packed u16 saturating subtract (v_pk_sub_u16 clamp)
+__device__ __forceinline__ uint32_t pk_sub_sat_u16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(us2_t, a), __builtin_bit_cast(us2_t, b)));
+}
+
+template <int TW_, int TH_, int N0, int N1, int N2, int N3, int N4, int N5>
+struct PyrCfg {
+    static constexpr int TW = TW_, TH = TH_;
+    static constexpr int n(int l) { return l == 0 ? N0 : l == 1 ? N1 : l == 2 ? N2 : l == 3 ? N3 : l == 4 ? N4 : N5; }
+    static constexpr int cmax(int a, int b) { return a > b ? a : b; }
+    static constexpr int NMAX = cmax(cmax(cmax(N0, N1), cmax(N2, N3)), cmax(N4, N5));
+    static constexpr int R = (NMAX / 2 + 3) & ~3;  // halo, multiple of 4
+    static constexpr int RQ = (TH + 2 * R) / 4;    // row quads of the raw tile
+    static constexpr int RW = TW + 2 * R;          // raw tile width (pixels == rp dwords per row quad)
+    static constexpr int RWP = RW + 4;             // padded pitch (pass 1 may read 1 dword group past RW)
+    static constexpr int r(int l) { return n(l) / 2; }
+    static constexpr int delta(int l) { return (R - r(l)) & 3; }
+    static constexpr int A(int l) { return (R - r(l)) & ~3; }
+    static constexpr int ncg(int l) { return (TW + 2 * r(l) + delta(l) + 3) / 4; }   // h column groups of 4
+    static constexpr int m1(int l) { return ((delta(l) + 3 + n(l) - 1) >> 2) + 1; } // rp dwords per pass-1 item column
+    static constexpr int pmax(int l) { return (7 + delta(l) + 2 * r(l)) / 2; }      // last u16 pair a pass-2 item reads
+    static constexpr int nb(int l) { return pmax(l) / 4 + 1; }                      // b128 reads per row
+    static constexpr int hpp_l(int l) { return cmax(2 * ncg(l), TW / 2 - 4 + 4 * nb(l)); }
+    static constexpr int HPP =
+        (cmax(cmax(cmax(hpp_l(0), hpp_l(1)), cmax(hpp_l(2), hpp_l(3))), cmax(hpp_l(4), hpp_l(5))) + 15) & ~15;
+    static constexpr int T4M = ((3 + NMAX - 1) >> 2) + 1;  // tap dwords per alignment
+    static constexpr int TPM = NMAX + 1;                   // tap pairs
+    static constexpr int LDS_BYTES = (RQ * RWP + TH * HPP) * 4;
+    static_assert(TW % 8 == 0 && TH % 4 == 0 && (TH / 4) * (TW / 8) == 256, "one pass-2 item per thread");
+    static_assert((N0 & 1) && (N1 & 1) && (N2 & 1) && (N3 & 1) && (N4 & 1) && (N5 & 1), "odd kernels");
+};
+
+template <class CFG>
+struct PyrTaps {
+    uint32_t t4[6][4][CFG::T4M];
+    uint32_t tp[6][CFG::TPM];
+};
+
+// One Gaussian level of the tile: pass 1 into hp, pass 2 into registers, pack, DoG, store.
+template <class CFG, int L>
+__device__ __forceinline__ void pyr_level(const PyrTaps<CFG>& taps, const uint32_t* __restrict__ rp,
+                                          uint32_t* __restrict__ hp, uint8_t* __restrict__ out, size_t P, int cols,
+                                          int rows, int tile_x0, int tile_y0, uint32_t (&prev_e)[4][2],
+                                          uint32_t (&prev_o)[4][2]) {
+    constexpr int n = CFG::n(L), dl = CFG::delta(L), A = CFG::A(L);
+    constexpr int NCG = CFG::ncg(L), M = CFG::m1(L), NB = CFG::nb(L);
+    constexpr int RWP = CFG::RWP, HPP = CFG::HPP, TH = CFG::TH;
+    const int tid = threadIdx.x;
+
+    // ---- pass 1: vertical, item = 4 h-columns x 4 rows --------------------------------------
+    for (int it = tid; it < NCG * (TH / 4); it += 256) {
+        const int cg = it % NCG, rq = it / NCG;
+        uint32_t acc[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[j][c] = 0;
+        const uint4* col = reinterpret_cast<const uint4*>(rp + (rq + A / 4) * RWP + 4 * cg + A);
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            const uint4 v = col[m * (RWP / 4)];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int s = dl + j, o = s & 3, mm = m - (s >> 2);
+                if (mm >= 0 && mm <= ((o + n - 1) >> 2)) {
+                    const uint32_t t = taps.t4[L][o][mm];
+                    acc[j][0] = udot4(v.x, t, acc[j][0]);
+                    acc[j][1] = udot4(v.y, t, acc[j][1]);
+                    acc[j][2] = udot4(v.z, t, acc[j][2]);
+                    acc[j][3] = udot4(v.w, t, acc[j][3]);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint2 w;
+            w.x = acc[j][0] | (acc[j][1] << 16);
+            w.y = acc[j][2] | (acc[j][3] << 16);
+            *reinterpret_cast<uint2*>(hp + (4 * rq + j) * HPP + 2 * cg) = w;
+        }
+    }
+    __syncthreads();
+
+    // ---- pass 2: horizontal, item = 8 columns x 4 rows (exactly one per thread) -------------
+    const int xg = tid & (CFG::TW / 8 - 1), rg = tid / (CFG::TW / 8);
+    uint32_t acc[4][8];
+#pragma unroll
+    for (int jr = 0; jr < 4; ++jr)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[jr][j] = 32768u;  // the one round-half-up of A2-iv
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+#pragma unroll
+        for (int jr = 0; jr < 4; ++jr) {
+            const uint4 v = *reinterpret_cast<const uint4*>(hp + (4 * rg + jr) * HPP + 4 * xg + 4 * b);
+            const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int e = 2 * (4 * b + pp) - j - dl + 1;  // tap pair (e-1, e)
+                    if (e >= 0 && e <= n) acc[jr][j] = udot2(vv[pp], taps.tp[L][e], acc[jr][j]);
+                }
+            }
+        }
+    }
+    __syncthreads();  // hp is free for the next level's pass 1
+
+    // ---- pack (G = acc >> 16 is byte 2 of acc), DoG, store ----------------------------------
+    const int x = tile_x0 + 8 * xg;
+#pragma unroll
+    for (int jr = 0; jr < 4; ++jr) {
+        const int y = tile_y0 + 4 * rg + jr;
+        uint32_t g[2], d[2];
+#pragma unroll
+        for (int hw = 0; hw < 2; ++hw) {
+            const uint32_t lo = __builtin_amdgcn_perm(acc[jr][4 * hw + 1], acc[jr][4 * hw + 0], 0x0c0c0602);
+            const uint32_t hi = __builtin_amdgcn_perm(acc[jr][4 * hw + 3], acc[jr][4 * hw + 2], 0x0c0c0602);
+            g[hw] = __builtin_amdgcn_perm(hi, lo, 0x05040100);
+            const uint32_t e = g[hw] & 0x00ff00ffu, o = (g[hw] >> 8) & 0x00ff00ffu;
+            if (L > 0) {  // D_{L-1} = saturate_u8(G_L - G_{L-1}), GaussPyramid.cpp:197
+                const uint32_t de = pk_sub_sat_u16(e, prev_e[jr][hw]), dod = pk_sub_sat_u16(o, prev_o[jr][hw]);
+                d[hw] = de | (dod << 8);
+            }
+            prev_e[jr][hw] = e;
+            prev_o[jr][hw] = o;
+        }
+        if (y < rows && x < cols) {
+            const size_t off = (size_t)y * cols + x;
+            *reinterpret_cast<uint2*>(out + (size_t)L * P + off) = make_uint2(g[0], g[1]);
+            if (L > 0) *reinterpret_cast<uint2*>(out + (size_t)(VSLAM_NUM_LEVELS + L - 1) * P + off) = make_uint2(d[0], d[1]);
+        }
+    }
+}
+
+// grid = (ceil(cols/TW), ceil(rows/TH), frames); block = 256; dynamic LDS = CFG::LDS_BYTES.
+// Requires cols % 8 == 0 (8-byte row stores); rows arbitrary.
+template <class CFG>
+__global__ __launch_bounds__(256) void k_pyr_octave(const uint8_t* __restrict__ base, size_t bframe,
+                                                     uint8_t* __restrict__ oct_out, size_t pframe, int rows, int cols,
+                                                     const PyrTaps<CFG> taps) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint32_t* rp = smem;
+    uint32_t* hp = smem + CFG::RQ * CFG::RWP;
+    constexpr int R = CFG::R, RW = CFG::RW, RWP = CFG::RWP, RQ = CFG::RQ;
+    const int tid = threadIdx.x;
+    const int tile_x0 = blockIdx.x * CFG::TW, tile_y0 = blockIdx.y * CFG::TH;
+    const uint8_t* src = base + blockIdx.z * bframe;
+    uint8_t* out = oct_out + blockIdx.z * pframe;
+    const size_t P = (size_t)rows * cols;
+
+    // ---- stage the base tile, byte-transposed ------------------------------------------------
+    const bool interior = tile_x0 - R >= 0 && tile_x0 + CFG::TW + R <= cols && tile_y0 - R >= 0 &&
+                          tile_y0 + CFG::TH + R <= rows;
+    for (int it = tid; it < RQ * (RW / 4); it += 256) {
+        const int yq = it / (RW / 4), xq = it - yq * (RW / 4);
+        const int gy = tile_y0 - R + 4 * yq, gx = tile_x0 - R + 4 * xq;
+        uint32_t a[4];
+        if (interior) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a[k] = *reinterpret_cast<const uint32_t*>(src + (size_t)(gy + k) * cols + gx);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint8_t* row = src + (size_t)reflect101(gy + k, rows) * cols;
+                a[k] = (uint32_t)row[reflect101(gx, cols)] | ((uint32_t)row[reflect101(gx + 1, cols)] << 8) |
+                       ((uint32_t)row[reflect101(gx + 2, cols)] << 16) | ((uint32_t)row[reflect101(gx + 3, cols)] << 24);
+            }
+        }
+        // 4x4 byte transpose: t[c] = (a0.c, a1.c, a2.c, a3.c)
+        const uint32_t p01l = __builtin_amdgcn_perm(a[1], a[0], 0x05010400), p01h = __builtin_amdgcn_perm(a[1], a[0], 0x07030602);
+        const uint32_t p23l = __builtin_amdgcn_perm(a[3], a[2], 0x05010400), p23h = __builtin_amdgcn_perm(a[3], a[2], 0x07030602);
+        uint4 t;
+        t.x = __builtin_amdgcn_perm(p23l, p01l, 0x05040100);
+        t.y = __builtin_amdgcn_perm(p23l, p01l, 0x07060302);
+        t.z = __builtin_amdgcn_perm(p23h, p01h, 0x05040100);
+        t.w = __builtin_amdgcn_perm(p23h, p01h, 0x07060302);
+        *reinterpret_cast<uint4*>(rp + yq * RWP + 4 * xq) = t;
+    }
+    // the 4 pad dwords per row quad feed only h columns that pass 2 never reads (integers:
+    // any value is harmless), so they are left uninitialised.
+    __syncthreads();
+
+    uint32_t prev_e[4][2], prev_o[4][2];
+    pyr_level<CFG, 0>(taps, rp, hp, out, P, cols, rows, tile_x0, tile_y0, prev_e, prev_o);
+    pyr_level<CFG, 1>(taps, rp, hp, out, P, cols, rows, tile_x0, tile_y0, prev_e, prev_o);
+    pyr_level<CFG, 2>(taps, rp, hp, out, P, cols, rows, tile_x0, tile_y0, prev_e, prev_o);
+    pyr_level<CFG, 3>(taps, rp, hp, out, P, cols, rows, tile_x0, tile_y0, prev_e, prev_o);
+    pyr_level<CFG, 4>(taps, rp, hp, out, P, cols, rows, tile_x0, tile_y0, prev_e, prev_o);
+    pyr_level<CFG, 5>(taps, rp, hp, out, P, cols, rows, tile_x0, tile_y0, prev_e, prev_o);
+}
+
+// Host side: pack quantised taps into the operand shapes described at the top.
+template <class CFG>
+static void pyr_pack_taps(const uint16_t* const t[6], PyrTaps<CFG>& out) {
+    for (int l = 0; l < 6; ++l) {
+        const int n = CFG::n(l);
+        for (int o = 0; o < 4; ++o)
+            for (int m = 0; m < CFG::T4M; ++m) {
+                uint32_t w = 0;
+                for (int b = 0; b < 4; ++b) {
+                    const int k = 4 * m + b - o;
+                    if (k >= 0 && k < n) w |= (uint32_t)(t[l][k] & 0xff) << (8 * b);
+                }
+                out.t4[l][o][m] = w;
+            }
+        for (int e = 0; e < CFG::TPM; ++e) {
+            const uint32_t lo = (e - 1 >= 0 && e - 1 < n) ? t[l][e - 1] : 0, hi = e < n ? t[l][e] : 0;
+            out.tp[l][e] = lo | (hi << 16);
+        }
+    }
+}
+
+// The reference's fixed pyramid (sigma0 = 1.6, Diff_of_Gauss.cpp:743): kernel widths of
+// SURVEY.md Appendix C for octaves 0 and 1.
+using PyrCfgOct0 = PyrCfg<128, 64, 11, 13, 17, 21, 25, 31>;
+using PyrCfgOct1 = PyrCfg<128, 64, 21, 25, 31, 39, 49, 63>;
+
+}  // namespace vslam

@@ -1,0 +1,238 @@
+// K-D2 / K-D3: separable Gaussian levels for the coarse octaves (wide kernels on small images).
+//
+// Octaves >= 2 of the reference pyramid have 39..245-tap kernels on 960x540 / 480x270 images
+// (SURVEY.md Appendix C): a 2-D tile would be mostly halo.  Here each pass keeps the WHOLE
+// extent of its filtering axis in LDS, so there is no halo recomputation at all:
+//   k_gauss_v_strip: one workgroup = a 64-column strip x all rows of the octave base, staged
+//       byte-transposed (4 vertically adjacent pixels per dword); vertical pass with
+//       v_dot4_u32_u8 for all 6 levels; writes the u16 row sums h[level] (scratch, L2/MALL).
+//   k_gauss_h_strip: one workgroup = SH rows x all columns of h[level], staged as u16 pairs with
+//       the BORDER_REFLECT_101 extension; horizontal pass with v_dot2_u32_u16; packs G, forms the
+//       saturating DoG against the previous level and writes both.
+// Kernel widths are runtime values: the tap operands are wave-uniform scalar loads from a
+// table prepared on the host (StripTaps).  Arithmetic is the exact integer form of SURVEY A2.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "kernels_pyramid.hip.h"
+
+namespace vslam {
+
+constexpr int STRIP_W = 64;        // columns per vertical-pass workgroup
+constexpr int STRIP_MAXM = 64;     // tap dword groups per level: ceil((245+3)/4) = 62
+constexpr int STRIP_MAXTP = 272;   // padded u16 tap-pair table: 8 + (245+1) + 16, multiple of 8
+
+// Device-resident tap tables of one octave (6 levels).
+struct StripTaps {
+    // v4[l][m][j]: bytes b = taps[4m + b - j]  (window alignment j = 0..3)
+    uint32_t v4[VSLAM_NUM_LEVELS][STRIP_MAXM][4];
+    // hp[l][8 + e] = (taps[e-1], taps[e]) as u16 pair, zero outside e in [0, n]
+    uint32_t hp[VSLAM_NUM_LEVELS][STRIP_MAXTP];
+    int n[VSLAM_NUM_LEVELS];
+};
+
+// ------------------------------------------------------------------------------ vertical pass
+// grid = (ceil(cols/64), 1, frames); dynamic LDS = rhq * 64 * 4 bytes, rhq = (rows4 + 2*RM + 16)/4.
+// Requires cols % 4 == 0.  h: [frame][level][rows][cols] u16.
+__global__ __launch_bounds__(256) void k_gauss_v_strip(const uint8_t* __restrict__ base, size_t bframe,
+                                                        uint16_t* __restrict__ h, size_t hframe, int rows, int cols,
+                                                        int RM, int rhq, const StripTaps* __restrict__ taps) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint32_t* rp = smem;  // [rhq][64]: dword (yq, c) = raw rows 4yq..4yq+3 (ry = y + RM) of column c
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * STRIP_W;
+    const uint8_t* src = base + blockIdx.z * bframe;
+    const size_t P = (size_t)rows * cols;
+
+    for (int it = tid; it < rhq * (STRIP_W / 4); it += 256) {
+        const int yq = it >> 4, xq = it & 15;
+        const int gx = x0 + 4 * xq;
+        uint32_t a[4] = {0, 0, 0, 0};
+        if (gx < cols) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                a[k] = *reinterpret_cast<const uint32_t*>(src + (size_t)reflect101(4 * yq + k - RM, rows) * cols + gx);
+        }
+        const uint32_t p01l = __builtin_amdgcn_perm(a[1], a[0], 0x05010400), p01h = __builtin_amdgcn_perm(a[1], a[0], 0x07030602);
+        const uint32_t p23l = __builtin_amdgcn_perm(a[3], a[2], 0x05010400), p23h = __builtin_amdgcn_perm(a[3], a[2], 0x07030602);
+        uint4 t;
+        t.x = __builtin_amdgcn_perm(p23l, p01l, 0x05040100);
+        t.y = __builtin_amdgcn_perm(p23l, p01l, 0x07060302);
+        t.z = __builtin_amdgcn_perm(p23h, p01h, 0x05040100);
+        t.w = __builtin_amdgcn_perm(p23h, p01h, 0x07060302);
+        *reinterpret_cast<uint4*>(rp + yq * STRIP_W + 4 * xq) = t;
+    }
+    __syncthreads();
+
+    for (int l = 0; l < VSLAM_NUM_LEVELS; ++l) {
+        const int n = taps->n[l], r = n >> 1;
+        const int M = (n + 3 + 3) >> 2;            // dwords covering bytes [0, 3 + n)
+        const int phi = ((r - RM) % 4 + 4) % 4;    // item rows start where the window is dword aligned
+        const int ty_start = phi ? phi - 4 : 0;
+        const int nq = (rows - ty_start + 3) >> 2;
+        const uint4* tab = reinterpret_cast<const uint4*>(&taps->v4[l][0][0]);
+        uint16_t* hl = h + blockIdx.z * hframe + (size_t)l * P;
+        for (int it = tid; it < nq * (STRIP_W / 4); it += 256) {
+            const int cg = it & 15, q = it >> 4;
+            const int ty0 = ty_start + 4 * q;
+            uint32_t acc[4][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[j][c] = 0;
+            const uint4* col = reinterpret_cast<const uint4*>(rp + ((ty0 - r + RM) >> 2) * STRIP_W + 4 * cg);
+#pragma unroll 2
+            for (int m = 0; m < M; ++m) {
+                const uint4 v = col[m * (STRIP_W / 4)];
+                const uint4 t = tab[m];  // wave-uniform: scalar load
+                const uint32_t tt[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[j][0] = udot4(v.x, tt[j], acc[j][0]);
+                    acc[j][1] = udot4(v.y, tt[j], acc[j][1]);
+                    acc[j][2] = udot4(v.z, tt[j], acc[j][2]);
+                    acc[j][3] = udot4(v.w, tt[j], acc[j][3]);
+                }
+            }
+            const int gx = x0 + 4 * cg;
+            if (gx < cols) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int y = ty0 + j;
+                    if (y >= 0 && y < rows)
+                        *reinterpret_cast<uint2*>(hl + (size_t)y * cols + gx) =
+                            make_uint2(acc[j][0] | (acc[j][1] << 16), acc[j][2] | (acc[j][3] << 16));
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------- horizontal pass
+// One level of one item (8 columns x 4 rows): DL = r & 1 (window offset inside the first pair).
+template <int DL>
+__device__ __forceinline__ void h_item_level(const uint32_t* __restrict__ hrow, int pw, int tx0, int nb,
+                                             const uint32_t* __restrict__ tp, uint32_t (&acc)[4][8]) {
+#pragma unroll
+    for (int jr = 0; jr < 4; ++jr)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[jr][j] = 32768u;
+    for (int b = 0; b < nb; ++b) {
+        // tap pairs e in [8b-8, 8b+8): 16 wave-uniform dwords
+        uint32_t T[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) T[i] = tp[8 * b + i];
+#pragma unroll
+        for (int jr = 0; jr < 4; ++jr) {
+            const uint4 v = *reinterpret_cast<const uint4*>(hrow + jr * pw + (tx0 >> 1) + 4 * b);
+            const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    // e = 2(4b+pp) - j - DL + 1 ; table index = e + 8 - 8b
+                    const int ti = 2 * pp - j - DL + 1 + 8;
+                    acc[jr][j] = udot2(vv[pp], T[ti], acc[jr][j]);
+                }
+        }
+    }
+}
+
+// grid = (1, ceil(rows/SH), frames); dynamic LDS = SH * pw * 4 bytes, pw = (cols + 2*(rmax+1) + 8)/2
+// rounded up to a multiple of 4.  Requires cols % 8 == 0 and (cols/8)*(SH/4) <= 512.
+template <int SH>
+__global__ __launch_bounds__(256) void k_gauss_h_strip(const uint16_t* __restrict__ h, size_t hframe,
+                                                        uint8_t* __restrict__ oct_out, size_t pframe, int rows,
+                                                        int cols, int pw, const StripTaps* __restrict__ taps) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint32_t* hp = smem;  // [SH][pw] u16 pairs; LDS column cx = x + PL
+    const int tid = threadIdx.x;
+    const int y0 = blockIdx.y * SH;
+    const size_t P = (size_t)rows * cols;
+    uint8_t* out = oct_out + blockIdx.z * pframe;
+    const int ncg = cols >> 3, items = ncg * (SH / 4);
+    uint32_t prev_e[2][4][2], prev_o[2][4][2];
+
+    for (int l = 0; l < VSLAM_NUM_LEVELS; ++l) {
+        const int n = taps->n[l], r = n >> 1, dl = r & 1, PL = r + dl;
+        const uint16_t* hl = h + blockIdx.z * hframe + (size_t)l * P;
+        // ---- stage SH rows, reflect-101 extended, as u16 pairs -------------------------------
+        const int npairs = (cols + 2 * PL + 2) >> 1;  // covers cx in [0, cols + 2PL + 2)
+        __syncthreads();  // previous level's reads are done
+        for (int it = tid; it < SH * npairs; it += 256) {
+            const int jr = it / npairs, pi = it - jr * npairs;
+            const int y = min(y0 + jr, rows - 1);
+            const int x = 2 * pi - PL;
+            const uint16_t* row = hl + (size_t)y * cols;
+            uint32_t w;
+            if (x >= 0 && x + 1 < cols)
+                w = *reinterpret_cast<const uint32_t*>(row + x);
+            else
+                w = (uint32_t)row[reflect101(x, cols)] | ((uint32_t)row[reflect101(x + 1, cols)] << 16);
+            hp[jr * pw + pi] = w;
+        }
+        __syncthreads();
+        const int nb = (((7 + dl + 2 * r) >> 1) >> 2) + 1;
+        const uint32_t* tp = &taps->hp[l][0];
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+            const int it = tid + ii * 256;
+            if (it < items) {
+                const int cg = it % ncg, rg = it / ncg;
+                uint32_t acc[4][8];
+                if (dl)
+                    h_item_level<1>(hp + (4 * rg) * pw, pw, 8 * cg, nb, tp, acc);
+                else
+                    h_item_level<0>(hp + (4 * rg) * pw, pw, 8 * cg, nb, tp, acc);
+                const int x = 8 * cg;
+#pragma unroll
+                for (int jr = 0; jr < 4; ++jr) {
+                    const int y = y0 + 4 * rg + jr;
+                    uint32_t g[2], d[2] = {0, 0};
+#pragma unroll
+                    for (int hw = 0; hw < 2; ++hw) {
+                        const uint32_t lo = __builtin_amdgcn_perm(acc[jr][4 * hw + 1], acc[jr][4 * hw + 0], 0x0c0c0602);
+                        const uint32_t hi = __builtin_amdgcn_perm(acc[jr][4 * hw + 3], acc[jr][4 * hw + 2], 0x0c0c0602);
+                        g[hw] = __builtin_amdgcn_perm(hi, lo, 0x05040100);
+                        const uint32_t e = g[hw] & 0x00ff00ffu, o = (g[hw] >> 8) & 0x00ff00ffu;
+                        if (l > 0) d[hw] = pk_sub_sat_u16(e, prev_e[ii][jr][hw]) | (pk_sub_sat_u16(o, prev_o[ii][jr][hw]) << 8);
+                        prev_e[ii][jr][hw] = e;
+                        prev_o[ii][jr][hw] = o;
+                    }
+                    if (y < rows) {
+                        const size_t off = (size_t)y * cols + x;
+                        *reinterpret_cast<uint2*>(out + (size_t)l * P + off) = make_uint2(g[0], g[1]);
+                        if (l > 0) *reinterpret_cast<uint2*>(out + (size_t)(VSLAM_NUM_LEVELS + l - 1) * P + off) = make_uint2(d[0], d[1]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// Host side: build the tables for one octave.
+static bool strip_pack_taps(const uint16_t* const t[6], const int n[6], StripTaps& out) {
+    memset(&out, 0, sizeof(out));
+    for (int l = 0; l < VSLAM_NUM_LEVELS; ++l) {
+        if (n[l] > 245 || (n[l] & 1) == 0) return false;
+        out.n[l] = n[l];
+        for (int k = 0; k < n[l]; ++k)
+            if (t[l][k] > 255) return false;
+        for (int m = 0; m < STRIP_MAXM; ++m)
+            for (int j = 0; j < 4; ++j) {
+                uint32_t w = 0;
+                for (int b = 0; b < 4; ++b) {
+                    const int k = 4 * m + b - j;
+                    if (k >= 0 && k < n[l]) w |= (uint32_t)t[l][k] << (8 * b);
+                }
+                out.v4[l][m][j] = w;
+            }
+        for (int e = 0; e <= n[l]; ++e) {
+            const uint32_t lo = e >= 1 ? t[l][e - 1] : 0, hi = e < n[l] ? t[l][e] : 0;
+            out.hp[l][8 + e] = lo | (hi << 16);
+        }
+    }
+    return true;
+}
+
+}  // namespace vslam

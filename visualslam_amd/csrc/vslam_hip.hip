@@ -13,6 +13,8 @@
 #include "../../include/vslam.h"
 #include "kernels_generic.hip.h"
 #include "kernels_harris.hip.h"
+#include "kernels_pyramid.hip.h"
+#include "kernels_strip.hip.h"
 #include "vslam_internal.h"
 
 using namespace vslam;
@@ -28,6 +30,7 @@ struct vslam_ctx {
     char* ws = nullptr;
     size_t ws_cap = 0, ws_off = 0;
     std::map<std::pair<int, uint64_t>, uint16_t*> taps;  // device copies of quantised taps
+    std::map<std::pair<uint64_t, int>, StripTaps*> strip_taps;  // (sigma0 bits, octave) -> device tables
     // bench timing hook
     std::string timing_name;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timing_ev;
@@ -57,9 +60,18 @@ static int fail(vslam_ctx* c, int code, const std::string& msg) {
                         std::string(#expr) + ": " + hipGetErrorString(e_));                     \
     } while (0)
 
+#define ARGCHK(ctx, cond, msg) \
+    if (!(cond)) return fail(ctx, VSLAM_ERR_INVALID, msg)
+#define TRY(expr)              \
+    do {                       \
+        int rc_ = (expr);      \
+        if (rc_) return rc_;   \
+    } while (0)
+
 static const char* const kKernelNames =
     "k_harris_fused\nk_harris_post\nk_compact_harris\nk_resize_linear2x\nk_blur_h_generic\nk_blur_v_generic\n"
-    "k_dog5\nk_resize_nearest_half\nk_extrema\nk_compact_dog";
+    "k_dog5\nk_resize_nearest_half\nk_extrema\nk_compact_dog\nk_pyr_octave\n"
+    "k_gauss_v_strip\nk_gauss_h_strip";
 
 // Launch on the context stream; bracket with events when the bench hook names this kernel.
 #define LAUNCH(ctx, name, kern, grid, block, ...)                                                \
@@ -130,6 +142,127 @@ static inline dim3 grid_rows(int cols, int rows, int frames = 1) { return dim3((
 
 // ---------------------------------------------------------------- enqueue helpers (device)
 
+// ---- octave path selection -----------------------------------------------------------------
+enum class OctPath { Tile0, Tile1, Strip, Generic };
+
+struct OctPlan {
+    OctPath path = OctPath::Generic;
+    int ks[6] = {};
+    double sg[6] = {};
+    int sh = 0;  // rows per horizontal strip workgroup
+};
+
+static bool taps_fit_u8(const int ks[6], const double sg[6]) {
+    for (int l = 0; l < 6; ++l) {
+        std::vector<uint16_t> t((size_t)ks[l]);
+        if (!gauss_taps_q8(ks[l], sg[l], t.data())) return false;
+        for (uint16_t v : t)
+            if (v > 255) return false;
+    }
+    return true;
+}
+
+template <class CFG>
+static bool matches_cfg(const int ks[6]) {
+    for (int l = 0; l < 6; ++l)
+        if (ks[l] != CFG::n(l)) return false;
+    return true;
+}
+
+static OctPlan plan_octave(double sigma0, int o, int rows, int cols) {
+    OctPlan pl;
+    int nmax = 0;
+    for (int l = 0; l < 6; ++l) {
+        pl.sg[l] = sigma_at(sigma0, o, l);
+        pl.ks[l] = gauss_ksize_u8(pl.sg[l]);
+        nmax = std::max(nmax, pl.ks[l]);
+    }
+    if (cols % 8 != 0 || !taps_fit_u8(pl.ks, pl.sg)) return pl;
+    if (matches_cfg<PyrCfgOct0>(pl.ks)) {
+        pl.path = OctPath::Tile0;
+    } else if (matches_cfg<PyrCfgOct1>(pl.ks)) {
+        pl.path = OctPath::Tile1;
+    } else if (nmax <= 245) {
+        const int RM = (nmax / 2 + 3) & ~3;
+        const size_t v_lds = (size_t)((((rows + 3) & ~3) + 2 * RM + 16) / 4) * STRIP_W * 4;
+        pl.sh = cols <= 1024 ? 16 : cols <= 2048 ? 8 : cols <= 4096 ? 4 : 0;
+        const size_t pw = (size_t)((cols / 2 + nmax / 2 + 8 + 3) & ~3);
+        if (pl.sh && v_lds <= 150 * 1024 && pl.sh * pw * 4 <= 150 * 1024) pl.path = OctPath::Strip;
+    }
+    return pl;
+}
+
+static int get_strip_taps(vslam_ctx* c, double sigma0, int o, const OctPlan& pl, const StripTaps** out) {
+    uint64_t sb;
+    std::memcpy(&sb, &sigma0, 8);
+    auto key = std::make_pair(sb, o);
+    auto it = c->strip_taps.find(key);
+    if (it == c->strip_taps.end()) {
+        std::vector<uint16_t> host[6];
+        const uint16_t* tp[6];
+        for (int l = 0; l < 6; ++l) {
+            host[l].resize((size_t)pl.ks[l]);
+            gauss_taps_q8(pl.ks[l], pl.sg[l], host[l].data());
+            tp[l] = host[l].data();
+        }
+        std::vector<StripTaps> st(1);
+        if (!strip_pack_taps(tp, pl.ks, st[0])) return fail(c, VSLAM_ERR_UNSUPPORTED, "strip kernels: taps out of range");
+        StripTaps* d = nullptr;
+        HIPCHK(c, hipMalloc((void**)&d, sizeof(StripTaps)));
+        HIPCHK(c, hipMemcpy(d, st.data(), sizeof(StripTaps), hipMemcpyHostToDevice));
+        it = c->strip_taps.emplace(key, d).first;
+    }
+    *out = it->second;
+    return VSLAM_OK;
+}
+
+template <int SH>
+static int launch_h_strip(vslam_ctx* c, const uint16_t* h, size_t hframe, uint8_t* oct, size_t pframe, int rows, int cols,
+                          int pw, int nf, const StripTaps* taps) {
+    const size_t lds = (size_t)SH * pw * 4;
+    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gauss_h_strip<SH>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const bool timed = c->timing_name == "k_gauss_h_strip";
+    std::pair<hipEvent_t, hipEvent_t>* ev = timed ? timing_slot(c) : nullptr;
+    if (ev) (void)hipEventRecord(ev->first, c->stream);
+    hipLaunchKernelGGL(k_gauss_h_strip<SH>, dim3(1, (rows + SH - 1) / SH, nf), dim3(256), lds, c->stream, h, hframe, oct,
+                       pframe, rows, cols, pw, taps);
+    if (ev) (void)hipEventRecord(ev->second, c->stream);
+    HIPCHK(c, hipGetLastError());
+    return VSLAM_OK;
+}
+
+// Coarse octave: vertical strips (dot4) into the u16 scratch, then horizontal strips (dot2).
+static int enqueue_strip_octave(vslam_ctx* c, double sigma0, int o, const OctPlan& pl, const uint8_t* base, size_t bframe,
+                                uint8_t* oct, size_t pframe, uint16_t* h, int rows, int cols, int nf) {
+    const StripTaps* taps;
+    TRY(get_strip_taps(c, sigma0, o, pl, &taps));
+    int nmax = 0;
+    for (int l = 0; l < 6; ++l) nmax = std::max(nmax, pl.ks[l]);
+    const int RM = (nmax / 2 + 3) & ~3;
+    const int rhq = (((rows + 3) & ~3) + 2 * RM + 16) / 4;
+    const size_t v_lds = (size_t)rhq * STRIP_W * 4;
+    const size_t P = (size_t)rows * cols;
+    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gauss_v_strip),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)v_lds));
+    {
+        const bool timed = c->timing_name == "k_gauss_v_strip";
+        std::pair<hipEvent_t, hipEvent_t>* ev = timed ? timing_slot(c) : nullptr;
+        if (ev) (void)hipEventRecord(ev->first, c->stream);
+        hipLaunchKernelGGL(k_gauss_v_strip, dim3((cols + STRIP_W - 1) / STRIP_W, 1, nf), dim3(256), v_lds, c->stream, base,
+                           bframe, h, 6 * P, rows, cols, RM, rhq, taps);
+        if (ev) (void)hipEventRecord(ev->second, c->stream);
+        HIPCHK(c, hipGetLastError());
+    }
+    const int pw = (cols / 2 + nmax / 2 + 8 + 3) & ~3;
+    switch (pl.sh) {
+        case 16: return launch_h_strip<16>(c, h, 6 * P, oct, pframe, rows, cols, pw, nf, taps);
+        case 8: return launch_h_strip<8>(c, h, 6 * P, oct, pframe, rows, cols, pw, nf, taps);
+        default: return launch_h_strip<4>(c, h, 6 * P, oct, pframe, rows, cols, pw, nf, taps);
+    }
+}
+
+
 // GaussianBlur CV_8U on nf dense images; h = u16 scratch of nf*rows*cols elements.
 static int enqueue_blur(vslam_ctx* c, const uint8_t* src, size_t sstep, size_t sframe, uint8_t* dst, size_t dstep,
                         size_t dframe, uint16_t* h, int rows, int cols, int nf, int n, double sigma) {
@@ -169,14 +302,27 @@ struct DogScratch {
     unsigned long long* lflags = nullptr;
 };
 
-static size_t dog_scratch_bytes(const vslam_batch_layout& L, int nf) {
-    size_t sum_p = 0;
-    for (int o = 0; o < L.n_octaves; ++o) sum_p += (size_t)L.rows[o] * L.cols[o];
-    const size_t P0 = L.n_octaves ? (size_t)L.rows[0] * L.cols[0] : 0;
-    return ws_need((size_t)nf * sum_p) + ws_need((size_t)nf * P0 * 2) + ws_need((size_t)nf * L.bits_frame_words * 8);
+// u16 scratch elements per frame: 6 row-sum images for a strip octave, 1 for a generic octave,
+// none for the LDS-tiled octaves.
+static size_t dog_h_elems(const vslam_batch_layout& L, double sigma0) {
+    size_t m = 0;
+    for (int o = 0; o < L.n_octaves; ++o) {
+        const size_t P = (size_t)L.rows[o] * L.cols[o];
+        const OctPath path = plan_octave(sigma0, o, L.rows[o], L.cols[o]).path;
+        if (path == OctPath::Strip) m = std::max(m, 6 * P);
+        if (path == OctPath::Generic) m = std::max(m, P);
+    }
+    return m;
 }
 
-static int dog_scratch_take(vslam_ctx* c, const vslam_batch_layout& L, int nf, DogScratch& s) {
+static size_t dog_scratch_bytes(const vslam_batch_layout& L, double sigma0, int nf) {
+    size_t sum_p = 0;
+    for (int o = 0; o < L.n_octaves; ++o) sum_p += (size_t)L.rows[o] * L.cols[o];
+    return ws_need((size_t)nf * sum_p) + ws_need((size_t)nf * dog_h_elems(L, sigma0) * 2 + 256) +
+           ws_need((size_t)nf * L.bits_frame_words * 8);
+}
+
+static int dog_scratch_take(vslam_ctx* c, const vslam_batch_layout& L, double sigma0, int nf, DogScratch& s) {
     size_t sum_p = 0;
     for (int o = 0; o < L.n_octaves; ++o) {
         s.base_off[o] = sum_p;
@@ -184,11 +330,51 @@ static int dog_scratch_take(vslam_ctx* c, const vslam_batch_layout& L, int nf, D
     }
     s.bases_frame = sum_p;
     s.bases = ws_take<uint8_t>(c, (size_t)nf * sum_p);
-    s.h = ws_take<uint16_t>(c, (size_t)nf * L.rows[0] * L.cols[0]);
+    s.h = ws_take<uint16_t>(c, (size_t)nf * dog_h_elems(L, sigma0) + 128);
     s.lflags = ws_take<unsigned long long>(c, (size_t)nf * L.bits_frame_words);
     if (!s.bases || !s.h || !s.lflags) return fail(c, VSLAM_ERR_NOMEM, "workspace sizing error (dog)");
     return VSLAM_OK;
 }
+
+
+// Fused LDS-tiled octave (kernels_pyramid.hip.h) when the six kernel widths match a compiled
+// configuration; returns false (nothing enqueued) otherwise so the caller takes the generic path.
+template <class CFG>
+static int try_enqueue_pyr_octave(vslam_ctx* c, const int ks[6], const double sg[6], const uint8_t* base, size_t bframe,
+                                  uint8_t* oct_out, size_t pframe, int rows, int cols, int nf, bool* done) {
+    *done = false;
+    if (cols % 8 != 0) return VSLAM_OK;
+    for (int l = 0; l < 6; ++l)
+        if (ks[l] != CFG::n(l)) return VSLAM_OK;
+    std::vector<uint16_t> host[6];
+    const uint16_t* tp[6];
+    for (int l = 0; l < 6; ++l) {
+        host[l].resize((size_t)ks[l]);
+        if (!gauss_taps_q8(ks[l], sg[l], host[l].data())) return fail(c, VSLAM_ERR_INVALID, "invalid Gaussian kernel size");
+        for (int k = 0; k < ks[l]; ++k)
+            if (host[l][k] > 255) return VSLAM_OK;  // u8 operand of the vertical dot4
+        tp[l] = host[l].data();
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pyr_octave<CFG>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES));
+        attr_set = true;
+    }
+    PyrTaps<CFG> taps;
+    pyr_pack_taps<CFG>(tp, taps);
+    const dim3 grid((cols + CFG::TW - 1) / CFG::TW, (rows + CFG::TH - 1) / CFG::TH, nf);
+    const bool timed = c->timing_name == "k_pyr_octave";
+    std::pair<hipEvent_t, hipEvent_t>* ev = timed ? timing_slot(c) : nullptr;
+    if (ev) (void)hipEventRecord(ev->first, c->stream);
+    hipLaunchKernelGGL(k_pyr_octave<CFG>, grid, dim3(256), CFG::LDS_BYTES, c->stream, base, bframe, oct_out, pframe, rows,
+                       cols, taps);
+    if (ev) (void)hipEventRecord(ev->second, c->stream);
+    HIPCHK(c, hipGetLastError());
+    *done = true;
+    return VSLAM_OK;
+}
+
 
 // createPyramid (GaussPyramid.cpp:106-131) + initialKeypointDetection (Diff_of_Gauss.cpp:254)
 // for nf frames; pyr/bits/points are per-frame blocks with the given strides.
@@ -204,14 +390,23 @@ static int enqueue_dog(vslam_ctx* c, const vslam_params& p, const vslam_batch_la
         const size_t P = (size_t)rows * cols;
         const uint8_t* base = s.bases + s.base_off[o];
         uint8_t* oct = pyr + L.octave_offset[o];
-        for (int l = 0; l < VSLAM_NUM_LEVELS; ++l) {
-            const double sg = sigma_at(p.sigma0, o, l);
-            int rc = enqueue_blur(c, base, (size_t)cols, s.bases_frame, oct + (size_t)l * P, (size_t)cols, pframe, s.h,
-                                  rows, cols, nf, gauss_ksize_u8(sg), sg);
-            if (rc) return rc;
+        const OctPlan pl = plan_octave(p.sigma0, o, rows, cols);
+        bool fused = false;
+        if (pl.path == OctPath::Tile0)
+            TRY(try_enqueue_pyr_octave<PyrCfgOct0>(c, pl.ks, pl.sg, base, s.bases_frame, oct, pframe, rows, cols, nf, &fused));
+        else if (pl.path == OctPath::Tile1)
+            TRY(try_enqueue_pyr_octave<PyrCfgOct1>(c, pl.ks, pl.sg, base, s.bases_frame, oct, pframe, rows, cols, nf, &fused));
+        else if (pl.path == OctPath::Strip) {
+            TRY(enqueue_strip_octave(c, p.sigma0, o, pl, base, s.bases_frame, oct, pframe, s.h, rows, cols, nf));
+            fused = true;
         }
-        LAUNCH(c, "k_dog5", k_dog5, dim3((unsigned)((P + 255) / 256), 1, nf), dim3(256), oct,
-               oct + (size_t)VSLAM_NUM_LEVELS * P, P, pframe);
+        if (!fused) {
+            for (int l = 0; l < VSLAM_NUM_LEVELS; ++l)
+                TRY(enqueue_blur(c, base, (size_t)cols, s.bases_frame, oct + (size_t)l * P, (size_t)cols, pframe, s.h, rows,
+                                 cols, nf, pl.ks[l], pl.sg[l]));
+            LAUNCH(c, "k_dog5", k_dog5, dim3((unsigned)((P + 255) / 256), 1, nf), dim3(256), oct,
+                   oct + (size_t)VSLAM_NUM_LEVELS * P, P, pframe);
+        }
         if (o + 1 < L.n_octaves)
             LAUNCH(c, "k_resize_nearest_half", k_resize_nearest_half, grid_rows(L.cols[o + 1], L.rows[o + 1], nf),
                    dim3(256), oct + (size_t)3 * P, (size_t)cols, pframe, s.bases + s.base_off[o + 1],
@@ -258,13 +453,6 @@ static int d2h(vslam_ctx* c, void* dst, size_t dpitch, const void* src, size_t s
     return VSLAM_OK;
 }
 
-#define ARGCHK(ctx, cond, msg) \
-    if (!(cond)) return fail(ctx, VSLAM_ERR_INVALID, msg)
-#define TRY(expr)              \
-    do {                       \
-        int rc_ = (expr);      \
-        if (rc_) return rc_;   \
-    } while (0)
 
 static int bind_device(vslam_ctx* c) {
     if (!c) return VSLAM_ERR_INVALID;
@@ -303,6 +491,7 @@ int vslam_ctx_destroy(vslam_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (auto& kv : c->taps) (void)hipFree(kv.second);
+    for (auto& kv : c->strip_taps) (void)hipFree(kv.second);
     for (auto& ev : c->timing_ev) {
         (void)hipEventDestroy(ev.first);
         (void)hipEventDestroy(ev.second);
@@ -583,11 +772,11 @@ int vslam_pyramid_build_u8(vslam_ctx* c, const uint8_t* img, int rows, int cols,
         hipMalloc((void**)&py->d_bases, sum_p) != hipSuccess)
         return cleanup(fail(c, VSLAM_ERR_NOMEM, "device allocation failed (pyramid)"));
     const size_t N = (size_t)rows * cols;
-    int rc = ws_reserve(c, ws_need(N) + dog_scratch_bytes(L, 1));
+    int rc = ws_reserve(c, ws_need(N) + dog_scratch_bytes(L, sigma0, 1));
     if (rc) return cleanup(rc);
     uint8_t* d_img = ws_take<uint8_t>(c, N);
     DogScratch s;
-    if ((rc = dog_scratch_take(c, L, 1, s))) return cleanup(rc);
+    if ((rc = dog_scratch_take(c, L, sigma0, 1, s))) return cleanup(rc);
     if ((rc = h2d(c, d_img, cols, img, step, cols, rows))) return cleanup(rc);
     if ((rc = enqueue_dog(c, p, L, d_img, cols, N, 1, py->d_block, L.pyramid_frame_bytes, s, nullptr, false, nullptr,
                           nullptr)))
@@ -702,13 +891,15 @@ int vslam_detect_batch_dev(vslam_ctx* c, const vslam_params* pp, const uint8_t* 
     ARGCHK(c, !dog || out->pyramid, "detect_batch: the DoG path needs out->pyramid");
     const size_t N = (size_t)p.rows * p.cols;
     const int wpr = (p.cols + 63) / 64;
-    const int chunk = std::min(n_frames, 8);  // bounds the scratch (octave bases + u16 row pass)
+    // Whole-batch launches: every kernel sees all frames (grid.z = frames), so even the coarse
+    // octaves fill the chip.  Scratch: octave bases (+ u16 row sums of the non-tiled octaves).
+    const int chunk = std::min(n_frames, 256);
     size_t need = 0;
-    if (dog) need += dog_scratch_bytes(L, chunk);
+    if (dog) need += dog_scratch_bytes(L, p.sigma0, chunk);
     if (harris) need += (out->response ? 0 : ws_need((size_t)chunk * N * 4)) + ws_need((size_t)chunk * p.rows * wpr * 8);
     TRY(ws_reserve(c, need));
     DogScratch s;
-    if (dog) TRY(dog_scratch_take(c, L, chunk, s));
+    if (dog) TRY(dog_scratch_take(c, L, p.sigma0, chunk, s));
     float* resp_ws = (harris && !out->response) ? ws_take<float>(c, (size_t)chunk * N) : nullptr;
     unsigned long long* hflags = harris ? ws_take<unsigned long long>(c, (size_t)chunk * p.rows * wpr) : nullptr;
     for (int f0 = 0; f0 < n_frames; f0 += chunk) {
