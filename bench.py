@@ -29,11 +29,11 @@ def kernel_algorithmic_bytes(L, rows, cols):
     N = rows * cols
     P = [L.rows[o] * L.cols[o] for o in range(L.n_octaves)]
     return {
-        "k_harris_fused": 5 * N,          # u8 frame in, f32 response out
-        "k_harris_post": N,               # u8 NMS mask out
-        "k_resize_linear2x": N,           # DoG path's read of the frame
-        "k_blur_v_generic": 6 * sum(P),   # the six Gaussian images of every octave
-        "k_dog5": 5 * sum(P),             # the five DoG images of every octave
+        "k_harris_fused": 5 * N,                 # u8 frame in, f32 response out
+        "k_harris_post": N,                      # u8 NMS mask out
+        "k_resize_linear2x_v8": N,               # DoG path's read of the frame
+        "k_pyr_octave": 11 * sum(P[:2]),         # 6 Gaussian + 5 DoG images of octaves 0-1 (LDS-tiled)
+        "k_gauss_h_strip": 11 * sum(P[2:]),      # the same for the coarse octaves (strip kernels)
     }
 
 
@@ -140,7 +140,7 @@ def main():
     for _ in range(args.warmup):
         step()
     algo = kernel_algorithmic_bytes(L, rows, cols)
-    kname = args.kernel or "k_blur_v_generic"
+    kname = args.kernel or "k_pyr_octave"
     fence()
     ctx.kernel_timing_enable(kname)
     t0 = time.perf_counter()

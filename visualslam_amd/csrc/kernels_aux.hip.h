@@ -1,0 +1,122 @@
+// Vectorised memory-side kernels of the DoG path for gfx950: 2x bilinear upsample (K-D0),
+// 2:1 nearest decimation (K-D4) and the scale-space extrema scan for windowSize 3 (K-D3).
+// All are HBM/L2-bound byte movers: coalesced 4/8/16-byte accesses, LDS row staging where a
+// row is shared, one ballot word per 64 lattice sites.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "kernels_generic.hip.h"
+
+namespace vslam {
+
+// ---- K-D0: cv::resize(img, Size(), 2, 2, INTER_LINEAR) on CV_8U (GaussPyramid.cpp:110) ----
+// One thread = 8 consecutive destination pixels of one row.  Clamped source reads reproduce
+// OpenCV's border rule exactly because the two 11-bit weights always sum to 2048.
+// Requires cols % 4 == 0 (dst row pitch 2*cols is then a multiple of 8).
+__global__ __launch_bounds__(256) void k_resize_linear2x_v8(const uint8_t* __restrict__ src, size_t sframe,
+                                                             uint8_t* __restrict__ dst, size_t dframe, int rows,
+                                                             int cols) {
+    const int k = blockIdx.x * 256 + threadIdx.x;  // group of 8 dst px = 4 src px
+    const int dy = blockIdx.y;
+    if (4 * k >= cols) return;
+    const int sy = (dy >> 1) - 1 + (dy & 1);
+    const int b1 = (dy & 1) ? 512 : 1536, b0 = 2048 - b1;
+    const uint8_t* r0 = src + blockIdx.z * sframe + (size_t)clampi(sy, 0, rows - 1) * cols;
+    const uint8_t* r1 = src + blockIdx.z * sframe + (size_t)clampi(sy + 1, 0, rows - 1) * cols;
+    // source pixels 4k-1 .. 4k+4 of both rows
+    int s0[6], s1[6];
+    const uint32_t w0 = *reinterpret_cast<const uint32_t*>(r0 + 4 * k), w1 = *reinterpret_cast<const uint32_t*>(r1 + 4 * k);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        s0[i + 1] = (w0 >> (8 * i)) & 255;
+        s1[i + 1] = (w1 >> (8 * i)) & 255;
+    }
+    const int xl = max(4 * k - 1, 0), xr = min(4 * k + 4, cols - 1);
+    s0[0] = r0[xl], s0[5] = r0[xr], s1[0] = r1[xl], s1[5] = r1[xr];
+    uint32_t o[2] = {0, 0};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        // dx = 8k + j: source pair (i, i+1) with i = (j>>1) - 1 + (j&1) relative to 4k, i.e. s[i+1], s[i+2]
+        const int i = (j >> 1) + (j & 1);  // index into s[] of the first sample
+        const int a1 = (j & 1) ? 512 : 1536, a0 = 2048 - a1;
+        const int h0 = s0[i] * a0 + s0[i + 1] * a1;
+        const int h1 = s1[i] * a0 + s1[i + 1] * a1;
+        const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+        o[j >> 2] |= (uint32_t)min(v, 255) << (8 * (j & 3));
+    }
+    *reinterpret_cast<uint2*>(dst + blockIdx.z * dframe + (size_t)dy * (2 * cols) + 8 * k) = make_uint2(o[0], o[1]);
+}
+
+// ---- K-D4: cv::resize(src, Size(), 0.5, 0.5, INTER_NEAREST) (GaussPyramid.cpp:126) ----------
+// One thread = 4 destination pixels.  Requires cols % 8 == 0 (then dcols = cols/2, % 4 == 0).
+__global__ __launch_bounds__(256) void k_resize_nearest_half_v4(const uint8_t* __restrict__ src, size_t sframe,
+                                                                 uint8_t* __restrict__ dst, size_t dframe, int rows,
+                                                                 int cols, int drows, int dcols) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    const int y = blockIdx.y;
+    if (4 * k >= dcols) return;
+    const int sy = min(2 * y, rows - 1);
+    const uint2 w = *reinterpret_cast<const uint2*>(src + blockIdx.z * sframe + (size_t)sy * cols + 8 * k);
+    *reinterpret_cast<uint32_t*>(dst + blockIdx.z * dframe + (size_t)y * dcols + 4 * k) =
+        __builtin_amdgcn_perm(w.y, w.x, 0x06040200);
+}
+
+// ---- K-D3: initialKeypointDetection for windowSize 3 (Diff_of_Gauss.cpp:254-297) -----------
+// One workgroup = one lattice row of one frame, all three levels.  The two image rows the
+// row's 2x2x3 windows touch (unpadded rows 3li-1 and 3li, clamped) are staged once for all five
+// DoG levels with 16-byte loads; each thread then serves lattice sites lj = lane-consecutive, so
+// a wave's 64 candidate flags are one ballot word = the bitmask layout of include/vslam.h.
+// Requires cols % 16 == 0.  Dynamic LDS = 10 * cols bytes.
+__global__ __launch_bounds__(256) void k_extrema_w3(const uint8_t* __restrict__ pyr, size_t pframe, ExtGeom g, int o,
+                                                     unsigned long long* __restrict__ bits,
+                                                     unsigned long long* __restrict__ lflags, size_t bframe) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t srow[];  // [level 0..4][row 0..1][cols]
+    const int li = blockIdx.y, f = blockIdx.z;
+    const int rows = g.rows[o], cols = g.cols[o];
+    const size_t P = (size_t)rows * cols;
+    const uint8_t* dog = pyr + f * pframe + g.oct_off[o] + (size_t)VSLAM_NUM_LEVELS * P;
+    const int ya = max(3 * li - 1, 0), yb = 3 * li;  // padded rows i-1, i with i = 1 + 3li -> unpadded 3li-1, 3li
+    const int c16 = cols >> 4;
+    for (int it = threadIdx.x; it < 10 * c16; it += 256) {
+        const int rl = it / c16, x16 = it - rl * c16;  // rl = level*2 + row
+        const int y = (rl & 1) ? yb : ya;
+        const uint4 v = *reinterpret_cast<const uint4*>(dog + (size_t)(rl >> 1) * P + (size_t)y * cols + 16 * x16);
+        *reinterpret_cast<uint4*>(srow + rl * cols + 16 * x16) = v;
+    }
+    __syncthreads();
+    const int lc = g.lat_cols[o], wpr = g.wpr[o], lr = g.lat_rows[o];
+    for (int lj0 = 0; lj0 < wpr * 64; lj0 += 256) {
+        const int lj = lj0 + threadIdx.x;
+        bool cand[3] = {false, false, false}, listed[3] = {false, false, false};
+        if (lj < lc) {
+            const int xa = max(3 * lj - 1, 0), xb = 3 * lj;
+            int mn[5], mx[5], self[5];
+#pragma unroll
+            for (int l = 0; l < 5; ++l) {
+                const uint8_t* r0 = srow + (2 * l) * cols;
+                const uint8_t* r1 = r0 + cols;
+                const int a = r0[xa], b = r0[xb], c = r1[xa], d = r1[xb];
+                mn[l] = min(min(a, b), min(c, d));
+                mx[l] = max(max(a, b), max(c, d));
+                self[l] = d;  // (i, j) itself
+            }
+#pragma unroll
+            for (int L = 1; L <= 3; ++L) {
+                const int lo = min(mn[L - 1], min(mn[L], mn[L + 1])), hi = max(mx[L - 1], max(mx[L], mx[L + 1]));
+                cand[L - 1] = self[L] == lo || self[L] == hi;
+                listed[L - 1] = cand[L - 1] && self[L] >= g.min_contrast;
+            }
+        }
+#pragma unroll
+        for (int L = 0; L < 3; ++L) {
+            const unsigned long long wc = __ballot(cand[L]), wl = __ballot(listed[L]);
+            if ((threadIdx.x & 63) == 0 && (lj >> 6) < wpr) {
+                const size_t w = f * bframe + g.bits_off[o] + ((size_t)L * lr + li) * wpr + (lj >> 6);
+                if (bits) bits[w] = wc;
+                lflags[w] = wl;
+            }
+        }
+    }
+}
+
+}  // namespace vslam

@@ -159,17 +159,17 @@ __global__ __launch_bounds__(256) void k_gauss_h_strip(const uint16_t* __restric
         // ---- stage SH rows, reflect-101 extended, as u16 pairs -------------------------------
         const int npairs = (cols + 2 * PL + 2) >> 1;  // covers cx in [0, cols + 2PL + 2)
         __syncthreads();  // previous level's reads are done
-        for (int it = tid; it < SH * npairs; it += 256) {
-            const int jr = it / npairs, pi = it - jr * npairs;
-            const int y = min(y0 + jr, rows - 1);
-            const int x = 2 * pi - PL;
-            const uint16_t* row = hl + (size_t)y * cols;
-            uint32_t w;
-            if (x >= 0 && x + 1 < cols)
-                w = *reinterpret_cast<const uint32_t*>(row + x);
-            else
-                w = (uint32_t)row[reflect101(x, cols)] | ((uint32_t)row[reflect101(x + 1, cols)] << 16);
-            hp[jr * pw + pi] = w;
+        for (int jr = tid >> 6; jr < SH; jr += 4) {  // one wave per row: coalesced dword loads
+            const uint16_t* row = hl + (size_t)min(y0 + jr, rows - 1) * cols;
+            for (int pi = tid & 63; pi < npairs; pi += 64) {
+                const int x = 2 * pi - PL;
+                uint32_t w;
+                if (x >= 0 && x + 1 < cols)
+                    w = *reinterpret_cast<const uint32_t*>(row + x);
+                else
+                    w = (uint32_t)row[reflect101(x, cols)] | ((uint32_t)row[reflect101(x + 1, cols)] << 16);
+                hp[jr * pw + pi] = w;
+            }
         }
         __syncthreads();
         const int nb = (((7 + dl + 2 * r) >> 1) >> 2) + 1;

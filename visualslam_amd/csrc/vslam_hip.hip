@@ -15,6 +15,7 @@
 #include "kernels_harris.hip.h"
 #include "kernels_pyramid.hip.h"
 #include "kernels_strip.hip.h"
+#include "kernels_aux.hip.h"
 #include "vslam_internal.h"
 
 using namespace vslam;
@@ -71,7 +72,7 @@ static int fail(vslam_ctx* c, int code, const std::string& msg) {
 static const char* const kKernelNames =
     "k_harris_fused\nk_harris_post\nk_compact_harris\nk_resize_linear2x\nk_blur_h_generic\nk_blur_v_generic\n"
     "k_dog5\nk_resize_nearest_half\nk_extrema\nk_compact_dog\nk_pyr_octave\n"
-    "k_gauss_v_strip\nk_gauss_h_strip";
+    "k_gauss_v_strip\nk_gauss_h_strip\nk_resize_linear2x_v8\nk_resize_nearest_half_v4\nk_extrema_w3";
 
 // Launch on the context stream; bracket with events when the bench hook names this kernel.
 #define LAUNCH(ctx, name, kern, grid, block, ...)                                                \
@@ -383,8 +384,12 @@ static int enqueue_dog(vslam_ctx* c, const vslam_params& p, const vslam_batch_la
                        unsigned long long* bits, bool do_extrema, vslam_point* points, unsigned int* counts) {
     ExtGeom g;
     fill_geom(p, L, g);
-    LAUNCH(c, "k_resize_linear2x", k_resize_linear2x, grid_rows(2 * p.cols, 2 * p.rows, nf), dim3(256), frames, fstep,
-           fframe, s.bases + s.base_off[0], (size_t)L.cols[0], s.bases_frame, p.rows, p.cols);
+    if (p.cols % 4 == 0 && fstep == (size_t)p.cols && fframe % 4 == 0)
+        LAUNCH(c, "k_resize_linear2x_v8", k_resize_linear2x_v8, dim3((p.cols / 4 + 255) / 256, 2 * p.rows, nf), dim3(256),
+               frames, fframe, s.bases + s.base_off[0], s.bases_frame, p.rows, p.cols);
+    else
+        LAUNCH(c, "k_resize_linear2x", k_resize_linear2x, grid_rows(2 * p.cols, 2 * p.rows, nf), dim3(256), frames, fstep,
+               fframe, s.bases + s.base_off[0], (size_t)L.cols[0], s.bases_frame, p.rows, p.cols);
     for (int o = 0; o < L.n_octaves; ++o) {
         const int rows = L.rows[o], cols = L.cols[o];
         const size_t P = (size_t)rows * cols;
@@ -407,13 +412,25 @@ static int enqueue_dog(vslam_ctx* c, const vslam_params& p, const vslam_batch_la
             LAUNCH(c, "k_dog5", k_dog5, dim3((unsigned)((P + 255) / 256), 1, nf), dim3(256), oct,
                    oct + (size_t)VSLAM_NUM_LEVELS * P, P, pframe);
         }
-        if (o + 1 < L.n_octaves)
-            LAUNCH(c, "k_resize_nearest_half", k_resize_nearest_half, grid_rows(L.cols[o + 1], L.rows[o + 1], nf),
-                   dim3(256), oct + (size_t)3 * P, (size_t)cols, pframe, s.bases + s.base_off[o + 1],
-                   (size_t)L.cols[o + 1], s.bases_frame, rows, cols, L.rows[o + 1], L.cols[o + 1]);
-        if (do_extrema && L.lat_rows[o] > 0 && L.lat_cols[o] > 0)
-            LAUNCH(c, "k_extrema", k_extrema, dim3((L.lat_cols[o] + 255) / 256, L.lat_rows[o], nf * 3), dim3(256), pyr,
-                   pframe, g, o, bits, s.lflags, L.bits_frame_words);
+        if (o + 1 < L.n_octaves) {
+            if (cols % 8 == 0 && (L.octave_offset[o] + 3 * P) % 8 == 0 && s.base_off[o + 1] % 4 == 0 && s.bases_frame % 4 == 0)
+                LAUNCH(c, "k_resize_nearest_half_v4", k_resize_nearest_half_v4,
+                       dim3((L.cols[o + 1] / 4 + 255) / 256, L.rows[o + 1], nf), dim3(256), oct + (size_t)3 * P, pframe,
+                       s.bases + s.base_off[o + 1], s.bases_frame, rows, cols, L.rows[o + 1], L.cols[o + 1]);
+            else
+                LAUNCH(c, "k_resize_nearest_half", k_resize_nearest_half, grid_rows(L.cols[o + 1], L.rows[o + 1], nf),
+                       dim3(256), oct + (size_t)3 * P, (size_t)cols, pframe, s.bases + s.base_off[o + 1],
+                       (size_t)L.cols[o + 1], s.bases_frame, rows, cols, L.rows[o + 1], L.cols[o + 1]);
+        }
+        if (do_extrema && L.lat_rows[o] > 0 && L.lat_cols[o] > 0) {
+            if (p.extrema_window == 3 && cols % 16 == 0 && (size_t)10 * cols <= 64 * 1024)
+                hipLaunchKernelGGL(k_extrema_w3, dim3(1, L.lat_rows[o], nf), dim3(256), (size_t)10 * cols, c->stream, pyr, pframe,
+                                   g, o, bits, s.lflags, L.bits_frame_words);
+            else
+                hipLaunchKernelGGL(k_extrema, dim3((L.lat_cols[o] + 255) / 256, L.lat_rows[o], nf * 3), dim3(256), 0, c->stream,
+                                   pyr, pframe, g, o, bits, s.lflags, L.bits_frame_words);
+            HIPCHK(c, hipGetLastError());
+        }
     }
     if (do_extrema && points && counts)
         LAUNCH(c, "k_compact_dog", k_compact_dog, dim3(nf), dim3(1024), s.lflags, L.bits_frame_words, pyr, pframe, g, 0,
