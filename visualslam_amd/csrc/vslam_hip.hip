@@ -16,6 +16,7 @@
 #include "kernels_pyramid.hip.h"
 #include "kernels_strip.hip.h"
 #include "kernels_aux.hip.h"
+#include "kernels_harris_strip.hip.h"
 #include "vslam_internal.h"
 
 using namespace vslam;
@@ -72,7 +73,8 @@ static int fail(vslam_ctx* c, int code, const std::string& msg) {
 static const char* const kKernelNames =
     "k_harris_fused\nk_harris_post\nk_compact_harris\nk_resize_linear2x\nk_blur_h_generic\nk_blur_v_generic\n"
     "k_dog5\nk_resize_nearest_half\nk_extrema\nk_compact_dog\nk_pyr_octave\n"
-    "k_gauss_v_strip\nk_gauss_h_strip\nk_resize_linear2x_v8\nk_resize_nearest_half_v4\nk_extrema_w3";
+    "k_gauss_v_strip\nk_gauss_h_strip\nk_resize_linear2x_v8\nk_resize_nearest_half_v4\nk_extrema_w3\n"
+    "k_harris_strip\nk_compact_harris_strip";
 
 // Launch on the context stream; bracket with events when the bench hook names this kernel.
 #define LAUNCH(ctx, name, kern, grid, block, ...)                                                \
@@ -438,12 +440,43 @@ static int enqueue_dog(vslam_ctx* c, const vslam_params& p, const vslam_batch_la
     return VSLAM_OK;
 }
 
+// Words of keypoint-flag scratch per frame for the Harris chain.
+static size_t harris_flag_words(int rows, int cols) {
+    if (cols % 4 == 0) return (size_t)rows * ((cols + HS_STRIP_W - 1) / HS_STRIP_W) * 4;
+    return (size_t)rows * ((cols + 63) / 64);
+}
+
 // Harris chain on nf device frames: response (required buffer), optional mask / nms2 /
-// keypoint list.
+// keypoint list.  cols % 4 == 0: the single-pass wave-strip kernel; otherwise the LDS-tiled
+// response kernel + the post-processing kernel.
 static int enqueue_harris(vslam_ctx* c, const uint8_t* frames, size_t fstep, size_t fframe, int rows, int cols,
                           int nf, float k, float* resp, uint8_t* mask, float* nms2, unsigned long long* hflags,
                           vslam_kp* kps, unsigned int cap, unsigned int* counts) {
     const size_t N = (size_t)rows * cols;
+    if (cols % 4 == 0 && fstep == (size_t)cols && fframe % 4 == 0) {
+        HarrisStripArgs a;
+        a.img = frames;
+        a.frame = fframe;
+        a.rows = rows;
+        a.cols = cols;
+        a.k = k;
+        a.resp = resp;
+        a.mask = mask;
+        a.nms2 = nms2;
+        a.flags = hflags;
+        a.nstrips = (cols + HS_STRIP_W - 1) / HS_STRIP_W;
+        a.fframe = (size_t)rows * a.nstrips * 4;
+        // enough waves to fill the chip several times over, long enough strips to amortise the
+        // 9-row pipeline fill
+        const long want_seg = std::max<long>(1, 12288 / ((long)a.nstrips * nf));
+        a.seg = (int)std::min<long>(rows, std::max<long>(16, (rows + want_seg - 1) / want_seg));
+        const int nseg = (rows + a.seg - 1) / a.seg;
+        LAUNCH(c, "k_harris_strip", k_harris_strip, dim3((a.nstrips * nseg + 3) / 4, 1, nf), dim3(256), a);
+        if (hflags && kps && counts)
+            LAUNCH(c, "k_compact_harris_strip", k_compact_harris_strip, dim3(nf), dim3(1024), hflags, a.fframe, rows, cols,
+                   a.nstrips, resp, N, kps, cap, counts);
+        return VSLAM_OK;
+    }
     LAUNCH(c, "k_harris_fused", k_harris_fused, dim3((cols + HT_W - 1) / HT_W, (rows + HT_H - 1) / HT_H, nf),
            dim3(256), frames, fstep, fframe, rows, cols, k, resp, (size_t)cols, N);
     if (mask || nms2 || hflags) {
@@ -727,12 +760,11 @@ int vslam_harris_keypoints_u8(vslam_ctx* c, const uint8_t* img, int rows, int co
     TRY(bind_device(c));
     ARGCHK(c, img && count && rows > 0 && cols > 0 && step >= (size_t)cols && (out || cap == 0), "harris_keypoints: bad arguments");
     const size_t P = (size_t)rows * cols;
-    const int wpr = (cols + 63) / 64;
     const unsigned int dcap = (unsigned int)std::min<size_t>(cap, 0x7fffffff);
-    TRY(ws_reserve(c, ws_need(P) + ws_need(4 * P) + ws_need((size_t)rows * wpr * 8) + ws_need(sizeof(vslam_kp) * (size_t)dcap) + 256));
+    TRY(ws_reserve(c, ws_need(P) + ws_need(4 * P) + ws_need(harris_flag_words(rows, cols) * 8) + ws_need(sizeof(vslam_kp) * (size_t)dcap) + 256));
     uint8_t* d_img = ws_take<uint8_t>(c, P);
     float* d_r = ws_take<float>(c, P);
-    unsigned long long* d_f = ws_take<unsigned long long>(c, (size_t)rows * wpr);
+    unsigned long long* d_f = ws_take<unsigned long long>(c, harris_flag_words(rows, cols));
     vslam_kp* d_k = ws_take<vslam_kp>(c, dcap);
     unsigned int* d_n = ws_take<unsigned int>(c, 1);
     TRY(h2d(c, d_img, cols, img, step, cols, rows));
@@ -907,18 +939,17 @@ int vslam_detect_batch_dev(vslam_ctx* c, const vslam_params* pp, const uint8_t* 
     const bool harris = p.do_harris && (out->response || out->nms_mask || out->nms2 || want_kps);
     ARGCHK(c, !dog || out->pyramid, "detect_batch: the DoG path needs out->pyramid");
     const size_t N = (size_t)p.rows * p.cols;
-    const int wpr = (p.cols + 63) / 64;
     // Whole-batch launches: every kernel sees all frames (grid.z = frames), so even the coarse
     // octaves fill the chip.  Scratch: octave bases (+ u16 row sums of the non-tiled octaves).
     const int chunk = std::min(n_frames, 256);
     size_t need = 0;
     if (dog) need += dog_scratch_bytes(L, p.sigma0, chunk);
-    if (harris) need += (out->response ? 0 : ws_need((size_t)chunk * N * 4)) + ws_need((size_t)chunk * p.rows * wpr * 8);
+    if (harris) need += (out->response ? 0 : ws_need((size_t)chunk * N * 4)) + ws_need((size_t)chunk * harris_flag_words(p.rows, p.cols) * 8);
     TRY(ws_reserve(c, need));
     DogScratch s;
     if (dog) TRY(dog_scratch_take(c, L, p.sigma0, chunk, s));
     float* resp_ws = (harris && !out->response) ? ws_take<float>(c, (size_t)chunk * N) : nullptr;
-    unsigned long long* hflags = harris ? ws_take<unsigned long long>(c, (size_t)chunk * p.rows * wpr) : nullptr;
+    unsigned long long* hflags = harris ? ws_take<unsigned long long>(c, (size_t)chunk * harris_flag_words(p.rows, p.cols)) : nullptr;
     for (int f0 = 0; f0 < n_frames; f0 += chunk) {
         const int nf = std::min(chunk, n_frames - f0);
         const uint8_t* fr = d_frames + (size_t)f0 * frame_stride;
