@@ -19,10 +19,13 @@
 //        the taps are symmetric).
 //   hp  [TH][HPP]         dwords: pass-1 output of the current level as u16 PAIRS of
 //        horizontally adjacent columns -- the operand shape of a horizontal dot2.
-// Taps come from the kernel-argument segment (scalar loads, SGPR operands): t4[l][o][m] =
-// 4 taps packed as bytes for window alignment o, tp[l][e] = taps (e-1, e) packed as u16.
-// Kernel widths are template parameters, so every loop is fully unrolled and all-zero tap
-// words are skipped at compile time.
+// Taps are wave-uniform scalar loads (SGPR operands) from a small device table: t4[l][o][m] =
+// 4 taps packed as bytes for window alignment o, tp[l][e] = taps (e-1, e) packed as u16.  The
+// loads of a pass are pinned behind an opaque zero defined at the start of that pass, so only
+// one pass's taps are live at a time (letting the scheduler hoist all 6 levels' loads to the
+// kernel entry spilled ~400 SGPRs through v_readlane).  Kernel widths are template parameters
+// (the zero-trimmed effective widths), so every loop is fully unrolled and all-zero tap words
+// are skipped at compile time.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -78,7 +81,7 @@ struct PyrTaps {
 
 // One Gaussian level of the tile: pass 1 into hp, pass 2 into registers, pack, DoG, store.
 template <class CFG, int L>
-__device__ __forceinline__ void pyr_level(const PyrTaps<CFG>& taps, const uint32_t* __restrict__ rp,
+__device__ __forceinline__ void pyr_level(const PyrTaps<CFG>* __restrict__ taps, const uint32_t* __restrict__ rp,
                                           uint32_t* __restrict__ hp, uint8_t* __restrict__ out, size_t P, int cols,
                                           int rows, int tile_x0, int tile_y0, uint32_t (&prev_e)[4][2],
                                           uint32_t (&prev_o)[4][2]) {
@@ -86,6 +89,10 @@ __device__ __forceinline__ void pyr_level(const PyrTaps<CFG>& taps, const uint32
     constexpr int NCG = CFG::ncg(L), M = CFG::m1(L), NB = CFG::nb(L);
     constexpr int RWP = CFG::RWP, HPP = CFG::HPP, TH = CFG::TH;
     const int tid = threadIdx.x;
+    uint32_t z1;
+    asm volatile("s_mov_b32 %0, 0" : "=s"(z1));  // pins this pass's tap loads here
+    const uint32_t* __restrict__ t4 = &taps->t4[L][0][0] + z1;
+    const uint4* __restrict__ rp4 = reinterpret_cast<const uint4*>(rp);
 
     // ---- pass 1: vertical, item = 4 h-columns x 4 rows --------------------------------------
     for (int it = tid; it < NCG * (TH / 4); it += 256) {
@@ -95,7 +102,7 @@ __device__ __forceinline__ void pyr_level(const PyrTaps<CFG>& taps, const uint32
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int c = 0; c < 4; ++c) acc[j][c] = 0;
-        const uint4* col = reinterpret_cast<const uint4*>(rp + (rq + A / 4) * RWP + 4 * cg + A);
+        const uint4* col = rp4 + (rq + A / 4) * (RWP / 4) + cg + A / 4;
 #pragma unroll
         for (int m = 0; m < M; ++m) {
             const uint4 v = col[m * (RWP / 4)];
@@ -103,7 +110,7 @@ __device__ __forceinline__ void pyr_level(const PyrTaps<CFG>& taps, const uint32
             for (int j = 0; j < 4; ++j) {
                 const int s = dl + j, o = s & 3, mm = m - (s >> 2);
                 if (mm >= 0 && mm <= ((o + n - 1) >> 2)) {
-                    const uint32_t t = taps.t4[L][o][mm];
+                    const uint32_t t = t4[o * CFG::T4M + mm];
                     acc[j][0] = udot4(v.x, t, acc[j][0]);
                     acc[j][1] = udot4(v.y, t, acc[j][1]);
                     acc[j][2] = udot4(v.z, t, acc[j][2]);
@@ -122,6 +129,9 @@ __device__ __forceinline__ void pyr_level(const PyrTaps<CFG>& taps, const uint32
     __syncthreads();
 
     // ---- pass 2: horizontal, item = 8 columns x 4 rows (exactly one per thread) -------------
+    uint32_t z2;
+    asm volatile("s_mov_b32 %0, 0" : "=s"(z2));
+    const uint32_t* __restrict__ tp = &taps->tp[L][0] + z2;
     const int xg = tid & (CFG::TW / 8 - 1), rg = tid / (CFG::TW / 8);
     uint32_t acc[4][8];
 #pragma unroll
@@ -139,7 +149,7 @@ __device__ __forceinline__ void pyr_level(const PyrTaps<CFG>& taps, const uint32
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int e = 2 * (4 * b + pp) - j - dl + 1;  // tap pair (e-1, e)
-                    if (e >= 0 && e <= n) acc[jr][j] = udot2(vv[pp], taps.tp[L][e], acc[jr][j]);
+                    if (e >= 0 && e <= n) acc[jr][j] = udot2(vv[pp], tp[e], acc[jr][j]);
                 }
             }
         }
@@ -178,7 +188,7 @@ __device__ __forceinline__ void pyr_level(const PyrTaps<CFG>& taps, const uint32
 template <class CFG>
 __global__ __launch_bounds__(256) void k_pyr_octave(const uint8_t* __restrict__ base, size_t bframe,
                                                      uint8_t* __restrict__ oct_out, size_t pframe, int rows, int cols,
-                                                     const PyrTaps<CFG> taps) {
+                                                     const PyrTaps<CFG>* __restrict__ taps) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t* rp = smem;
     uint32_t* hp = smem + CFG::RQ * CFG::RWP;
@@ -251,9 +261,9 @@ static void pyr_pack_taps(const uint16_t* const t[6], PyrTaps<CFG>& out) {
     }
 }
 
-// The reference's fixed pyramid (sigma0 = 1.6, Diff_of_Gauss.cpp:743): kernel widths of
-// SURVEY.md Appendix C for octaves 0 and 1.
-using PyrCfgOct0 = PyrCfg<128, 64, 11, 13, 17, 21, 25, 31>;
-using PyrCfgOct1 = PyrCfg<128, 64, 21, 25, 31, 39, 49, 63>;
+// The reference's fixed pyramid (sigma0 = 1.6, Diff_of_Gauss.cpp:743): the zero-trimmed widths
+// of the SURVEY.md Appendix C kernels (11,13,17,21,25,31 / 21,25,31,39,49,63) for octaves 0, 1.
+using PyrCfgOct0 = PyrCfg<128, 64, 9, 13, 15, 19, 23, 29>;
+using PyrCfgOct1 = PyrCfg<128, 64, 19, 23, 29, 37, 45, 57>;
 
 }  // namespace vslam

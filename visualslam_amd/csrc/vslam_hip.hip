@@ -33,6 +33,7 @@ struct vslam_ctx {
     size_t ws_cap = 0, ws_off = 0;
     std::map<std::pair<int, uint64_t>, uint16_t*> taps;  // device copies of quantised taps
     std::map<std::pair<uint64_t, int>, StripTaps*> strip_taps;  // (sigma0 bits, octave) -> device tables
+    std::map<std::pair<uint64_t, int>, void*> tile_taps;        // (sigma0 bits, octave) -> PyrTaps<CFG>
     // bench timing hook
     std::string timing_name;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timing_ev;
@@ -124,17 +125,19 @@ static T* ws_take(vslam_ctx* c, size_t count) {
 }
 static inline size_t ws_need(size_t bytes) { return align_up(bytes, 256); }
 
-static int get_taps(vslam_ctx* c, int n, double sigma, const uint16_t** out) {
+// Device copy of the (zero-trimmed) quantised taps of one GaussianBlur; *n_eff = trimmed width.
+static int get_taps(vslam_ctx* c, int n, double sigma, const uint16_t** out, int* n_eff) {
     uint64_t sb;
     std::memcpy(&sb, &sigma, 8);
     auto key = std::make_pair(n, sb);
+    std::vector<uint16_t> h;
+    if (!gauss_taps_q8_trimmed(n, sigma, h)) return fail(c, VSLAM_ERR_INVALID, "invalid Gaussian kernel size");
+    *n_eff = (int)h.size();
     auto it = c->taps.find(key);
     if (it == c->taps.end()) {
-        std::vector<uint16_t> h((size_t)n);
-        if (!gauss_taps_q8(n, sigma, h.data())) return fail(c, VSLAM_ERR_INVALID, "invalid Gaussian kernel size");
         uint16_t* d = nullptr;
-        HIPCHK(c, hipMalloc((void**)&d, sizeof(uint16_t) * (size_t)n));
-        HIPCHK(c, hipMemcpy(d, h.data(), sizeof(uint16_t) * (size_t)n, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMalloc((void**)&d, sizeof(uint16_t) * h.size()));
+        HIPCHK(c, hipMemcpy(d, h.data(), sizeof(uint16_t) * h.size(), hipMemcpyHostToDevice));
         it = c->taps.emplace(key, d).first;
     }
     *out = it->second;
@@ -150,18 +153,17 @@ enum class OctPath { Tile0, Tile1, Strip, Generic };
 
 struct OctPlan {
     OctPath path = OctPath::Generic;
-    int ks[6] = {};
+    int ks[6] = {};                 // OpenCV kernel widths (GaussianBlur's ksize)
     double sg[6] = {};
-    int sh = 0;  // rows per horizontal strip workgroup
+    int ke[6] = {};                 // zero-trimmed widths the fast kernels run with
+    std::vector<uint16_t> taps[6];  // trimmed taps
+    int sh = 0;                     // rows per horizontal strip workgroup
 };
 
-static bool taps_fit_u8(const int ks[6], const double sg[6]) {
-    for (int l = 0; l < 6; ++l) {
-        std::vector<uint16_t> t((size_t)ks[l]);
-        if (!gauss_taps_q8(ks[l], sg[l], t.data())) return false;
-        for (uint16_t v : t)
+static bool taps_fit_u8(const OctPlan& pl) {
+    for (int l = 0; l < 6; ++l)
+        for (uint16_t v : pl.taps[l])
             if (v > 255) return false;
-    }
     return true;
 }
 
@@ -178,12 +180,14 @@ static OctPlan plan_octave(double sigma0, int o, int rows, int cols) {
     for (int l = 0; l < 6; ++l) {
         pl.sg[l] = sigma_at(sigma0, o, l);
         pl.ks[l] = gauss_ksize_u8(pl.sg[l]);
-        nmax = std::max(nmax, pl.ks[l]);
+        if (!gauss_taps_q8_trimmed(pl.ks[l], pl.sg[l], pl.taps[l])) return pl;
+        pl.ke[l] = (int)pl.taps[l].size();
+        nmax = std::max(nmax, pl.ke[l]);
     }
-    if (cols % 8 != 0 || !taps_fit_u8(pl.ks, pl.sg)) return pl;
-    if (matches_cfg<PyrCfgOct0>(pl.ks)) {
+    if (cols % 8 != 0 || !taps_fit_u8(pl)) return pl;
+    if (matches_cfg<PyrCfgOct0>(pl.ke)) {
         pl.path = OctPath::Tile0;
-    } else if (matches_cfg<PyrCfgOct1>(pl.ks)) {
+    } else if (matches_cfg<PyrCfgOct1>(pl.ke)) {
         pl.path = OctPath::Tile1;
     } else if (nmax <= 245) {
         const int RM = (nmax / 2 + 3) & ~3;
@@ -201,15 +205,10 @@ static int get_strip_taps(vslam_ctx* c, double sigma0, int o, const OctPlan& pl,
     auto key = std::make_pair(sb, o);
     auto it = c->strip_taps.find(key);
     if (it == c->strip_taps.end()) {
-        std::vector<uint16_t> host[6];
         const uint16_t* tp[6];
-        for (int l = 0; l < 6; ++l) {
-            host[l].resize((size_t)pl.ks[l]);
-            gauss_taps_q8(pl.ks[l], pl.sg[l], host[l].data());
-            tp[l] = host[l].data();
-        }
+        for (int l = 0; l < 6; ++l) tp[l] = pl.taps[l].data();
         std::vector<StripTaps> st(1);
-        if (!strip_pack_taps(tp, pl.ks, st[0])) return fail(c, VSLAM_ERR_UNSUPPORTED, "strip kernels: taps out of range");
+        if (!strip_pack_taps(tp, pl.ke, st[0])) return fail(c, VSLAM_ERR_UNSUPPORTED, "strip kernels: taps out of range");
         StripTaps* d = nullptr;
         HIPCHK(c, hipMalloc((void**)&d, sizeof(StripTaps)));
         HIPCHK(c, hipMemcpy(d, st.data(), sizeof(StripTaps), hipMemcpyHostToDevice));
@@ -241,7 +240,7 @@ static int enqueue_strip_octave(vslam_ctx* c, double sigma0, int o, const OctPla
     const StripTaps* taps;
     TRY(get_strip_taps(c, sigma0, o, pl, &taps));
     int nmax = 0;
-    for (int l = 0; l < 6; ++l) nmax = std::max(nmax, pl.ks[l]);
+    for (int l = 0; l < 6; ++l) nmax = std::max(nmax, pl.ke[l]);
     const int RM = (nmax / 2 + 3) & ~3;
     const int rhq = (((rows + 3) & ~3) + 2 * RM + 16) / 4;
     const size_t v_lds = (size_t)rhq * STRIP_W * 4;
@@ -270,7 +269,7 @@ static int enqueue_strip_octave(vslam_ctx* c, double sigma0, int o, const OctPla
 static int enqueue_blur(vslam_ctx* c, const uint8_t* src, size_t sstep, size_t sframe, uint8_t* dst, size_t dstep,
                         size_t dframe, uint16_t* h, int rows, int cols, int nf, int n, double sigma) {
     const uint16_t* taps;
-    int rc = get_taps(c, n, sigma, &taps);
+    int rc = get_taps(c, n, sigma, &taps, &n);  // n becomes the trimmed width
     if (rc) return rc;
     const size_t P = (size_t)rows * cols;
     LAUNCH(c, "k_blur_h_generic", k_blur_h_generic, grid_rows(cols, rows, nf), dim3(256), src, sstep, sframe, h, P,
@@ -340,32 +339,27 @@ static int dog_scratch_take(vslam_ctx* c, const vslam_batch_layout& L, double si
 }
 
 
-// Fused LDS-tiled octave (kernels_pyramid.hip.h) when the six kernel widths match a compiled
-// configuration; returns false (nothing enqueued) otherwise so the caller takes the generic path.
+// Fused LDS-tiled octave (kernels_pyramid.hip.h); the plan has already matched CFG's widths.
 template <class CFG>
-static int try_enqueue_pyr_octave(vslam_ctx* c, const int ks[6], const double sg[6], const uint8_t* base, size_t bframe,
-                                  uint8_t* oct_out, size_t pframe, int rows, int cols, int nf, bool* done) {
-    *done = false;
-    if (cols % 8 != 0) return VSLAM_OK;
-    for (int l = 0; l < 6; ++l)
-        if (ks[l] != CFG::n(l)) return VSLAM_OK;
-    std::vector<uint16_t> host[6];
-    const uint16_t* tp[6];
-    for (int l = 0; l < 6; ++l) {
-        host[l].resize((size_t)ks[l]);
-        if (!gauss_taps_q8(ks[l], sg[l], host[l].data())) return fail(c, VSLAM_ERR_INVALID, "invalid Gaussian kernel size");
-        for (int k = 0; k < ks[l]; ++k)
-            if (host[l][k] > 255) return VSLAM_OK;  // u8 operand of the vertical dot4
-        tp[l] = host[l].data();
-    }
-    static bool attr_set = false;
-    if (!attr_set) {
+static int enqueue_pyr_octave(vslam_ctx* c, double sigma0, int o, const OctPlan& pl, const uint8_t* base, size_t bframe,
+                              uint8_t* oct_out, size_t pframe, int rows, int cols, int nf) {
+    uint64_t sb;
+    std::memcpy(&sb, &sigma0, 8);
+    auto key = std::make_pair(sb, o);
+    auto it = c->tile_taps.find(key);
+    if (it == c->tile_taps.end()) {
+        const uint16_t* tp[6];
+        for (int l = 0; l < 6; ++l) tp[l] = pl.taps[l].data();
+        std::vector<PyrTaps<CFG>> host(1);
+        pyr_pack_taps<CFG>(tp, host[0]);
+        void* d = nullptr;
+        HIPCHK(c, hipMalloc(&d, sizeof(PyrTaps<CFG>)));
+        HIPCHK(c, hipMemcpy(d, host.data(), sizeof(PyrTaps<CFG>), hipMemcpyHostToDevice));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pyr_octave<CFG>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES));
-        attr_set = true;
+        it = c->tile_taps.emplace(key, d).first;
     }
-    PyrTaps<CFG> taps;
-    pyr_pack_taps<CFG>(tp, taps);
+    const PyrTaps<CFG>* taps = static_cast<const PyrTaps<CFG>*>(it->second);
     const dim3 grid((cols + CFG::TW - 1) / CFG::TW, (rows + CFG::TH - 1) / CFG::TH, nf);
     const bool timed = c->timing_name == "k_pyr_octave";
     std::pair<hipEvent_t, hipEvent_t>* ev = timed ? timing_slot(c) : nullptr;
@@ -374,10 +368,8 @@ static int try_enqueue_pyr_octave(vslam_ctx* c, const int ks[6], const double sg
                        cols, taps);
     if (ev) (void)hipEventRecord(ev->second, c->stream);
     HIPCHK(c, hipGetLastError());
-    *done = true;
     return VSLAM_OK;
 }
-
 
 // createPyramid (GaussPyramid.cpp:106-131) + initialKeypointDetection (Diff_of_Gauss.cpp:254)
 // for nf frames; pyr/bits/points are per-frame blocks with the given strides.
@@ -398,16 +390,13 @@ static int enqueue_dog(vslam_ctx* c, const vslam_params& p, const vslam_batch_la
         const uint8_t* base = s.bases + s.base_off[o];
         uint8_t* oct = pyr + L.octave_offset[o];
         const OctPlan pl = plan_octave(p.sigma0, o, rows, cols);
-        bool fused = false;
         if (pl.path == OctPath::Tile0)
-            TRY(try_enqueue_pyr_octave<PyrCfgOct0>(c, pl.ks, pl.sg, base, s.bases_frame, oct, pframe, rows, cols, nf, &fused));
+            TRY(enqueue_pyr_octave<PyrCfgOct0>(c, p.sigma0, o, pl, base, s.bases_frame, oct, pframe, rows, cols, nf));
         else if (pl.path == OctPath::Tile1)
-            TRY(try_enqueue_pyr_octave<PyrCfgOct1>(c, pl.ks, pl.sg, base, s.bases_frame, oct, pframe, rows, cols, nf, &fused));
-        else if (pl.path == OctPath::Strip) {
+            TRY(enqueue_pyr_octave<PyrCfgOct1>(c, p.sigma0, o, pl, base, s.bases_frame, oct, pframe, rows, cols, nf));
+        else if (pl.path == OctPath::Strip)
             TRY(enqueue_strip_octave(c, p.sigma0, o, pl, base, s.bases_frame, oct, pframe, s.h, rows, cols, nf));
-            fused = true;
-        }
-        if (!fused) {
+        else {
             for (int l = 0; l < VSLAM_NUM_LEVELS; ++l)
                 TRY(enqueue_blur(c, base, (size_t)cols, s.bases_frame, oct + (size_t)l * P, (size_t)cols, pframe, s.h, rows,
                                  cols, nf, pl.ks[l], pl.sg[l]));
@@ -542,6 +531,7 @@ int vslam_ctx_destroy(vslam_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     for (auto& kv : c->taps) (void)hipFree(kv.second);
     for (auto& kv : c->strip_taps) (void)hipFree(kv.second);
+    for (auto& kv : c->tile_taps) (void)hipFree(kv.second);
     for (auto& ev : c->timing_ev) {
         (void)hipEventDestroy(ev.first);
         (void)hipEventDestroy(ev.second);

@@ -2,6 +2,7 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <vector>
 
 #include "../../include/vslam.h"
 
@@ -10,6 +11,7 @@
 namespace vslam {
 int gauss_ksize_u8(double sigma);
 bool gauss_taps_q8(int n, double sigma, uint16_t* taps);
+bool gauss_taps_q8_trimmed(int n, double sigma, std::vector<uint16_t>& out);
 double sigma_at(double sigma0, int octave, int level);
 int auto_num_octaves(int rows, int cols);
 void half_size(int rows, int cols, int* r, int* c);

@@ -60,6 +60,19 @@ bool gauss_taps_q8(int n, double sigma, uint16_t* taps) {
     return true;
 }
 
+// Quantised Gaussian taps with their all-zero tails removed.  Error diffusion leaves the
+// outermost taps of every sigma >= 1.6 kernel at 0 (sigma = 5.08: 31 -> 29 taps; sigma = 40.6:
+// 245 -> 223), and a zero tap contributes nothing to the exact integer sum, so the kernels may
+// use the trimmed window: same result, fewer MACs, smaller halos.
+bool gauss_taps_q8_trimmed(int n, double sigma, std::vector<uint16_t>& out) {
+    std::vector<uint16_t> t((size_t)(n > 0 ? n : 0));
+    if (!gauss_taps_q8(n, sigma, t.data())) return false;
+    int z = 0;
+    while (2 * z + 1 < n && t[z] == 0 && t[n - 1 - z] == 0) ++z;
+    out.assign(t.begin() + z, t.end() - z);
+    return true;
+}
+
 double sigma_at(double sigma0, int octave, int level) {
     const double k = std::pow(2.0f, 1.0f / (double)3);  // GaussPyramid.hpp:69
     return std::pow(2, octave) * sigma0 * std::pow(k, level);
