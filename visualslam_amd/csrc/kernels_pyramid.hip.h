@@ -143,6 +143,10 @@ __device__ __forceinline__ void pyr_level(const PyrTaps<CFG>* __restrict__ taps,
 #pragma unroll
         for (int jr = 0; jr < 4; ++jr) {
             const uint4 v = *reinterpret_cast<const uint4*>(hp + (4 * rg + jr) * HPP + 4 * xg + 4 * b);
+            // keep the access one conflict-free ds_read_b128: if only part of v is used (window
+            // edges) hipcc narrows it to ds_read2_b32, which at this 16-byte lane stride is a
+            // 4-way bank conflict
+            asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
             const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int pp = 0; pp < 4; ++pp) {

@@ -125,6 +125,7 @@ __device__ __forceinline__ void h_item_level(const uint32_t* __restrict__ hrow, 
 #pragma unroll
         for (int jr = 0; jr < 4; ++jr) {
             const uint4 v = *reinterpret_cast<const uint4*>(hrow + jr * pw + (tx0 >> 1) + 4 * b);
+            asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));  // stay one ds_read_b128
             const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int pp = 0; pp < 4; ++pp)
