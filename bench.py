@@ -166,15 +166,20 @@ def main():
         roof = None
         if launches and kms > 0:
             ach = algo.get(kname, 0) * n * args.steps / (kms * 1e-3) / 1e9
+            # measured HBM bytes per launch from the committed PMC passes (profiles/traffic.json,
+            # made by tools/pmc_summary.py), scaled to this run's frames per launch
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tpath):
-                traffic = json.load(open(tpath)).get(kname)
+                t = json.load(open(tpath)).get(kname)
+                if t:
+                    traffic = t["hbm_bytes_per_frame"] * n * args.steps / launches
             roof = {
                 "kernel": kname, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBPS, "traffic": traffic,
                 "launches": launches, "avg_launch_ms": kms / launches,
                 "algorithmic_bytes_per_frame": algo.get(kname, 0),
+                "algorithmic_bytes_per_launch": algo.get(kname, 0) * n * args.steps / launches,
             }
         line = {
             "metric": "frames/sec @1080p (Harris + DoG keypoint detection)",

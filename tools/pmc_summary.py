@@ -23,9 +23,10 @@ for d in sys.argv[1:]:
             acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {}
 for k, cs in sorted(acc.items()):
-    row = {c: sum(v) / len(v) for c, v in cs.items()}
+    row = {c: sum(v) / len(v) for c, v in cs.items()}          # mean per launch
     row["launches"] = max(len(v) for v in cs.values())
-    if "FETCH_SIZE" in row and "WRITE_SIZE" in row:
-        row["hbm_bytes_per_launch"] = 2 * row["FETCH_SIZE"] * 1024 + row["WRITE_SIZE"] * 1024
+    if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+        # totals over every launch of the run (a kernel may be launched once per octave)
+        row["hbm_bytes_total"] = 2 * sum(cs["FETCH_SIZE"]) * 1024 + sum(cs["WRITE_SIZE"]) * 1024
     out[k] = row
 print(json.dumps(out, indent=1))
