@@ -84,7 +84,7 @@ def main():
     import torch
     import torch.distributed as dist
 
-    from visualslam_amd import capi, synth
+    from visualslam_amd import capi, sharding, synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -126,10 +126,7 @@ def main():
         ctx.detect_batch(p, frames, **out)
         counts_local[0] = out["harris_counts"].sum()
         counts_local[1] = out["dog_counts"].sum()
-        if world > 1:  # the one collective of the path: 16 B per rank over RCCL
-            dist.all_gather_into_tensor(counts_all.view(-1), counts_local)
-        else:
-            counts_all[0] = counts_local
+        sharding.gather_counts(counts_local, counts_all)  # the one collective of the path: 16 B per rank over RCCL
 
     def fence():
         torch.cuda.synchronize()

@@ -1,0 +1,77 @@
+"""The C++ host mirror (visualslam_amd/cxx) builds against the C ABI; its headless executables
+(same target names as the reference: Harris, DoG, Pyramid_Test) run on the GPU box and fail
+loudly without a GPU."""
+import json
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "visualslam_amd", "bin")
+
+
+@pytest.fixture(scope="module")
+def built():
+    from visualslam_amd import capi
+
+    capi.build()
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "visualslam_amd", "cxx")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    return BIN
+
+
+def test_cxx_mirror_builds(built):
+    for exe in ("Harris", "DoG", "Pyramid_Test"):
+        assert os.access(os.path.join(built, exe), os.X_OK)
+
+
+def test_executables_fail_loudly_without_gpu(built):
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    r = subprocess.run([os.path.join(built, "Harris"), "64x48"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "no CPU fallback" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("exe,arg", [("Harris", "640x480"), ("Harris", "1754x1240"), ("DoG", "512x384"), ("Pyramid_Test", None)])
+def test_executables_run(built, exe, arg):
+    cmd = [os.path.join(built, exe)] + ([arg] if arg else [])
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["exe"] == exe
+    if exe == "Harris":
+        assert out["keypoints_stagewise"] == out["keypoints_fused"] > 0
+    if exe == "DoG":
+        assert len(out["octaves"]) == 4 and out["keypoints"] > 0
+    if exe == "Pyramid_Test":
+        assert out["failures"] == 0
+
+
+@pytest.mark.gpu
+def test_cxx_results_match_oracle(built, tmp_path):
+    # a PGM on disk through the C++ executables gives the oracle's counts
+    import numpy as np
+
+    import oracle
+    from visualslam_amd import synth
+
+    img = synth.frame_np(96, 160, 0, 0, "checker")  # same generator as imgio::synthetic(96,160)
+    p = tmp_path / "f.pgm"
+    with open(p, "wb") as f:
+        f.write(b"P5\n160 96\n255\n" + img.tobytes())
+    r = subprocess.run([os.path.join(built, "Harris"), str(p)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    want = len(oracle.harris_keypoints(oracle.nms2(oracle.harris_response(img), 5)[0]))
+    assert json.loads(r.stdout.strip().splitlines()[-1])["keypoints_fused"] == want
+    r = subprocess.run([os.path.join(built, "Harris"), "160x96"], capture_output=True, text=True, timeout=300)
+    assert json.loads(r.stdout.strip().splitlines()[-1])["keypoints_fused"] == want  # imgio::synthetic == synth.py
+    r = subprocess.run([os.path.join(built, "DoG"), str(p)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    pyr = oracle.Pyramid(img, 4, 1.6)
+    want_oct = [len(pyr.extrema(o, 3, 8)[1]) for o in range(4)]
+    got = json.loads(r.stdout.strip().splitlines()[-1])
+    assert [o["candidates"] for o in got["octaves"]] == want_oct

@@ -1,0 +1,58 @@
+// Headless, asserting counterpart of the reference's `Pyramid_Test` (tests/GaussPyramid_Test.cpp):
+// the values that program prints are checked against the answers derivable from the reference
+// sources.  building.jpg is 868x600; geometry needs only its size.
+#include <cmath>
+#include <cstdio>
+
+#include "imgio.hpp"
+#include "vslam_cxx.hpp"
+
+using namespace cv;
+
+static int failures = 0;
+#define EXPECT(cond)                                                    \
+    do {                                                                \
+        if (!(cond)) {                                                  \
+            std::fprintf(stderr, "FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); \
+            ++failures;                                                 \
+        }                                                               \
+    } while (0)
+
+int main() {
+    try {
+        Mat img = imgio::synthetic(600, 868);
+        GaussPyramid pyramid{img, 4, 1.6};                      // tests/GaussPyramid_Test.cpp:83-85
+        EXPECT(pyramid.getNumOctaves() == 4);                   // :88
+        EXPECT(pyramid.getNumLevels() == 6);                    // :89
+        const int want[4][2] = {{1736, 1200}, {868, 600}, {434, 300}, {217, 150}};
+        for (int o = 0; o < 4; ++o) {                           // :92-93
+            EXPECT(pyramid.octaveBlur(o).size() == 6);
+            EXPECT(pyramid.octaveDiff(o).size() == 5);
+            EXPECT(pyramid.octaveBlur(o)[0].cols == want[o][0] && pyramid.octaveBlur(o)[0].rows == want[o][1]);
+            EXPECT(pyramid.octaveImage(o).cols == want[o][0]);
+        }
+        EXPECT(pyramid.getSigmaAt(0, 0) == 1.6);                                  // :99
+        EXPECT(std::fabs(pyramid.getSigmaAt(0, 5) - 5.079683366298239) < 1e-12);  // :102
+        EXPECT(std::fabs(pyramid.getSigmaAt(0, 3) - 3.2) < 1e-12);                // :105
+        EXPECT(pyramid.octaveSigma(3).size() == 6);                               // :110
+        // DoG = saturating difference of adjacent Gaussians (GaussPyramid.cpp:197)
+        const auto& g = pyramid.octaveBlur(2);
+        const auto& d = pyramid.octaveDiff(2);
+        long bad = 0;
+        for (int r = 0; r < g[0].rows; ++r)
+            for (int c = 0; c < g[0].cols; ++c) {
+                const int diff = (int)g[3].at<uchar>(r, c) - (int)g[2].at<uchar>(r, c);
+                bad += d[2].at<uchar>(r, c) != (diff > 0 ? diff : 0);
+            }
+        EXPECT(bad == 0);
+        GaussPyramid autop{img, 1.6};  // second constructor: floor(log2(600)) - 4 = 5 octaves
+        EXPECT(autop.getNumOctaves() == 5);
+        std::vector<Mat> padded = GaussPyramid::padOctave(1, d);
+        EXPECT(padded.size() == 5 && padded[0].rows == d[0].rows + 2 && padded[0].at<uchar>(0, 0) == d[0].at<uchar>(0, 0));
+        std::printf("{\"exe\": \"Pyramid_Test\", \"failures\": %d}\n", failures);
+        return failures ? 1 : 0;
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "Pyramid_Test: %s\n", e.what());
+        return EXIT_FAILURE;
+    }
+}

@@ -1,0 +1,251 @@
+#include "vslam_cxx.hpp"
+
+#include <cmath>
+#include <mutex>
+
+using cv::Mat;
+
+namespace vslam {
+
+vslam_ctx* default_context(int device) {
+    static std::mutex mu;
+    static std::map<int, vslam_ctx*> ctxs;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = ctxs.find(device);
+    if (it != ctxs.end()) return it->second;
+    vslam_ctx* c = nullptr;
+    const int rc = vslam_ctx_create(device, nullptr, &c);
+    if (rc != VSLAM_OK) throw Error(rc, std::string("vslam_ctx_create: ") + vslam_status_string(rc) + " (no usable HIP device: there is no CPU fallback)");
+    ctxs[device] = c;
+    return c;
+}
+
+void check(int status, vslam_ctx* ctx, const char* what) {
+    if (status != VSLAM_OK)
+        throw Error(status, std::string(what) + ": " + vslam_status_string(status) + ": " + vslam_last_error(ctx));
+}
+
+}  // namespace vslam
+
+using vslam::check;
+using vslam::default_context;
+
+static void require(bool ok, const char* msg) {
+    if (!ok) throw vslam::Error(VSLAM_ERR_INVALID, msg);
+}
+
+namespace vslamcv {
+
+void GaussianBlur(const Mat& src, Mat& dst, cv::Size ksize, double sigmaX, double, int) {
+    require(src.type() == cv::CV_8U && ksize.width == ksize.height, "GaussianBlur: CV_8U, square kernels only");
+    Mat out(src.rows, src.cols, cv::CV_8U);
+    vslam_ctx* c = default_context();
+    check(vslam_gaussian_blur_u8(c, src.data, src.rows, src.cols, src.step, ksize.width, sigmaX, out.data, out.step), c, "GaussianBlur");
+    dst = out;
+}
+
+void Sobel(const Mat& src, Mat& dst, int ddepth, int dx, int dy, int ksize, double scale, double delta, int) {
+    require(src.type() == cv::CV_8U && ddepth == cv::CV_32F && ksize == 1 && scale == 1 && delta == 0, "Sobel: CV_8U -> CV_32F, ksize 1 only");
+    Mat out(src.rows, src.cols, cv::CV_32F);
+    vslam_ctx* c = default_context();
+    check(vslam_sobel_k1_u8_f32(c, src.data, src.rows, src.cols, src.step, dx, dy, out.ptr<float>(), out.step), c, "Sobel");
+    dst = out;
+}
+
+void convertScaleAbs(const Mat& src, Mat& dst) {
+    require(src.type() == cv::CV_32F, "convertScaleAbs: CV_32F input only");
+    Mat out(src.rows, src.cols, cv::CV_8U);
+    vslam_ctx* c = default_context();
+    check(vslam_convert_scale_abs_f32(c, src.ptr<float>(), src.rows, src.cols, src.step, out.data, out.step), c, "convertScaleAbs");
+    dst = out;
+}
+
+void resize(const Mat& src, Mat& dst, cv::Size, double fx, double fy, int interpolation) {
+    require(src.type() == cv::CV_8U, "resize: CV_8U only");
+    vslam_ctx* c = default_context();
+    if (fx == 2 && fy == 2 && interpolation == INTER_LINEAR) {
+        Mat out(src.rows * 2, src.cols * 2, cv::CV_8U);
+        check(vslam_resize_linear2x_u8(c, src.data, src.rows, src.cols, src.step, out.data, out.step), c, "resize x2");
+        dst = out;
+    } else if (fx == 0.5 && fy == 0.5 && interpolation == INTER_NEAREST) {
+        int r, cc;
+        vslam_half_size(src.rows, src.cols, &r, &cc);
+        Mat out(r, cc, cv::CV_8U);
+        check(vslam_resize_nearest_half_u8(c, src.data, src.rows, src.cols, src.step, out.data, out.step), c, "resize x0.5");
+        dst = out;
+    } else {
+        throw vslam::Error(VSLAM_ERR_UNSUPPORTED, "resize: only (2,2,INTER_LINEAR) and (0.5,0.5,INTER_NEAREST) are on the hot path");
+    }
+}
+
+}  // namespace vslamcv
+
+Mat HarrisCorner(Mat& Ix, Mat& Iy) {
+    require(Ix.type() == cv::CV_32F && Iy.type() == cv::CV_32F && Ix.rows == Iy.rows && Ix.cols == Iy.cols && Ix.step == Iy.step,
+            "HarrisCorner: two CV_32F gradients of equal geometry");
+    // intended geometry rows x cols (the reference allocates it transposed: SURVEY Appendix B-1)
+    Mat image(Ix.rows, Ix.cols, cv::CV_32F);
+    vslam_ctx* c = default_context();
+    check(vslam_harris_from_grad_f32(c, Ix.ptr<float>(), Iy.ptr<float>(), Ix.rows, Ix.cols, Ix.step, 0.04f, 3, image.ptr<float>(), image.step), c,
+          "HarrisCorner");
+    return image;
+}
+
+Mat NonMaximumSuppression(Mat& response, int windowSize) {
+    Mat localMax(response.rows, response.cols, cv::CV_8U);
+    vslam_ctx* c = default_context();
+    if (response.type() == cv::CV_8U)
+        check(vslam_nms_strict_u8(c, response.data, response.rows, response.cols, response.step, windowSize, localMax.data, localMax.step), c,
+              "NonMaximumSuppression");
+    else
+        check(vslam_nms_strict_f32(c, response.ptr<float>(), response.rows, response.cols, response.step, windowSize, localMax.data, localMax.step),
+              c, "NonMaximumSuppression");
+    return localMax;
+}
+
+Mat NMS2(Mat& response, int windowSize) {
+    require(response.type() == cv::CV_32F, "NMS2: CV_32F response");
+    Mat nms(response.rows, response.cols, cv::CV_32F);  // intended f32 map (Appendix B-3)
+    vslam_ctx* c = default_context();
+    float true_max = 0;
+    check(vslam_nms2_f32(c, response.ptr<float>(), response.rows, response.cols, response.step, windowSize, nms.ptr<float>(), nms.step, &true_max), c,
+          "NMS2");
+    return nms;
+}
+
+std::vector<vslam_kp> HarrisKeypoints(const Mat& gray, float k) {
+    require(gray.type() == cv::CV_8U, "HarrisKeypoints: CV_8U frame");
+    vslam_ctx* c = default_context();
+    std::vector<vslam_kp> out(1 << 16);
+    size_t n = 0;
+    check(vslam_harris_keypoints_u8(c, gray.data, gray.rows, gray.cols, gray.step, k, out.data(), out.size(), &n), c, "HarrisKeypoints");
+    if (n > out.size()) {
+        out.resize(n);
+        check(vslam_harris_keypoints_u8(c, gray.data, gray.rows, gray.cols, gray.step, k, out.data(), out.size(), &n), c, "HarrisKeypoints");
+    }
+    out.resize(n);
+    return out;
+}
+
+// ------------------------------------------------------------------------------- GaussPyramid
+
+GaussPyramid::GaussPyramid(Mat& img, int numOctaves, double sigma) { build(img, numOctaves, sigma); }
+GaussPyramid::GaussPyramid(Mat& img, double sigma) { build(img, 0, sigma); }  // automatic octave count
+
+GaussPyramid::~GaussPyramid() {
+    if (pyr_) vslam_pyramid_destroy(pyr_);
+}
+
+void GaussPyramid::build(Mat& img, int numOctaves, double sigma) {
+    require(img.type() == cv::CV_8U && !img.empty(), "GaussPyramid: CV_8U image");
+    vslam_ctx* c = default_context();
+    check(vslam_pyramid_build_u8(c, img.data, img.rows, img.cols, img.step, numOctaves, sigma, &pyr_), c, "GaussPyramid");
+    check(vslam_pyramid_get_info(pyr_, &info_), c, "GaussPyramid info");
+    for (int o = 0; o < info_.n_octaves; ++o)
+        sigmas_[o] = std::vector<double>(info_.sigma[o], info_.sigma[o] + info_.n_levels);
+}
+
+void GaussPyramid::checkOctave(int octave) const {
+    if (octave < 0 || octave >= info_.n_octaves) throw std::out_of_range("GaussPyramid: octave");  // std::map::at in the reference
+}
+
+double GaussPyramid::getSigmaAt(int octave, int level) const {
+    checkOctave(octave);
+    if (level < 0 || level >= info_.n_levels) throw std::out_of_range("GaussPyramid: level");
+    return info_.sigma[octave][level];
+}
+
+double GaussPyramid::calculateSigma(int octave, int level) const { return vslam_sigma_at(info_.sigma0, octave, level); }
+
+const std::vector<double>& GaussPyramid::octaveSigma(int octave) {
+    checkOctave(octave);
+    return sigmas_.at(octave);
+}
+
+const std::vector<Mat>& GaussPyramid::octaveBlur(int octave) {
+    checkOctave(octave);
+    auto it = gauss_.find(octave);
+    if (it == gauss_.end()) {
+        std::vector<Mat> v;
+        for (int l = 0; l < info_.n_levels; ++l) {
+            Mat m(info_.rows[octave], info_.cols[octave], cv::CV_8U);
+            check(vslam_pyramid_get_gauss(pyr_, octave, l, m.data, m.step), default_context(), "octaveBlur");
+            v.push_back(m);
+        }
+        it = gauss_.emplace(octave, std::move(v)).first;
+    }
+    return it->second;
+}
+
+const std::vector<Mat>& GaussPyramid::octaveDiff(int octave) {
+    checkOctave(octave);
+    auto it = diff_.find(octave);
+    if (it == diff_.end()) {
+        std::vector<Mat> v;
+        for (int l = 0; l < info_.n_dogs; ++l) {
+            Mat m(info_.rows[octave], info_.cols[octave], cv::CV_8U);
+            check(vslam_pyramid_get_dog(pyr_, octave, l, m.data, m.step), default_context(), "octaveDiff");
+            v.push_back(m);
+        }
+        it = diff_.emplace(octave, std::move(v)).first;
+    }
+    return it->second;
+}
+
+const std::vector<Mat>& GaussPyramid::imagePyramid() {
+    if (img_pyramid_.empty())
+        for (int o = 0; o < info_.n_octaves; ++o) {
+            Mat m(info_.rows[o], info_.cols[o], cv::CV_8U);
+            check(vslam_pyramid_get_base(pyr_, o, m.data, m.step), default_context(), "imagePyramid");
+            img_pyramid_.push_back(m);
+        }
+    return img_pyramid_;
+}
+
+const Mat& GaussPyramid::octaveImage(int octave) {
+    checkOctave(octave);
+    return imagePyramid().at((size_t)octave);
+}
+
+const std::map<int, std::vector<Mat>>& GaussPyramid::pyramidGauss() {
+    for (int o = 0; o < info_.n_octaves; ++o) octaveBlur(o);
+    return gauss_;
+}
+
+const std::map<int, std::vector<Mat>>& GaussPyramid::pyramidDiff() {
+    for (int o = 0; o < info_.n_octaves; ++o) octaveDiff(o);
+    return diff_;
+}
+
+// copyMakeBorder(..., BORDER_REPLICATE) + clone (GaussPyramid.cpp:133-141).  Pure data movement
+// for callers that want the padded copies; the extrema kernel itself clamps addresses instead.
+std::vector<Mat> GaussPyramid::padOctave(int padding, const std::vector<Mat>& images) {
+    std::vector<Mat> padded;
+    for (const Mat& im : images) {
+        Mat p(im.rows + 2 * padding, im.cols + 2 * padding, im.type());
+        const size_t es = im.elemSize();
+        for (int r = 0; r < p.rows; ++r) {
+            const int sr = std::min(std::max(r - padding, 0), im.rows - 1);
+            for (int c = 0; c < p.cols; ++c) {
+                const int sc = std::min(std::max(c - padding, 0), im.cols - 1);
+                std::memcpy(p.data + p.step * r + es * c, im.data + im.step * sr + es * sc, es);
+            }
+        }
+        padded.push_back(p);
+    }
+    return padded;
+}
+
+void initialKeypointDetection(std::vector<SLAM::point>& keypoints, GaussPyramid& pyramid, int octave, int windowSize, int minContrast) {
+    vslam_ctx* c = default_context();
+    size_t n = 0;
+    std::vector<vslam_point> buf(1 << 16);
+    check(vslam_dog_extrema(c, pyramid.handle(), octave, windowSize, minContrast, nullptr, buf.data(), buf.size(), &n), c, "initialKeypointDetection");
+    if (n > buf.size()) {
+        buf.resize(n);
+        check(vslam_dog_extrema(c, pyramid.handle(), octave, windowSize, minContrast, nullptr, buf.data(), buf.size(), &n), c,
+              "initialKeypointDetection");
+    }
+    for (size_t i = 0; i < n; ++i)
+        keypoints.emplace_back(buf[i].row, buf[i].col, buf[i].value, buf[i].padding, buf[i].octave, buf[i].level);
+}

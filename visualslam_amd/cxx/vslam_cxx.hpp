@@ -1,0 +1,104 @@
+// C++17 mirror of the reference's detector API for the hot path, implemented over the C ABI
+// of include/vslam.h (hand-written HIP kernels; no CPU compute here).  Same names, argument
+// meaning and return types as the reference's free functions / class, so its callers compile
+// against this header unchanged (paths relative to /root/reference/KeyPointDetection/):
+//
+//   Mat HarrisCorner(Mat& Ix, Mat& Iy)                         Harris_corners.cpp:31
+//   Mat NonMaximumSuppression(Mat& response, int windowSize)   Harris_corners.cpp:70
+//   Mat NMS2(Mat& response, int windowSize)                    Harris_corners.cpp:83
+//   class GaussPyramid                                         include/src/GaussPyramid/GaussPyramid.hpp:14
+//   struct SLAM::point                                         Diff_of_Gauss.cpp:27
+//   void initialKeypointDetection(std::vector<SLAM::point>&, GaussPyramid&, int, int)
+//                                                              Diff_of_Gauss.cpp:254
+// plus the OpenCV calls on the path (vslamcv::GaussianBlur / Sobel / convertScaleAbs / resize).
+// StructureMatrix (:10) is a per-pixel helper used only inside HarrisCorner and is subsumed by
+// it.  Errors of the C ABI surface as vslam::Error (the reference relies on cv::Exception).
+// The per-level gradient getters (octaveGradX ...) belong to processGradients, a "next" row of
+// SURVEY.md section 8f, and are not provided yet.
+#pragma once
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/vslam.h"
+#include "cvlite.hpp"
+
+namespace vslam {
+
+struct Error : std::runtime_error {
+    int status;
+    Error(int s, const std::string& what) : std::runtime_error(what), status(s) {}
+};
+
+// One process-wide context per device (the reference is single-threaded: SURVEY 8b).
+vslam_ctx* default_context(int device = 0);
+void check(int status, vslam_ctx* ctx, const char* what);
+
+}  // namespace vslam
+
+namespace SLAM {
+struct point {  // Diff_of_Gauss.cpp:27-35
+    point(int row_, int col_, int value_, int padding_, int octave_, int level_)
+        : row(row_), col(col_), value(value_), padding(padding_), octave(octave_), level(level_) {}
+    point() = default;
+    int row = 0, col = 0, value = 0, padding = 0, octave = 0, level = 0;
+};
+static_assert(sizeof(point) == sizeof(vslam_point), "SLAM::point must stay six ints");
+}  // namespace SLAM
+
+namespace vslamcv {  // the OpenCV call sites of the hot path
+enum { BORDER_DEFAULT = 4, INTER_NEAREST = 0, INTER_LINEAR = 1 };
+void GaussianBlur(const cv::Mat& src, cv::Mat& dst, cv::Size ksize, double sigmaX, double sigmaY = 0,
+                  int borderType = BORDER_DEFAULT);
+void Sobel(const cv::Mat& src, cv::Mat& dst, int ddepth, int dx, int dy, int ksize = 1, double scale = 1,
+           double delta = 0, int borderType = BORDER_DEFAULT);
+void convertScaleAbs(const cv::Mat& src, cv::Mat& dst);
+void resize(const cv::Mat& src, cv::Mat& dst, cv::Size dsize, double fx, double fy, int interpolation);
+}  // namespace vslamcv
+
+cv::Mat HarrisCorner(cv::Mat& Ix, cv::Mat& Iy);
+cv::Mat NonMaximumSuppression(cv::Mat& response, int windowSize);
+cv::Mat NMS2(cv::Mat& response, int windowSize);
+// Whole Harris front end on the 8-bit frame in one fused kernel (Harris_corners.cpp:158-182).
+std::vector<vslam_kp> HarrisKeypoints(const cv::Mat& gray, float k = 0.04f);
+
+class GaussPyramid {
+public:
+    GaussPyramid(cv::Mat& img, int numOctaves, double sigma);
+    GaussPyramid(cv::Mat& img, double sigma);
+    ~GaussPyramid();
+    GaussPyramid(const GaussPyramid&) = delete;
+    GaussPyramid& operator=(const GaussPyramid&) = delete;
+    int getNumOctaves() const { return info_.n_octaves; }
+    int getNumLevels() const { return info_.n_levels; }
+    int getNumScaleSamples() const { return info_.n_levels - 3; }
+    double getSigmaAt(int octave, int level) const;
+    double calculateSigma(int octave, int level) const;
+    const cv::Mat& octaveImage(int octave);
+    const std::vector<double>& octaveSigma(int octave);
+    const std::vector<cv::Mat>& octaveBlur(int octave);
+    const std::vector<cv::Mat>& octaveDiff(int octave);
+    const std::vector<cv::Mat>& imagePyramid();
+    const std::map<int, std::vector<cv::Mat>>& pyramidGauss();
+    const std::map<int, std::vector<cv::Mat>>& pyramidDiff();
+    static std::vector<cv::Mat> padOctave(int padding, const std::vector<cv::Mat>& images);
+    const vslam_pyramid* handle() const { return pyr_; }  // the HBM-resident pyramid
+
+private:
+    void build(cv::Mat& img, int numOctaves, double sigma);
+    void checkOctave(int octave) const;
+    vslam_pyramid* pyr_ = nullptr;
+    vslam_pyramid_info info_{};
+    // host copies are fetched lazily, one octave at a time (the stacks stay in HBM)
+    std::vector<cv::Mat> img_pyramid_;
+    std::map<int, std::vector<double>> sigmas_;
+    std::map<int, std::vector<cv::Mat>> gauss_, diff_;
+};
+
+// Appends the scale-space extrema candidates of one octave in the reference's loop order.
+// The reference filters each candidate through FeaturePointLocalization (a "next" row); here
+// candidates with DoG value >= minContrast are appended (8 reproduces the
+// degenerate-case contrast test 0.03*255).
+void initialKeypointDetection(std::vector<SLAM::point>& keypoints, GaussPyramid& pyramid, int octave, int windowSize,
+                              int minContrast = 8);
