@@ -174,7 +174,7 @@ def test_fast_paths_are_the_ones_that_run(env):
     # (a silent fall-back to the generic kernels would still pass parity)
     ctx, torch = env
     frames = synth.frames_np(1, 480, 640, stream_id=1)
-    for name, want in (("k_pyr_octave", 2), ("k_harris_strip", 1), ("k_gauss_h_strip", 2), ("k_resize_linear2x_v8", 1)):
+    for name, want in (("k_pyr_octave", 2), ("k_harris_strip", 1), ("k_gauss_h_strip", 2), ("k_resize_linear2x_slide", 1)):
         ctx.kernel_timing_enable(name)
         run_batch(ctx, torch, frames)
         launches, ms = ctx.kernel_timing_read()

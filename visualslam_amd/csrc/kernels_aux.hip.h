@@ -47,6 +47,68 @@ __global__ __launch_bounds__(256) void k_resize_linear2x_v8(const uint8_t* __res
     *reinterpret_cast<uint2*>(dst + blockIdx.z * dframe + (size_t)dy * (2 * cols) + 8 * k) = make_uint2(o[0], o[1]);
 }
 
+
+// ---- K-D0 (sliding form): the same operator, 3.4 instead of 17 VALU instructions per pixel ----
+// A thread owns 4 source columns (= 8 destination columns) and walks down a segment of source
+// rows; per source row the horizontal pass is done ONCE in 16-bit lanes and reused by the four
+// destination rows it feeds.  With s = source pixels, the 11-bit fixed-point steps collapse to
+//   A = s_i + 3 s_{i+1}  (or 3 s_i + s_{i+1})            h = 512 A,  h >> 4 = 32 A
+//   (512*32A) >> 16 = A >> 2,   (1536*32A) >> 16 = (3A) >> 2
+//   dst(2m)   = ((A(m-1) >> 2) + ((3 A(m)) >> 2) + 2) >> 2
+//   dst(2m+1) = (((3 A(m)) >> 2) + (A(m+1) >> 2) + 2) >> 2
+// which is bit-identical to the literal formula of k_resize_linear2x_v8 (clamped reads at the
+// borders).  Requires cols % 4 == 0.  grid = (ceil(cols/4/256), ceil(rows/seg), frames).
+typedef unsigned short us2r_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_lshr_u16(uint32_t a, int sh) {
+    return __builtin_bit_cast(uint32_t, (us2r_t)(__builtin_bit_cast(us2r_t, a) >> (unsigned short)sh));
+}
+
+__global__ __launch_bounds__(256) void k_resize_linear2x_slide(const uint8_t* __restrict__ src, size_t sframe,
+                                                                uint8_t* __restrict__ dst, size_t dframe, int rows,
+                                                                int cols, int seg) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (4 * k >= cols) return;
+    const int m0 = blockIdx.y * seg, m1 = min(m0 + seg, rows);
+    const uint8_t* s = src + blockIdx.z * sframe;
+    uint8_t* d = dst + blockIdx.z * dframe + 8 * k;
+    const int xl = max(4 * k - 1, 0), xr = min(4 * k + 4, cols - 1);
+    // X = A >> 2 and Y = 3A >> 2 of one source row, as (j0,j2) (j1,j3) (j4,j6) (j5,j7) 16-bit pairs
+    auto hrow = [&](int m, uint32_t (&X)[4], uint32_t (&Y)[4]) {
+        const uint8_t* r = s + (size_t)min(max(m, 0), rows - 1) * cols;
+        const uint32_t w = *reinterpret_cast<const uint32_t*>(r + 4 * k);  // s1 s2 s3 s4
+        const uint32_t s0 = r[xl], s5 = r[xr];
+        const uint32_t P = __builtin_amdgcn_perm(w, w, 0x0c010c00);   // (s1, s2)
+        const uint32_t Q = __builtin_amdgcn_perm(w, w, 0x0c030c02);   // (s3, s4)
+        const uint32_t Qm = __builtin_amdgcn_perm(w, w, 0x0c020c01);  // (s2, s3)
+        const uint32_t Pm = s0 | ((w & 0xffu) << 16);                  // (s0, s1)
+        const uint32_t Qp = (w >> 24) | (s5 << 16);                    // (s4, s5)
+        const uint32_t P3 = P + (P << 1), Q3 = Q + (Q << 1);          // <= 765 per lane
+        const uint32_t A[4] = {Pm + P3, P3 + Qm, Qm + Q3, Q3 + Qp};    // (j0,j2) (j1,j3) (j4,j6) (j5,j7)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            X[i] = pk_lshr_u16(A[i], 2);
+            Y[i] = pk_lshr_u16(A[i] + (A[i] << 1), 2);  // 3A <= 3060 per lane
+        }
+    };
+    auto emit = [&](int dy, const uint32_t (&U)[4], const uint32_t (&V)[4]) {
+        uint32_t v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = pk_lshr_u16(U[i] + V[i] + 0x00020002u, 2);
+        *reinterpret_cast<uint2*>(d + (size_t)dy * (2 * cols)) = make_uint2(v[0] | (v[1] << 8), v[2] | (v[3] << 8));
+    };
+    uint32_t Xp[4], Yp[4], Xc[4], Yc[4];
+    hrow(m0 - 1, Xp, Yp);
+    hrow(m0, Xc, Yc);
+    for (int m = m0; m < m1; ++m) {
+        uint32_t Xn[4], Yn[4];
+        hrow(m + 1, Xn, Yn);
+        emit(2 * m, Xp, Yc);      // rows (m-1, m), weights (512, 1536)
+        emit(2 * m + 1, Yc, Xn);  // rows (m, m+1), weights (1536, 512)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Xp[i] = Xc[i], Xc[i] = Xn[i], Yc[i] = Yn[i];
+    }
+}
+
 // ---- K-D4: cv::resize(src, Size(), 0.5, 0.5, INTER_NEAREST) (GaussPyramid.cpp:126) ----------
 // One thread = 4 destination pixels.  Requires cols % 8 == 0 (then dcols = cols/2, % 4 == 0).
 __global__ __launch_bounds__(256) void k_resize_nearest_half_v4(const uint8_t* __restrict__ src, size_t sframe,

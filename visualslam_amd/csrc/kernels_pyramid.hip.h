@@ -168,14 +168,13 @@ __device__ __forceinline__ void pyr_level(const PyrTaps<CFG>* __restrict__ taps,
         uint32_t g[2], d[2];
 #pragma unroll
         for (int hw = 0; hw < 2; ++hw) {
-            const uint32_t lo = __builtin_amdgcn_perm(acc[jr][4 * hw + 1], acc[jr][4 * hw + 0], 0x0c0c0602);
-            const uint32_t hi = __builtin_amdgcn_perm(acc[jr][4 * hw + 3], acc[jr][4 * hw + 2], 0x0c0c0602);
-            g[hw] = __builtin_amdgcn_perm(hi, lo, 0x05040100);
-            const uint32_t e = g[hw] & 0x00ff00ffu, o = (g[hw] >> 8) & 0x00ff00ffu;
-            if (L > 0) {  // D_{L-1} = saturate_u8(G_L - G_{L-1}), GaussPyramid.cpp:197
-                const uint32_t de = pk_sub_sat_u16(e, prev_e[jr][hw]), dod = pk_sub_sat_u16(o, prev_o[jr][hw]);
-                d[hw] = de | (dod << 8);
-            }
+            // G = acc >> 16 is byte 2 of each accumulator.  Pick the even / odd pixels straight
+            // into 16-bit lanes (the shape the saturating subtract wants), then interleave.
+            const uint32_t e = __builtin_amdgcn_perm(acc[jr][4 * hw + 2], acc[jr][4 * hw + 0], 0x0c060c02);  // (G0, G2)
+            const uint32_t o = __builtin_amdgcn_perm(acc[jr][4 * hw + 3], acc[jr][4 * hw + 1], 0x0c060c02);  // (G1, G3)
+            g[hw] = e | (o << 8);
+            if (L > 0)  // D_{L-1} = saturate_u8(G_L - G_{L-1}), GaussPyramid.cpp:197
+                d[hw] = pk_sub_sat_u16(e, prev_e[jr][hw]) | (pk_sub_sat_u16(o, prev_o[jr][hw]) << 8);
             prev_e[jr][hw] = e;
             prev_o[jr][hw] = o;
         }

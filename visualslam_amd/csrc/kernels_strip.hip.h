@@ -192,10 +192,9 @@ __global__ __launch_bounds__(256) void k_gauss_h_strip(const uint16_t* __restric
                     uint32_t g[2], d[2] = {0, 0};
 #pragma unroll
                     for (int hw = 0; hw < 2; ++hw) {
-                        const uint32_t lo = __builtin_amdgcn_perm(acc[jr][4 * hw + 1], acc[jr][4 * hw + 0], 0x0c0c0602);
-                        const uint32_t hi = __builtin_amdgcn_perm(acc[jr][4 * hw + 3], acc[jr][4 * hw + 2], 0x0c0c0602);
-                        g[hw] = __builtin_amdgcn_perm(hi, lo, 0x05040100);
-                        const uint32_t e = g[hw] & 0x00ff00ffu, o = (g[hw] >> 8) & 0x00ff00ffu;
+                        const uint32_t e = __builtin_amdgcn_perm(acc[jr][4 * hw + 2], acc[jr][4 * hw + 0], 0x0c060c02);
+                        const uint32_t o = __builtin_amdgcn_perm(acc[jr][4 * hw + 3], acc[jr][4 * hw + 1], 0x0c060c02);
+                        g[hw] = e | (o << 8);
                         if (l > 0) d[hw] = pk_sub_sat_u16(e, prev_e[ii][jr][hw]) | (pk_sub_sat_u16(o, prev_o[ii][jr][hw]) << 8);
                         prev_e[ii][jr][hw] = e;
                         prev_o[ii][jr][hw] = o;
