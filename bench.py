@@ -96,7 +96,10 @@ def main():
         raise SystemExit("bench.py needs a GPU: the product has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ  # under torchrun even a single rank goes through RCCL
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     if args.gpus != world and rank == 0:
         print(f"note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
@@ -130,7 +133,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -149,7 +152,7 @@ def main():
     ctx.kernel_timing_enable(None)
 
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     totals = counts_all.sum(0).tolist()
@@ -209,7 +212,7 @@ def main():
         }
         print(json.dumps(line))
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
