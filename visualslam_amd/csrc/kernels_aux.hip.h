@@ -124,59 +124,84 @@ __global__ __launch_bounds__(256) void k_resize_nearest_half_v4(const uint8_t* _
 }
 
 // ---- K-D3: initialKeypointDetection for windowSize 3 (Diff_of_Gauss.cpp:254-297) -----------
-// One workgroup = one lattice row of one frame, all three levels.  The two image rows the
-// row's 2x2x3 windows touch (unpadded rows 3li-1 and 3li, clamped) are staged once for all five
-// DoG levels with 16-byte loads; each thread then serves lattice sites lj = lane-consecutive, so
-// a wave's 64 candidate flags are one ballot word = the bitmask layout of include/vslam.h.
-// Requires cols % 16 == 0.  Dynamic LDS = 10 * cols bytes.
+// One workgroup = 256 consecutive sites (4 ballot words) of one lattice row of one frame, all
+// three levels.  The 768-column span those sites touch, for the two image rows of the row's
+// 2x2x3 windows (unpadded rows 3li-1 and 3li, clamped) and all five DoG levels, is staged with
+// 16-byte loads (7.8 KB of LDS: small enough to co-reside with the pyramid kernel when the two
+// run on different streams).  One thread per site: its two columns (3lj-1, 3lj) are adjacent
+// bytes, fetched per staged row by one ds_read2_b32 of the enclosing dword pair and one v_perm
+// with a per-site selector, landing as (a, b) in 16-bit lanes for packed min/max.  A wave's 64
+// candidate flags leave as one ballot word = the bitmask layout of include/vslam.h.
+// Requires cols % 16 == 0.  grid = (ceil(words_per_row/4), lat_rows, frames).
+typedef unsigned short us2e_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(us2e_t, a), __builtin_bit_cast(us2e_t, b)));
+}
+__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(us2e_t, a), __builtin_bit_cast(us2e_t, b)));
+}
+
+constexpr int EXT_SPAN = 768;            // image columns per workgroup (256 sites x stride 3)
+constexpr int EXT_PITCH = EXT_SPAN + 16; // 16 guard bytes in front: column -1 of the span
+
 __global__ __launch_bounds__(256) void k_extrema_w3(const uint8_t* __restrict__ pyr, size_t pframe, ExtGeom g, int o,
                                                      unsigned long long* __restrict__ bits,
                                                      unsigned long long* __restrict__ lflags, size_t bframe) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t srow[];  // [level 0..4][row 0..1][cols]
+    __shared__ __attribute__((aligned(16))) uint8_t srow[10 * EXT_PITCH + 16];  // [level 0..4][row 0..1][EXT_PITCH]
     const int li = blockIdx.y, f = blockIdx.z;
     const int rows = g.rows[o], cols = g.cols[o];
     const size_t P = (size_t)rows * cols;
     const uint8_t* dog = pyr + f * pframe + g.oct_off[o] + (size_t)VSLAM_NUM_LEVELS * P;
     const int ya = max(3 * li - 1, 0), yb = 3 * li;  // padded rows i-1, i with i = 1 + 3li -> unpadded 3li-1, 3li
-    const int c16 = cols >> 4;
-    for (int it = threadIdx.x; it < 10 * c16; it += 256) {
-        const int rl = it / c16, x16 = it - rl * c16;  // rl = level*2 + row
-        const int y = (rl & 1) ? yb : ya;
-        const uint4 v = *reinterpret_cast<const uint4*>(dog + (size_t)(rl >> 1) * P + (size_t)y * cols + 16 * x16);
-        *reinterpret_cast<uint4*>(srow + rl * cols + 16 * x16) = v;
+    const int c0 = blockIdx.x * EXT_SPAN - 16;       // image column of staged byte 0
+    constexpr int C16 = EXT_PITCH / 16, NV = 10 * C16;  // 49 x 10 sixteen-byte pieces
+#pragma unroll
+    for (int i = 0; i < (NV + 255) / 256; ++i) {
+        const int it = threadIdx.x + 256 * i;
+        if (it < NV) {
+            const int rl = it / C16, x16 = it - rl * C16;  // rl = level*2 + row
+            const int c = c0 + 16 * x16;
+            if (c >= 0 && c < cols)
+                *reinterpret_cast<uint4*>(srow + rl * EXT_PITCH + 16 * x16) =
+                    *reinterpret_cast<const uint4*>(dog + (size_t)(rl >> 1) * P + (size_t)((rl & 1) ? yb : ya) * cols + c);
+        }
     }
+    if (blockIdx.x == 0 && threadIdx.x < 10)  // column -1 replicates column 0 (padOctave)
+        srow[threadIdx.x * EXT_PITCH + 15] = dog[(size_t)(threadIdx.x >> 1) * P + (size_t)((threadIdx.x & 1) ? yb : ya) * cols];
     __syncthreads();
     const int lc = g.lat_cols[o], wpr = g.wpr[o], lr = g.lat_rows[o];
-    for (int lj0 = 0; lj0 < wpr * 64; lj0 += 256) {
-        const int lj = lj0 + threadIdx.x;
-        bool cand[3] = {false, false, false}, listed[3] = {false, false, false};
-        if (lj < lc) {
-            const int xa = max(3 * lj - 1, 0), xb = 3 * lj;
-            int mn[5], mx[5], self[5];
+    const int lj = blockIdx.x * 256 + threadIdx.x;
+    bool cand[3] = {false, false, false}, listed[3] = {false, false, false};
+    if (lj < lc) {
+        const int xa = 3 * (int)threadIdx.x - 1 + 16;       // byte offset of column 3lj-1 in a staged row
+        const uint8_t* p0 = srow + (xa & ~3);               // enclosing dword pair
+        const uint32_t s = xa & 3;
+        const uint32_t sel = 0x0c000c00u | s | ((s + 1) << 16);  // (byte s, 0, byte s+1, 0)
+        uint32_t mn[5], mx[5], self[5];
 #pragma unroll
-            for (int l = 0; l < 5; ++l) {
-                const uint8_t* r0 = srow + (2 * l) * cols;
-                const uint8_t* r1 = r0 + cols;
-                const int a = r0[xa], b = r0[xb], c = r1[xa], d = r1[xb];
-                mn[l] = min(min(a, b), min(c, d));
-                mx[l] = max(max(a, b), max(c, d));
-                self[l] = d;  // (i, j) itself
-            }
-#pragma unroll
-            for (int L = 1; L <= 3; ++L) {
-                const int lo = min(mn[L - 1], min(mn[L], mn[L + 1])), hi = max(mx[L - 1], max(mx[L], mx[L + 1]));
-                cand[L - 1] = self[L] == lo || self[L] == hi;
-                listed[L - 1] = cand[L - 1] && self[L] >= g.min_contrast;
-            }
+        for (int l = 0; l < 5; ++l) {
+            const uint32_t* q0 = reinterpret_cast<const uint32_t*>(p0 + (2 * l) * EXT_PITCH);  // 4-byte aligned: ds_read2_b32
+            const uint32_t* q1 = reinterpret_cast<const uint32_t*>(p0 + (2 * l + 1) * EXT_PITCH);
+            const uint32_t v0 = __builtin_amdgcn_perm(q0[1], q0[0], sel), v1 = __builtin_amdgcn_perm(q1[1], q1[0], sel);  // (a,b), (c,d)
+            const uint32_t lo = pk_min_u16(v0, v1), hi = pk_max_u16(v0, v1);
+            mn[l] = min(lo & 0xffffu, lo >> 16);
+            mx[l] = max(hi & 0xffffu, hi >> 16);
+            self[l] = v1 >> 16;  // (i, j) itself = d
         }
 #pragma unroll
-        for (int L = 0; L < 3; ++L) {
-            const unsigned long long wc = __ballot(cand[L]), wl = __ballot(listed[L]);
-            if ((threadIdx.x & 63) == 0 && (lj >> 6) < wpr) {
-                const size_t w = f * bframe + g.bits_off[o] + ((size_t)L * lr + li) * wpr + (lj >> 6);
-                if (bits) bits[w] = wc;
-                lflags[w] = wl;
-            }
+        for (int L = 1; L <= 3; ++L) {
+            const uint32_t lo = min(mn[L - 1], min(mn[L], mn[L + 1])), hi = max(mx[L - 1], max(mx[L], mx[L + 1]));
+            cand[L - 1] = self[L] == lo || self[L] == hi;
+            listed[L - 1] = cand[L - 1] && (int)self[L] >= g.min_contrast;
+        }
+    }
+#pragma unroll
+    for (int L = 0; L < 3; ++L) {
+        const unsigned long long wc = __ballot(cand[L]), wl = __ballot(listed[L]);
+        if ((threadIdx.x & 63) == 0 && (lj >> 6) < wpr) {
+            const size_t w = f * bframe + g.bits_off[o] + ((size_t)L * lr + li) * wpr + (lj >> 6);
+            if (bits) bits[w] = wc;
+            lflags[w] = wl;
         }
     }
 }

@@ -447,8 +447,8 @@ static int enqueue_dog(vslam_ctx* c, const vslam_params& p, const vslam_batch_la
                 HIPCHK(c, hipStreamWaitEvent(side, c->ev_oct[o], 0));
                 es = side;
             }
-            if (p.extrema_window == 3 && cols % 16 == 0 && (size_t)10 * cols <= 64 * 1024)
-                hipLaunchKernelGGL(k_extrema_w3, dim3(1, L.lat_rows[o], nf), dim3(256), (size_t)10 * cols, es, pyr, pframe, g, o,
+            if (p.extrema_window == 3 && cols % 16 == 0)
+                hipLaunchKernelGGL(k_extrema_w3, dim3((L.lat_words[o] + 3) / 4, L.lat_rows[o], nf), dim3(256), 0, es, pyr, pframe, g, o,
                                    bits, s.lflags, L.bits_frame_words);
             else
                 hipLaunchKernelGGL(k_extrema, dim3((L.lat_cols[o] + 255) / 256, L.lat_rows[o], nf * 3), dim3(256), 0, es, pyr,
