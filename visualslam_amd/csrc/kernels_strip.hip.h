@@ -158,18 +158,24 @@ __global__ __launch_bounds__(256) void k_gauss_h_strip(const uint16_t* __restric
         const int n = taps->n[l], r = n >> 1, dl = r & 1, PL = r + dl;
         const uint16_t* hl = h + blockIdx.z * hframe + (size_t)l * P;
         // ---- stage SH rows, reflect-101 extended, as u16 pairs -------------------------------
-        const int npairs = (cols + 2 * PL + 2) >> 1;  // covers cx in [0, cols + 2PL + 2)
         __syncthreads();  // previous level's reads are done
-        for (int jr = tid >> 6; jr < SH; jr += 4) {  // one wave per row: coalesced dword loads
+        for (int jr = tid >> 6; jr < SH; jr += 4) {  // one wave per row
             const uint16_t* row = hl + (size_t)min(y0 + jr, rows - 1) * cols;
-            for (int pi = tid & 63; pi < npairs; pi += 64) {
+            uint32_t* dstp = hp + jr * pw + (PL >> 1);  // pair index of image column 0
+            // interior: 16-byte coalesced loads (8 columns), LDS side is only 4-byte aligned
+            for (int x8 = tid & 63; x8 < (cols >> 3); x8 += 64) {
+                const uint4 v = *reinterpret_cast<const uint4*>(row + 8 * x8);
+                uint32_t* q = dstp + 4 * x8;
+                q[0] = v.x, q[1] = v.y, q[2] = v.z, q[3] = v.w;
+            }
+            // reflect-101 halos: PL/2 pairs on the left, PL/2 + 1 on the right
+            const int nh = (PL >> 1) + 1;
+            for (int i = tid & 63; i < 2 * nh; i += 64) {
+                const int pi = i < nh ? i - nh + (PL >> 1) : (cols >> 1) + (PL >> 1) + (i - nh);  // left: 0..PL/2-1 (i=0 unused), right
+                if (pi < 0) continue;
                 const int x = 2 * pi - PL;
-                uint32_t w;
-                if (x >= 0 && x + 1 < cols)
-                    w = *reinterpret_cast<const uint32_t*>(row + x);
-                else
-                    w = (uint32_t)row[reflect101(x, cols)] | ((uint32_t)row[reflect101(x + 1, cols)] << 16);
-                hp[jr * pw + pi] = w;
+                if (x >= 0 && x + 1 < cols) continue;
+                hp[jr * pw + pi] = (uint32_t)row[reflect101(x, cols)] | ((uint32_t)row[reflect101(x + 1, cols)] << 16);
             }
         }
         __syncthreads();
