@@ -180,3 +180,15 @@ def test_fast_paths_are_the_ones_that_run(env):
         launches, ms = ctx.kernel_timing_read()
         ctx.kernel_timing_enable(None)
         assert launches >= want and ms > 0, (name, launches)
+
+
+@pytest.mark.parametrize("shape,n_oct", [((8, 8), 1), ((24, 40), 2), ((64, 48), 3), ((32, 128), 4)])
+def test_batch_tiny_frames(env, shape, n_oct):
+    # tiny frames through the specialised kernels: halos far larger than the image (repeated
+    # reflection), single-tile grids, lattice rows shorter than one ballot word
+    ctx, torch = env
+    frames = synth.frames_np(3, shape[0], shape[1], stream_id=11)
+    frames[1] = synth.frame_np(shape[0], shape[1], kind="noise")
+    p, L, out = run_batch(ctx, torch, frames, n_octaves=n_oct)
+    for f in range(3):
+        check_frame(p, L, out, f, frames[f], n_oct)

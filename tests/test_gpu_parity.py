@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
-SHAPES = [(48, 64), (33, 47), (1, 1), (1, 9), (7, 1), (2, 2), (16, 64), (17, 65), (70, 130), (3, 300)]
+SHAPES = [(48, 64), (33, 47), (1, 1), (1, 9), (7, 1), (2, 2), (16, 64), (17, 65), (70, 130), (3, 300), (1, 4), (2, 8), (5, 12), (9, 244), (300, 4)]
 
 
 @pytest.fixture(scope="module")
@@ -176,7 +176,7 @@ def check_pyramid(ctx, img, n_oct, sigma0=1.6):
         want.close()
 
 
-@pytest.mark.parametrize("shape,n_oct", [((48, 64), 3), ((33, 47), 3), ((40, 56), 4), ((9, 13), 2), ((2, 3), 1), ((135, 240), 4)])
+@pytest.mark.parametrize("shape,n_oct", [((48, 64), 3), ((33, 47), 3), ((40, 56), 4), ((9, 13), 2), ((2, 3), 1), ((135, 240), 4), ((4, 8), 3), ((16, 32), 4), ((3, 64), 2), ((67, 4), 2)])
 @pytest.mark.parametrize("kind", ["checker", "noise"])
 def test_pyramid_and_extrema_bit_exact(ctx, shape, n_oct, kind):
     check_pyramid(ctx, frame(shape, kind, 4), n_oct)
