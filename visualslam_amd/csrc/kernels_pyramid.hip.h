@@ -52,7 +52,7 @@ struct PyrCfg {
     static constexpr int n(int l) { return l == 0 ? N0 : l == 1 ? N1 : l == 2 ? N2 : l == 3 ? N3 : l == 4 ? N4 : N5; }
     static constexpr int cmax(int a, int b) { return a > b ? a : b; }
     static constexpr int NMAX = cmax(cmax(cmax(N0, N1), cmax(N2, N3)), cmax(N4, N5));
-    static constexpr int R = (NMAX / 2 + 3) & ~3;  // halo, multiple of 4
+    static constexpr int R = (NMAX / 2 + 15) & ~15;  // halo, multiple of 16 (16-byte staging loads)
     static constexpr int RQ = (TH + 2 * R) / 4;    // row quads of the raw tile
     static constexpr int RW = TW + 2 * R;          // raw tile width (pixels == rp dwords per row quad)
     static constexpr int RWP = RW + 4;             // padded pitch (pass 1 may read 1 dword group past RW)
@@ -60,7 +60,7 @@ struct PyrCfg {
     static constexpr int delta(int l) { return (R - r(l)) & 3; }
     static constexpr int A(int l) { return (R - r(l)) & ~3; }
     static constexpr int ncg(int l) { return (TW + 2 * r(l) + delta(l) + 3) / 4; }   // h column groups of 4
-    static constexpr int m1(int l) { return ((delta(l) + 3 + n(l) - 1) >> 2) + 1; } // rp dwords per pass-1 item column
+    static constexpr int m1(int l) { return ((delta(l) + 7 + n(l) - 1) >> 2) + 1; } // rp dwords per pass-1 item column (8 rows)
     static constexpr int pmax(int l) { return (7 + delta(l) + 2 * r(l)) / 2; }      // last u16 pair a pass-2 item reads
     static constexpr int nb(int l) { return pmax(l) / 4 + 1; }                      // b128 reads per row
     static constexpr int hpp_l(int l) { return cmax(2 * ncg(l), TW / 2 - 4 + 4 * nb(l)); }
@@ -69,7 +69,7 @@ struct PyrCfg {
     static constexpr int T4M = ((3 + NMAX - 1) >> 2) + 1;  // tap dwords per alignment
     static constexpr int TPM = NMAX + 1;                   // tap pairs
     static constexpr int LDS_BYTES = (RQ * RWP + TH * HPP) * 4;
-    static_assert(TW % 8 == 0 && TH % 4 == 0 && (TH / 4) * (TW / 8) == 256, "one pass-2 item per thread");
+    static_assert(TW % 16 == 0 && TH % 8 == 0 && (TH / 4) * (TW / 8) == 256, "one pass-2 item per thread");
     static_assert((N0 & 1) && (N1 & 1) && (N2 & 1) && (N3 & 1) && (N4 & 1) && (N5 & 1), "odd kernels");
 };
 
@@ -94,20 +94,20 @@ __device__ __forceinline__ void pyr_level(const PyrTaps<CFG>* __restrict__ taps,
     const uint32_t* __restrict__ t4 = &taps->t4[L][0][0] + z1;
     const uint4* __restrict__ rp4 = reinterpret_cast<const uint4*>(rp);
 
-    // ---- pass 1: vertical, item = 4 h-columns x 4 rows --------------------------------------
-    for (int it = tid; it < NCG * (TH / 4); it += 256) {
-        const int cg = it % NCG, rq = it / NCG;
-        uint32_t acc[4][4];
+    // ---- pass 1: vertical, item = 4 h-columns x 8 rows -------------------------------------
+    for (int it = tid; it < NCG * (TH / 8); it += 256) {
+        const int cg = it % NCG, ro = it / NCG;
+        uint32_t acc[8][4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 8; ++j)
 #pragma unroll
             for (int c = 0; c < 4; ++c) acc[j][c] = 0;
-        const uint4* col = rp4 + (rq + A / 4) * (RWP / 4) + cg + A / 4;
+        const uint4* col = rp4 + (2 * ro + A / 4) * (RWP / 4) + cg + A / 4;
 #pragma unroll
         for (int m = 0; m < M; ++m) {
             const uint4 v = col[m * (RWP / 4)];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < 8; ++j) {
                 const int s = dl + j, o = s & 3, mm = m - (s >> 2);
                 if (mm >= 0 && mm <= ((o + n - 1) >> 2)) {
                     const uint32_t t = t4[o * CFG::T4M + mm];
@@ -119,11 +119,11 @@ __device__ __forceinline__ void pyr_level(const PyrTaps<CFG>* __restrict__ taps,
             }
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 8; ++j) {
             uint2 w;
             w.x = acc[j][0] | (acc[j][1] << 16);
             w.y = acc[j][2] | (acc[j][3] << 16);
-            *reinterpret_cast<uint2*>(hp + (4 * rq + j) * HPP + 2 * cg) = w;
+            *reinterpret_cast<uint2*>(hp + (8 * ro + j) * HPP + 2 * cg) = w;
         }
     }
     __syncthreads();
@@ -205,30 +205,56 @@ __global__ __launch_bounds__(256) void k_pyr_octave(const uint8_t* __restrict__ 
     // ---- stage the base tile, byte-transposed ------------------------------------------------
     const bool interior = tile_x0 - R >= 0 && tile_x0 + CFG::TW + R <= cols && tile_y0 - R >= 0 &&
                           tile_y0 + CFG::TH + R <= rows;
-    for (int it = tid; it < RQ * (RW / 4); it += 256) {
-        const int yq = it / (RW / 4), xq = it - yq * (RW / 4);
-        const int gy = tile_y0 - R + 4 * yq, gx = tile_x0 - R + 4 * xq;
-        uint32_t a[4];
-        if (interior) {
+    if (interior && (cols & 15) == 0) {
+        // 16 pixels x 4 rows per item: 16-byte coalesced loads, four 4x4 byte transposes, four
+        // 16-byte LDS stores (RW is a multiple of 16, tile origin - R is 16-byte aligned)
+        for (int it = tid; it < RQ * (RW / 16); it += 256) {
+            const int yq = it / (RW / 16), xs = it - yq * (RW / 16);
+            const uint8_t* p = src + (size_t)(tile_y0 - R + 4 * yq) * cols + (tile_x0 - R + 16 * xs);
+            uint4 a[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) a[k] = *reinterpret_cast<const uint32_t*>(src + (size_t)(gy + k) * cols + gx);
-        } else {
+            for (int k = 0; k < 4; ++k) a[k] = *reinterpret_cast<const uint4*>(p + (size_t)k * cols);
+            const uint32_t* aw[4] = {&a[0].x, &a[1].x, &a[2].x, &a[3].x};
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint8_t* row = src + (size_t)reflect101(gy + k, rows) * cols;
-                a[k] = (uint32_t)row[reflect101(gx, cols)] | ((uint32_t)row[reflect101(gx + 1, cols)] << 8) |
-                       ((uint32_t)row[reflect101(gx + 2, cols)] << 16) | ((uint32_t)row[reflect101(gx + 3, cols)] << 24);
+            for (int q = 0; q < 4; ++q) {  // dword q of each row = pixels 4q..4q+3
+                const uint32_t r0 = aw[0][q], r1 = aw[1][q], r2 = aw[2][q], r3 = aw[3][q];
+                const uint32_t p01l = __builtin_amdgcn_perm(r1, r0, 0x05010400), p01h = __builtin_amdgcn_perm(r1, r0, 0x07030602);
+                const uint32_t p23l = __builtin_amdgcn_perm(r3, r2, 0x05010400), p23h = __builtin_amdgcn_perm(r3, r2, 0x07030602);
+                uint4 t;
+                t.x = __builtin_amdgcn_perm(p23l, p01l, 0x05040100);
+                t.y = __builtin_amdgcn_perm(p23l, p01l, 0x07060302);
+                t.z = __builtin_amdgcn_perm(p23h, p01h, 0x05040100);
+                t.w = __builtin_amdgcn_perm(p23h, p01h, 0x07060302);
+                *reinterpret_cast<uint4*>(rp + yq * RWP + 16 * xs + 4 * q) = t;
             }
         }
-        // 4x4 byte transpose: t[c] = (a0.c, a1.c, a2.c, a3.c)
-        const uint32_t p01l = __builtin_amdgcn_perm(a[1], a[0], 0x05010400), p01h = __builtin_amdgcn_perm(a[1], a[0], 0x07030602);
-        const uint32_t p23l = __builtin_amdgcn_perm(a[3], a[2], 0x05010400), p23h = __builtin_amdgcn_perm(a[3], a[2], 0x07030602);
-        uint4 t;
-        t.x = __builtin_amdgcn_perm(p23l, p01l, 0x05040100);
-        t.y = __builtin_amdgcn_perm(p23l, p01l, 0x07060302);
-        t.z = __builtin_amdgcn_perm(p23h, p01h, 0x05040100);
-        t.w = __builtin_amdgcn_perm(p23h, p01h, 0x07060302);
-        *reinterpret_cast<uint4*>(rp + yq * RWP + 4 * xq) = t;
+    } else {
+        // border tiles (and widths that are not a multiple of 16): one dword x 4 rows per item,
+        // BORDER_REFLECT_101 resolved per byte
+        for (int it = tid; it < RQ * (RW / 4); it += 256) {
+            const int yq = it / (RW / 4), xq = it - yq * (RW / 4);
+            const int gy = tile_y0 - R + 4 * yq, gx = tile_x0 - R + 4 * xq;
+            uint32_t a[4];
+            if (interior) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) a[k] = *reinterpret_cast<const uint32_t*>(src + (size_t)(gy + k) * cols + gx);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint8_t* row = src + (size_t)reflect101(gy + k, rows) * cols;
+                    a[k] = (uint32_t)row[reflect101(gx, cols)] | ((uint32_t)row[reflect101(gx + 1, cols)] << 8) |
+                           ((uint32_t)row[reflect101(gx + 2, cols)] << 16) | ((uint32_t)row[reflect101(gx + 3, cols)] << 24);
+                }
+            }
+            const uint32_t p01l = __builtin_amdgcn_perm(a[1], a[0], 0x05010400), p01h = __builtin_amdgcn_perm(a[1], a[0], 0x07030602);
+            const uint32_t p23l = __builtin_amdgcn_perm(a[3], a[2], 0x05010400), p23h = __builtin_amdgcn_perm(a[3], a[2], 0x07030602);
+            uint4 t;
+            t.x = __builtin_amdgcn_perm(p23l, p01l, 0x05040100);
+            t.y = __builtin_amdgcn_perm(p23l, p01l, 0x07060302);
+            t.z = __builtin_amdgcn_perm(p23h, p01h, 0x05040100);
+            t.w = __builtin_amdgcn_perm(p23h, p01h, 0x07060302);
+            *reinterpret_cast<uint4*>(rp + yq * RWP + 4 * xq) = t;
+        }
     }
     // the 4 pad dwords per row quad feed only h columns that pass 2 never reads (integers:
     // any value is harmless), so they are left uninitialised.
