@@ -84,7 +84,8 @@ template <class CFG, int L>
 __device__ __forceinline__ void pyr_level(const PyrTaps<CFG>* __restrict__ taps, const uint32_t* __restrict__ rp,
                                           uint32_t* __restrict__ hp, uint8_t* __restrict__ out, size_t P, int cols,
                                           int rows, int tile_x0, int tile_y0, uint32_t (&prev_e)[4][2],
-                                          uint32_t (&prev_o)[4][2]) {
+                                          uint32_t (&prev_o)[4][2], uint8_t* __restrict__ next_base, int nrows,
+                                          int ncols) {
     constexpr int n = CFG::n(L), dl = CFG::delta(L), A = CFG::A(L);
     constexpr int NCG = CFG::ncg(L), M = CFG::m1(L), NB = CFG::nb(L);
     constexpr int RWP = CFG::RWP, HPP = CFG::HPP, TH = CFG::TH;
@@ -182,6 +183,11 @@ __device__ __forceinline__ void pyr_level(const PyrTaps<CFG>* __restrict__ taps,
             const size_t off = (size_t)y * cols + x;
             *reinterpret_cast<uint2*>(out + (size_t)L * P + off) = make_uint2(g[0], g[1]);
             if (L > 0) *reinterpret_cast<uint2*>(out + (size_t)(VSLAM_NUM_LEVELS + L - 1) * P + off) = make_uint2(d[0], d[1]);
+            // next octave's base = Gaussian[3] decimated 2:1, INTER_NEAREST (GaussPyramid.cpp:123-126):
+            // pixel (2y', 2x'); tile origins and (jr, x) are even, so it is the even bytes of even rows
+            if (L == 3 && next_base && (jr & 1) == 0 && (y >> 1) < nrows && (x >> 1) < ncols)
+                *reinterpret_cast<uint32_t*>(next_base + (size_t)(y >> 1) * ncols + (x >> 1)) =
+                    __builtin_amdgcn_perm(g[1], g[0], 0x06040200);
         }
     }
 }
@@ -191,7 +197,8 @@ __device__ __forceinline__ void pyr_level(const PyrTaps<CFG>* __restrict__ taps,
 template <class CFG>
 __global__ __launch_bounds__(256) void k_pyr_octave(const uint8_t* __restrict__ base, size_t bframe,
                                                      uint8_t* __restrict__ oct_out, size_t pframe, int rows, int cols,
-                                                     const PyrTaps<CFG>* __restrict__ taps) {
+                                                     const PyrTaps<CFG>* __restrict__ taps, uint8_t* __restrict__ next_base,
+                                                     size_t nframe, int nrows, int ncols) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t* rp = smem;
     uint32_t* hp = smem + CFG::RQ * CFG::RWP;
@@ -260,13 +267,14 @@ __global__ __launch_bounds__(256) void k_pyr_octave(const uint8_t* __restrict__ 
     // any value is harmless), so they are left uninitialised.
     __syncthreads();
 
+    uint8_t* nb = next_base ? next_base + blockIdx.z * nframe : nullptr;
     uint32_t prev_e[4][2], prev_o[4][2];
-    pyr_level<CFG, 0>(taps, rp, hp, out, P, cols, rows, tile_x0, tile_y0, prev_e, prev_o);
-    pyr_level<CFG, 1>(taps, rp, hp, out, P, cols, rows, tile_x0, tile_y0, prev_e, prev_o);
-    pyr_level<CFG, 2>(taps, rp, hp, out, P, cols, rows, tile_x0, tile_y0, prev_e, prev_o);
-    pyr_level<CFG, 3>(taps, rp, hp, out, P, cols, rows, tile_x0, tile_y0, prev_e, prev_o);
-    pyr_level<CFG, 4>(taps, rp, hp, out, P, cols, rows, tile_x0, tile_y0, prev_e, prev_o);
-    pyr_level<CFG, 5>(taps, rp, hp, out, P, cols, rows, tile_x0, tile_y0, prev_e, prev_o);
+    pyr_level<CFG, 0>(taps, rp, hp, out, P, cols, rows, tile_x0, tile_y0, prev_e, prev_o, nb, nrows, ncols);
+    pyr_level<CFG, 1>(taps, rp, hp, out, P, cols, rows, tile_x0, tile_y0, prev_e, prev_o, nb, nrows, ncols);
+    pyr_level<CFG, 2>(taps, rp, hp, out, P, cols, rows, tile_x0, tile_y0, prev_e, prev_o, nb, nrows, ncols);
+    pyr_level<CFG, 3>(taps, rp, hp, out, P, cols, rows, tile_x0, tile_y0, prev_e, prev_o, nb, nrows, ncols);
+    pyr_level<CFG, 4>(taps, rp, hp, out, P, cols, rows, tile_x0, tile_y0, prev_e, prev_o, nb, nrows, ncols);
+    pyr_level<CFG, 5>(taps, rp, hp, out, P, cols, rows, tile_x0, tile_y0, prev_e, prev_o, nb, nrows, ncols);
 }
 
 // Host side: pack quantised taps into the operand shapes described at the top.

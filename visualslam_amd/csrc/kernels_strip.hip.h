@@ -144,7 +144,9 @@ __device__ __forceinline__ void h_item_level(const uint32_t* __restrict__ hrow, 
 template <int SH>
 __global__ __launch_bounds__(256) void k_gauss_h_strip(const uint16_t* __restrict__ h, size_t hframe,
                                                         uint8_t* __restrict__ oct_out, size_t pframe, int rows,
-                                                        int cols, int pw, const StripTaps* __restrict__ taps) {
+                                                        int cols, int pw, const StripTaps* __restrict__ taps,
+                                                        uint8_t* __restrict__ next_base, size_t nframe, int nrows,
+                                                        int ncols) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t* hp = smem;  // [SH][pw] u16 pairs; LDS column cx = x + PL
     const int tid = threadIdx.x;
@@ -209,6 +211,10 @@ __global__ __launch_bounds__(256) void k_gauss_h_strip(const uint16_t* __restric
                         const size_t off = (size_t)y * cols + x;
                         *reinterpret_cast<uint2*>(out + (size_t)l * P + off) = make_uint2(g[0], g[1]);
                         if (l > 0) *reinterpret_cast<uint2*>(out + (size_t)(VSLAM_NUM_LEVELS + l - 1) * P + off) = make_uint2(d[0], d[1]);
+                        // next octave's base = Gaussian[3] decimated 2:1 (GaussPyramid.cpp:123-126)
+                        if (l == 3 && next_base && (y & 1) == 0 && (y >> 1) < nrows && (x >> 1) < ncols)
+                            *reinterpret_cast<uint32_t*>(next_base + blockIdx.z * nframe + (size_t)(y >> 1) * ncols + (x >> 1)) =
+                                __builtin_amdgcn_perm(g[1], g[0], 0x06040200);
                     }
                 }
             }

@@ -244,7 +244,7 @@ static int get_strip_taps(vslam_ctx* c, double sigma0, int o, const OctPlan& pl,
 
 template <int SH>
 static int launch_h_strip(vslam_ctx* c, const uint16_t* h, size_t hframe, uint8_t* oct, size_t pframe, int rows, int cols,
-                          int pw, int nf, const StripTaps* taps) {
+                          int pw, int nf, const StripTaps* taps, uint8_t* next_base, size_t nframe, int nrows, int ncols) {
     const size_t lds = (size_t)SH * pw * 4;
     HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gauss_h_strip<SH>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -252,7 +252,7 @@ static int launch_h_strip(vslam_ctx* c, const uint16_t* h, size_t hframe, uint8_
     std::pair<hipEvent_t, hipEvent_t>* ev = timed ? timing_slot(c) : nullptr;
     if (ev) (void)hipEventRecord(ev->first, c->stream);
     hipLaunchKernelGGL(k_gauss_h_strip<SH>, dim3(1, (rows + SH - 1) / SH, nf), dim3(256), lds, c->stream, h, hframe, oct,
-                       pframe, rows, cols, pw, taps);
+                       pframe, rows, cols, pw, taps, next_base, nframe, nrows, ncols);
     if (ev) (void)hipEventRecord(ev->second, c->stream);
     HIPCHK(c, hipGetLastError());
     return VSLAM_OK;
@@ -260,7 +260,8 @@ static int launch_h_strip(vslam_ctx* c, const uint16_t* h, size_t hframe, uint8_
 
 // Coarse octave: vertical strips (dot4) into the u16 scratch, then horizontal strips (dot2).
 static int enqueue_strip_octave(vslam_ctx* c, double sigma0, int o, const OctPlan& pl, const uint8_t* base, size_t bframe,
-                                uint8_t* oct, size_t pframe, uint16_t* h, int rows, int cols, int nf) {
+                                uint8_t* oct, size_t pframe, uint16_t* h, int rows, int cols, int nf, uint8_t* next_base,
+                                size_t nframe, int nrows, int ncols) {
     const StripTaps* taps;
     TRY(get_strip_taps(c, sigma0, o, pl, &taps));
     int nmax = 0;
@@ -282,9 +283,9 @@ static int enqueue_strip_octave(vslam_ctx* c, double sigma0, int o, const OctPla
     }
     const int pw = (cols / 2 + nmax / 2 + 8 + 3) & ~3;
     switch (pl.sh) {
-        case 16: return launch_h_strip<16>(c, h, 6 * P, oct, pframe, rows, cols, pw, nf, taps);
-        case 8: return launch_h_strip<8>(c, h, 6 * P, oct, pframe, rows, cols, pw, nf, taps);
-        default: return launch_h_strip<4>(c, h, 6 * P, oct, pframe, rows, cols, pw, nf, taps);
+        case 16: return launch_h_strip<16>(c, h, 6 * P, oct, pframe, rows, cols, pw, nf, taps, next_base, nframe, nrows, ncols);
+        case 8: return launch_h_strip<8>(c, h, 6 * P, oct, pframe, rows, cols, pw, nf, taps, next_base, nframe, nrows, ncols);
+        default: return launch_h_strip<4>(c, h, 6 * P, oct, pframe, rows, cols, pw, nf, taps, next_base, nframe, nrows, ncols);
     }
 }
 
@@ -366,7 +367,8 @@ static int dog_scratch_take(vslam_ctx* c, const vslam_batch_layout& L, double si
 // Fused LDS-tiled octave (kernels_pyramid.hip.h); the plan has already matched CFG's widths.
 template <class CFG>
 static int enqueue_pyr_octave(vslam_ctx* c, double sigma0, int o, const OctPlan& pl, const uint8_t* base, size_t bframe,
-                              uint8_t* oct_out, size_t pframe, int rows, int cols, int nf) {
+                              uint8_t* oct_out, size_t pframe, int rows, int cols, int nf, uint8_t* next_base, size_t nframe,
+                              int nrows, int ncols) {
     uint64_t sb;
     std::memcpy(&sb, &sigma0, 8);
     auto key = std::make_pair(sb, o);
@@ -389,7 +391,7 @@ static int enqueue_pyr_octave(vslam_ctx* c, double sigma0, int o, const OctPlan&
     std::pair<hipEvent_t, hipEvent_t>* ev = timed ? timing_slot(c) : nullptr;
     if (ev) (void)hipEventRecord(ev->first, c->stream);
     hipLaunchKernelGGL(k_pyr_octave<CFG>, grid, dim3(256), CFG::LDS_BYTES, c->stream, base, bframe, oct_out, pframe, rows,
-                       cols, taps);
+                       cols, taps, next_base, nframe, nrows, ncols);
     if (ev) (void)hipEventRecord(ev->second, c->stream);
     HIPCHK(c, hipGetLastError());
     return VSLAM_OK;
@@ -417,12 +419,18 @@ static int enqueue_dog(vslam_ctx* c, const vslam_params& p, const vslam_batch_la
         const uint8_t* base = s.bases + s.base_off[o];
         uint8_t* oct = pyr + L.octave_offset[o];
         const OctPlan pl = plan_octave(p.sigma0, o, rows, cols);
+        // the fast octave kernels also emit the next octave's base (Gaussian[3] decimated 2:1)
+        const bool has_next = o + 1 < L.n_octaves;
+        const bool fuse_next = has_next && pl.path != OctPath::Generic && L.cols[o + 1] % 4 == 0 && s.base_off[o + 1] % 4 == 0 &&
+                               s.bases_frame % 4 == 0;
+        uint8_t* nb = fuse_next ? s.bases + s.base_off[o + 1] : nullptr;
+        const int nr = has_next ? L.rows[o + 1] : 0, nc = has_next ? L.cols[o + 1] : 0;
         if (pl.path == OctPath::Tile0)
-            TRY(enqueue_pyr_octave<PyrCfgOct0>(c, p.sigma0, o, pl, base, s.bases_frame, oct, pframe, rows, cols, nf));
+            TRY(enqueue_pyr_octave<PyrCfgOct0>(c, p.sigma0, o, pl, base, s.bases_frame, oct, pframe, rows, cols, nf, nb, s.bases_frame, nr, nc));
         else if (pl.path == OctPath::Tile1)
-            TRY(enqueue_pyr_octave<PyrCfgOct1>(c, p.sigma0, o, pl, base, s.bases_frame, oct, pframe, rows, cols, nf));
+            TRY(enqueue_pyr_octave<PyrCfgOct1>(c, p.sigma0, o, pl, base, s.bases_frame, oct, pframe, rows, cols, nf, nb, s.bases_frame, nr, nc));
         else if (pl.path == OctPath::Strip)
-            TRY(enqueue_strip_octave(c, p.sigma0, o, pl, base, s.bases_frame, oct, pframe, s.h, rows, cols, nf));
+            TRY(enqueue_strip_octave(c, p.sigma0, o, pl, base, s.bases_frame, oct, pframe, s.h, rows, cols, nf, nb, s.bases_frame, nr, nc));
         else {
             for (int l = 0; l < VSLAM_NUM_LEVELS; ++l)
                 TRY(enqueue_blur(c, base, (size_t)cols, s.bases_frame, oct + (size_t)l * P, (size_t)cols, pframe, s.h, rows,
@@ -430,7 +438,7 @@ static int enqueue_dog(vslam_ctx* c, const vslam_params& p, const vslam_batch_la
             LAUNCH(c, "k_dog5", k_dog5, dim3((unsigned)((P + 255) / 256), 1, nf), dim3(256), oct,
                    oct + (size_t)VSLAM_NUM_LEVELS * P, P, pframe);
         }
-        if (o + 1 < L.n_octaves) {
+        if (has_next && !fuse_next) {
             if (cols % 8 == 0 && (L.octave_offset[o] + 3 * P) % 8 == 0 && s.base_off[o + 1] % 4 == 0 && s.bases_frame % 4 == 0)
                 LAUNCH(c, "k_resize_nearest_half_v4", k_resize_nearest_half_v4,
                        dim3((L.cols[o + 1] / 4 + 255) / 256, L.rows[o + 1], nf), dim3(256), oct + (size_t)3 * P, pframe,
