@@ -165,6 +165,15 @@ int vslam_pyramid_get_base(const vslam_pyramid* pyr, int octave, uint8_t* dst, s
 int vslam_pyramid_get_gauss(const vslam_pyramid* pyr, int octave, int level, uint8_t* dst, size_t dst_step);
 int vslam_pyramid_get_dog(const vslam_pyramid* pyr, int octave, int level, uint8_t* dst, size_t dst_step);
 
+/* GaussPyramid::processGradients for one Gaussian level (GaussPyramid.cpp:65-104; getters
+ * octaveGradX / octaveGradY / octaveGradMag / octaveGradOrient, GaussPyramid.hpp:33-36):
+ * Sobel x, Sobel y (ksize 1), cv::magnitude, cv::phase in degrees (OpenCV's fastAtan2
+ * polynomial, ~0.01 deg from atan2).  Computed on demand from the HBM-resident Gaussian
+ * (the reference materialises all 96 bytes per pyramid pixel in its constructor).  Any of the
+ * four CV_32F destinations may be NULL; dst_step in bytes. */
+int vslam_pyramid_get_gradients(const vslam_pyramid* pyr, int octave, int level, float* grad_x, float* grad_y,
+                                float* mag, float* orient, size_t dst_step);
+
 /* void initialKeypointDetection(vector<SLAM::point>&, GaussPyramid&, int octave, int
  * windowSize), Diff_of_Gauss.cpp:254-297, up to the FeaturePointLocalization call.
  * Literal stride-`window` lattice and half-open window (Appendix B-7), padded

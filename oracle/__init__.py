@@ -93,6 +93,9 @@ def lib():
         L.vo_pyramid_build_u8.restype = C.POINTER(_Pyr)
         L.vo_pyramid_free.argtypes = [C.POINTER(_Pyr)]
         L.vo_pyramid_free.restype = None
+        L.vo_fast_atan2_deg.argtypes = [C.c_float, C.c_float]
+        L.vo_fast_atan2_deg.restype = C.c_float
+        L.vo_level_gradients.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
         L.vo_extrema_lattice.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.vo_extrema_lattice.restype = None
         L.vo_dog_extrema.argtypes = [C.POINTER(_Pyr), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
@@ -216,6 +219,18 @@ def harris_keypoints(nms2_map) -> np.ndarray:
     if n:
         lib().vo_harris_keypoints(m.ctypes.data, *m.shape, m.strides[0], out.ctypes.data, n)
     return out
+
+
+def fast_atan2_deg(y: float, x: float) -> float:
+    return lib().vo_fast_atan2_deg(float(y), float(x))
+
+
+def level_gradients(g):
+    """(gx, gy, mag, orient) f32 images of one Gaussian level (processGradients)."""
+    g = _u8(g)
+    outs = [np.empty(g.shape, np.float32) for _ in range(4)]
+    _chk(lib().vo_level_gradients(g.ctypes.data, *g.shape, g.strides[0], *[o.ctypes.data for o in outs], outs[0].strides[0]), "level_gradients")
+    return tuple(outs)
 
 
 def auto_num_octaves(rows: int, cols: int) -> int:

@@ -476,6 +476,48 @@ vo_pyramid* vo_pyramid_build_u8(const uint8_t* img, int rows, int cols, size_t s
     return p;
 }
 
+/* cv::fastAtan2 / hal::fastAtan32f scalar form (OpenCV 4.x mathfuncs_core.simd.hpp). */
+float vo_fast_atan2_deg(float y, float x) {
+    const float scale = (float)(180.0 / 3.14159265358979323846);
+    const float p1 = 0.9997878412794807f * scale, p3 = -0.3258083974640975f * scale;
+    const float p5 = 0.1555786518463281f * scale, p7 = -0.04432655554792128f * scale;
+    const float eps = (float)DBL_EPSILON;
+    float ax = fabsf(x), ay = fabsf(y), a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + eps);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + eps);
+        c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+int vo_level_gradients(const uint8_t* g, int rows, int cols, size_t step, float* gx, float* gy, float* mag,
+                       float* orient, size_t out_step_bytes) {
+    if (!g || rows <= 0 || cols <= 0) return -1;
+    for (int r = 0; r < rows; r++)
+        for (int c = 0; c < cols; c++) {
+            const float x = (float)((int)g[(size_t)r * step + vo_reflect101(c + 1, cols)] -
+                                    (int)g[(size_t)r * step + vo_reflect101(c - 1, cols)]);
+            const float y = (float)((int)g[(size_t)vo_reflect101(r + 1, rows) * step + c] -
+                                    (int)g[(size_t)vo_reflect101(r - 1, rows) * step + c]);
+            const size_t o = (size_t)r * out_step_bytes / sizeof(float) + c;
+            if (gx) gx[o] = x;
+            if (gy) gy[o] = y;
+            if (mag) {
+                const float xx = x * x, yy = y * y;
+                mag[o] = sqrtf(xx + yy);
+            }
+            if (orient) orient[o] = vo_fast_atan2_deg(y, x);
+        }
+    return 0;
+}
+
 void vo_extrema_lattice(int rows, int cols, int window, int* lat_rows, int* lat_cols) {
     int pad = (window - 1) / 2;
     *lat_rows = rows > pad ? (rows - pad + window - 1) / window : 0;

@@ -125,6 +125,15 @@ vo_pyramid* vo_pyramid_build_u8(const uint8_t* img, int rows, int cols, size_t s
                                 double sigma0);
 void vo_pyramid_free(vo_pyramid* p);
 
+/* processGradients, GaussPyramid.cpp:65-104, for ONE Gaussian image: Sobel x / y (ksize 1,
+ * :87,:90), cv::magnitude (:93) = sqrt(x*x + y*y) in f32, cv::phase(..., true) (:96) = OpenCV's
+ * fastAtan2 polynomial in degrees (restated from memory of mathfuncs_core: |error| <= 0.3 deg vs
+ * atan2; parity with a real OpenCV build is unpinned).  Any output pointer may be NULL.
+ * Steps are in bytes. */
+float vo_fast_atan2_deg(float y, float x);
+int vo_level_gradients(const uint8_t* g, int rows, int cols, size_t step, float* gx, float* gy, float* mag,
+                       float* orient, size_t out_step_bytes);
+
 /* Lattice geometry of initialKeypointDetection, Diff_of_Gauss.cpp:267-268:
  * sites i = pad, pad+ws, ... < rows. */
 void vo_extrema_lattice(int rows, int cols, int window, int* lat_rows, int* lat_cols);

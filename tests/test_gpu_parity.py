@@ -239,3 +239,22 @@ def test_golden_fixtures(ctx, name):
         assert same(np.stack([p.dog(o, l) for l in range(5)]), g[f"dog_{o}"])
         m, pts, cnt = p.extrema(o, 3, 8)
         assert same(m, g[f"ext_mask_{o}"]) and cnt == len(g[f"ext_pts_{o}"]) and same(pts, g[f"ext_pts_{o}"])
+
+
+@pytest.mark.parametrize("shape,n_oct", [((40, 56), 2), ((33, 47), 2), ((1, 5), 1)])
+def test_process_gradients(ctx, shape, n_oct):
+    # Sobel x/y exact, magnitude and fastAtan2 orientation bit-exact
+    # against the oracle's restatement (stated tolerance if ever relaxed: 1e-4 deg / 1 ulp)
+    img = frame(shape, "checker", 5)
+    want = oracle.Pyramid(img, n_oct, 1.6)
+    got = ctx.pyramid(img, n_oct, 1.6)
+    for o in range(n_oct):
+        for l in (0, 3, 5):
+            w = oracle.level_gradients(want.gauss(o, l))
+            g4 = got.gradients(o, l)
+            for a, b, name in zip(g4, w, ("gx", "gy", "mag", "orient")):
+                assert same(a, b), (name, o, l, float(np.abs(a - b).max()), int((a != b).sum()))
+            assert g4[3].min() >= 0.0 and g4[3].max() < 360.0
+    with pytest.raises(capi.VslamError):
+        got.gradients(0, 6)
+    got.close()

@@ -253,3 +253,28 @@ def test_synth_generators_agree():
     b = synth.frames_torch(2, 40, 72, stream_id=3, first_frame=5).numpy()
     assert (a == b).all()
     assert a.min() >= 40 and a.max() <= 215 and abs(int(a[0, 0, 0]) - 56) <= 16
+
+
+def test_process_gradients_oracle():
+    import math
+
+    # fastAtan2 polynomial: quadrants, axes and accuracy (OpenCV documents ~0.3 deg; the polynomial
+    # used here stays within 0.01 deg on integer gradients)
+    assert oracle.fast_atan2_deg(0, 0) == 0.0
+    assert oracle.fast_atan2_deg(1, 0) == 90.0 and oracle.fast_atan2_deg(-1, 0) == 270.0 and oracle.fast_atan2_deg(0, -1) == 180.0
+    worst = 0.0
+    for y in range(-255, 256, 17):
+        for x in range(-255, 256, 13):
+            if x == 0 and y == 0:
+                continue
+            d = abs(oracle.fast_atan2_deg(y, x) - math.degrees(math.atan2(y, x)) % 360)
+            worst = max(worst, min(d, 360 - d))
+    assert worst < 0.02
+    g = synth.frame_np(19, 27, kind="noise")
+    gx, gy, mag, orient = oracle.level_gradients(g)
+    assert (gx == oracle.sobel_k1(g, 1, 0)).all() and (gy == oracle.sobel_k1(g, 0, 1)).all()
+    assert (mag == np.sqrt(gx * gx + gy * gy, dtype=np.float32)).all()
+    three_four = np.zeros((3, 3), np.uint8)
+    three_four[1, 2], three_four[2, 1] = 3, 4  # centre pixel: gx = 3, gy = 4 -> magnitude 5
+    _, _, m, o = oracle.level_gradients(three_four)
+    assert m[1, 1] == 5.0 and abs(o[1, 1] - math.degrees(math.atan2(4, 3))) < 0.02

@@ -99,6 +99,7 @@ SIGNATURES = {
     "vslam_pyramid_get_base": (_I, [_P, _I, _P, _Z]),
     "vslam_pyramid_get_gauss": (_I, [_P, _I, _I, _P, _Z]),
     "vslam_pyramid_get_dog": (_I, [_P, _I, _I, _P, _Z]),
+    "vslam_pyramid_get_gradients": (_I, [_P, _I, _I, _P, _P, _P, _P, _Z]),
     "vslam_dog_extrema": (_I, [_P, _P, _I, _I, _I, _P, _P, _Z, C.POINTER(_Z)]),
     "vslam_params_default": (None, [C.POINTER(Params), _I, _I]),
     "vslam_batch_layout_query": (_I, [C.POINTER(Params), C.POINTER(BatchLayout)]),
@@ -378,6 +379,13 @@ class Pyramid:
 
     def dog(self, o, l):
         return self._get(lib().vslam_pyramid_get_dog, "vslam_pyramid_get_dog", o, l)
+
+    def gradients(self, o, l):
+        """(grad_x, grad_y, magnitude, orientation[deg]) of Gaussian level (o, l), computed on demand."""
+        shape = self.sizes[o] if 0 <= o < self.n_octaves else (1, 1)
+        outs = [np.empty(shape, np.float32) for _ in range(4)]
+        self.ctx._chk(lib().vslam_pyramid_get_gradients(self._h, o, l, *[a.ctypes.data for a in outs], outs[0].strides[0]), "vslam_pyramid_get_gradients")
+        return tuple(outs)
 
     def extrema(self, octave: int, window: int = 3, min_contrast: int = 8, cap: int = 1 << 22):
         """(mask[3, lat_rows, lat_cols] u8 unpacked from the bitmask, points, total count)."""

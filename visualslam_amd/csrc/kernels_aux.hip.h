@@ -206,4 +206,50 @@ __global__ __launch_bounds__(256) void k_extrema_w3(const uint8_t* __restrict__ 
     }
 }
 
+
+// ---- processGradients for one Gaussian level (GaussPyramid.cpp:65-104) ----
+// Sobel x / y with ksize 1 (reflect-101), cv::magnitude and cv::phase(..., angleInDegrees=true)
+// = OpenCV's fastAtan2 polynomial.  Materialised on demand (96 bytes per pyramid pixel if all
+// levels were kept); any output pointer may be null.  One thread per pixel; every f32 operation
+// is individually rounded (-ffp-contract=off) so the result equals the oracle's bit for bit.
+__device__ __forceinline__ float fast_atan2_deg(float y, float x) {
+    const float scale = (float)(180.0 / 3.14159265358979323846);
+    const float p1 = 0.9997878412794807f * scale, p3 = -0.3258083974640975f * scale;
+    const float p5 = 0.1555786518463281f * scale, p7 = -0.04432655554792128f * scale;
+    const float eps = (float)2.2204460492503131e-16;
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a;
+    if (ax >= ay) {
+        const float c = ay / (ax + eps), c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        const float c = ax / (ay + eps), c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+__global__ __launch_bounds__(256) void k_level_gradients(const uint8_t* __restrict__ g, int rows, int cols,
+                                                          float* __restrict__ gx, float* __restrict__ gy,
+                                                          float* __restrict__ mag, float* __restrict__ orient) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int r = blockIdx.y;
+    if (c >= cols) return;
+    const uint8_t* row = g + (size_t)r * cols;
+    const float x = (float)((int)row[reflect101(c + 1, cols)] - (int)row[reflect101(c - 1, cols)]);
+    const float y = (float)((int)g[(size_t)reflect101(r + 1, rows) * cols + c] - (int)g[(size_t)reflect101(r - 1, rows) * cols + c]);
+    const size_t o = (size_t)r * cols + c;
+    if (gx) gx[o] = x;
+    if (gy) gy[o] = y;
+    if (mag) {
+        const float xx = x * x, yy = y * y;
+        // IEEE-correct f32 square root: sqrt in f64 then one rounding (53 >= 2*24 + 2 bits), because
+        // the f32 hardware sqrt is not correctly rounded
+        mag[o] = (float)sqrt((double)(xx + yy));
+    }
+    if (orient) orient[o] = fast_atan2_deg(y, x);
+}
+
 }  // namespace vslam

@@ -80,7 +80,7 @@ static const char* const kKernelNames =
     "k_harris_fused\nk_harris_post\nk_compact_harris\nk_resize_linear2x\nk_blur_h_generic\nk_blur_v_generic\n"
     "k_dog5\nk_resize_nearest_half\nk_extrema\nk_compact_dog\nk_pyr_octave\n"
     "k_gauss_v_strip\nk_gauss_h_strip\nk_resize_linear2x_v8\nk_resize_linear2x_slide\nk_resize_nearest_half_v4\nk_extrema_w3\n"
-    "k_harris_strip\nk_compact_harris_strip";
+    "k_harris_strip\nk_compact_harris_strip\nk_level_gradients";
 
 // Launch on the context stream; bracket with events when the bench hook names this kernel.
 #define LAUNCH(ctx, name, kern, grid, block, ...)                                                \
@@ -927,6 +927,31 @@ int vslam_pyramid_get_dog(const vslam_pyramid* py, int octave, int level, uint8_
     return pyramid_fetch(py, octave,
                          py->d_block + py->layout.octave_offset[octave] + (size_t)(VSLAM_NUM_LEVELS + level) * P, dst,
                          dst_step);
+}
+
+int vslam_pyramid_get_gradients(const vslam_pyramid* py, int octave, int level, float* grad_x, float* grad_y, float* mag,
+                                float* orient, size_t dst_step) {
+    if (!py) return VSLAM_ERR_INVALID;
+    vslam_ctx* c = py->ctx;
+    TRY(bind_device(c));
+    if (octave < 0 || octave >= py->layout.n_octaves || level < 0 || level >= VSLAM_NUM_LEVELS)
+        return fail(c, VSLAM_ERR_RANGE, "octave/level out of range");
+    const int rows = py->layout.rows[octave], cols = py->layout.cols[octave];
+    ARGCHK(c, dst_step >= 4 * (size_t)cols, "pyramid gradients: bad destination step");
+    float* host[4] = {grad_x, grad_y, mag, orient};
+    const size_t P = (size_t)rows * cols;
+    TRY(ws_reserve(c, 4 * ws_need(4 * P)));
+    float* dev[4];
+    for (int i = 0; i < 4; ++i) {
+        float* d = ws_take<float>(c, P);
+        dev[i] = host[i] ? d : nullptr;
+    }
+    const uint8_t* g = py->d_block + py->layout.octave_offset[octave] + (size_t)level * P;
+    LAUNCH(c, "k_level_gradients", k_level_gradients, grid_rows(cols, rows), dim3(256), g, rows, cols, dev[0], dev[1], dev[2],
+           dev[3]);
+    for (int i = 0; i < 4; ++i)
+        if (host[i]) TRY(d2h(c, host[i], dst_step, dev[i], 4 * (size_t)cols, 4 * (size_t)cols, rows));
+    return vslam_ctx_sync(c);
 }
 
 int vslam_dog_extrema(vslam_ctx* c, const vslam_pyramid* py, int octave, int window, int min_contrast, uint64_t* bits,

@@ -45,6 +45,15 @@ int main() {
                 bad += d[2].at<uchar>(r, c) != (diff > 0 ? diff : 0);
             }
         EXPECT(bad == 0);
+        // gradient images exist for octave 1 level 0, CV_32F, 868x600 (tests/GaussPyramid_Test.cpp:114-117)
+        for (const Mat* m : {&pyramid.octaveGradX(1)[0], &pyramid.octaveGradY(1)[0], &pyramid.octaveGradMag(1)[0], &pyramid.octaveGradOrient(1)[0]})
+            EXPECT(m->type() == CV_32F && m->cols == 868 && m->rows == 600);
+        {
+            const Mat& gx = pyramid.octaveGradX(1)[0];
+            const Mat& b = pyramid.octaveBlur(1)[0];
+            EXPECT(gx.at<float>(10, 10) == (float)((int)b.at<uchar>(10, 11) - (int)b.at<uchar>(10, 9)));
+            EXPECT(gx.at<float>(10, 0) == 0.0f);  // reflect-101
+        }
         GaussPyramid autop{img, 1.6};  // second constructor: floor(log2(600)) - 4 = 5 octaves
         EXPECT(autop.getNumOctaves() == 5);
         std::vector<Mat> padded = GaussPyramid::padOctave(1, d);

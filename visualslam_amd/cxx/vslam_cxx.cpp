@@ -192,6 +192,24 @@ const std::vector<Mat>& GaussPyramid::octaveDiff(int octave) {
     return it->second;
 }
 
+const std::vector<Mat>& GaussPyramid::grads(int octave, int kind) {
+    checkOctave(octave);
+    auto it = grad_[kind].find(octave);
+    if (it == grad_[kind].end()) {  // one kernel per level fills all four kinds of the octave
+        std::vector<Mat> v[4];
+        for (int l = 0; l < info_.n_levels; ++l) {
+            Mat m[4];
+            for (auto& q : m) q.create(info_.rows[octave], info_.cols[octave], cv::CV_32F);
+            check(vslam_pyramid_get_gradients(pyr_, octave, l, m[0].ptr<float>(), m[1].ptr<float>(), m[2].ptr<float>(), m[3].ptr<float>(), m[0].step),
+                  default_context(), "processGradients");
+            for (int q = 0; q < 4; ++q) v[q].push_back(m[q]);
+        }
+        for (int q = 0; q < 4; ++q) grad_[q].emplace(octave, std::move(v[q]));
+        it = grad_[kind].find(octave);
+    }
+    return it->second;
+}
+
 const std::vector<Mat>& GaussPyramid::imagePyramid() {
     if (img_pyramid_.empty())
         for (int o = 0; o < info_.n_octaves; ++o) {

@@ -13,8 +13,8 @@
 // plus the OpenCV calls on the path (vslamcv::GaussianBlur / Sobel / convertScaleAbs / resize).
 // StructureMatrix (:10) is a per-pixel helper used only inside HarrisCorner and is subsumed by
 // it.  Errors of the C ABI surface as vslam::Error (the reference relies on cv::Exception).
-// The per-level gradient getters (octaveGradX ...) belong to processGradients, a "next" row of
-// SURVEY.md section 8f, and are not provided yet.
+// The per-level gradient getters (octaveGradX/Y/Mag/Orient, processGradients, SURVEY.md section 8f
+// row 1) are computed on the GPU on first access instead of in the constructor.
 #pragma once
 #include <map>
 #include <stdexcept>
@@ -79,6 +79,11 @@ public:
     const std::vector<double>& octaveSigma(int octave);
     const std::vector<cv::Mat>& octaveBlur(int octave);
     const std::vector<cv::Mat>& octaveDiff(int octave);
+    // processGradients results (GaussPyramid.hpp:33-36), computed on the GPU on first access
+    const std::vector<cv::Mat>& octaveGradX(int octave) { return grads(octave, 0); }
+    const std::vector<cv::Mat>& octaveGradY(int octave) { return grads(octave, 1); }
+    const std::vector<cv::Mat>& octaveGradMag(int octave) { return grads(octave, 2); }
+    const std::vector<cv::Mat>& octaveGradOrient(int octave) { return grads(octave, 3); }
     const std::vector<cv::Mat>& imagePyramid();
     const std::map<int, std::vector<cv::Mat>>& pyramidGauss();
     const std::map<int, std::vector<cv::Mat>>& pyramidDiff();
@@ -93,7 +98,8 @@ private:
     // host copies are fetched lazily, one octave at a time (the stacks stay in HBM)
     std::vector<cv::Mat> img_pyramid_;
     std::map<int, std::vector<double>> sigmas_;
-    std::map<int, std::vector<cv::Mat>> gauss_, diff_;
+    std::map<int, std::vector<cv::Mat>> gauss_, diff_, grad_[4];
+    const std::vector<cv::Mat>& grads(int octave, int kind);
 };
 
 // Appends the scale-space extrema candidates of one octave in the reference's loop order.
