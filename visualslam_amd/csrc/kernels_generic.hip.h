@@ -382,10 +382,12 @@ __global__ __launch_bounds__(1024) void k_compact_harris(const unsigned long lon
 __global__ __launch_bounds__(1024) void k_compact_dog(const unsigned long long* __restrict__ lflags, size_t bframe,
                                                        const uint8_t* __restrict__ pyr, size_t pframe, ExtGeom g,
                                                        int o_begin, int o_end, vslam_point* __restrict__ out,
-                                                       unsigned int cap, unsigned int* __restrict__ counts) {
+                                                       unsigned int cap, unsigned int* __restrict__ counts, int append) {
     __shared__ unsigned int wsum[16];
     const int f = blockIdx.x;
-    unsigned int running = 0;
+    // append: continue the frame's list where the previous launch (lower octaves) stopped, so the
+    // octaves can be compacted one by one while later octaves are still being computed
+    unsigned int running = append ? counts[f] : 0;
     for (int o = o_begin; o < o_end; ++o) {
         const unsigned long long* F = lflags + f * bframe + g.bits_off[o];
         const int wpr = g.wpr[o], lr = g.lat_rows[o];

@@ -463,11 +463,13 @@ static int enqueue_dog(vslam_ctx* c, const vslam_params& p, const vslam_batch_la
                                    pframe, g, o, bits, s.lflags, L.bits_frame_words);
             HIPCHK(c, hipGetLastError());
         }
-    }
-    if (do_extrema && points && counts) {
-        StreamSwap sw(c, side ? side : c->stream);
-        LAUNCH(c, "k_compact_dog", k_compact_dog, dim3(nf), dim3(1024), s.lflags, L.bits_frame_words, pyr, pframe, g, 0,
-               L.n_octaves, points, p.dog_cap, counts);
+        // compact this octave's points right away (appending to the frame's list): on the side
+        // stream it overlaps the next octave's kernels instead of forming a serial tail
+        if (do_extrema && points && counts) {
+            StreamSwap sw(c, side ? side : c->stream);
+            LAUNCH(c, "k_compact_dog", k_compact_dog, dim3(nf), dim3(1024), s.lflags, L.bits_frame_words, pyr, pframe, g, o,
+                   o + 1, points, p.dog_cap, counts, o > 0 ? 1 : 0);
+        }
     }
     return VSLAM_OK;
 }
@@ -980,7 +982,7 @@ int vslam_dog_extrema(vslam_ctx* c, const vslam_pyramid* py, int octave, int win
         LAUNCH(c, "k_extrema", k_extrema, dim3((L.lat_cols[octave] + 255) / 256, L.lat_rows[octave], 3), dim3(256),
                py->d_block, L.pyramid_frame_bytes, g, octave, d_bits, d_lf, words);
         LAUNCH(c, "k_compact_dog", k_compact_dog, dim3(1), dim3(1024), d_lf, words, py->d_block, L.pyramid_frame_bytes, g,
-               octave, octave + 1, d_pts, p.dog_cap, d_n);
+               octave, octave + 1, d_pts, p.dog_cap, d_n, 0);
     }
     unsigned int n = 0;
     HIPCHK(c, hipMemcpyAsync(&n, d_n, 4, hipMemcpyDeviceToHost, c->stream));
