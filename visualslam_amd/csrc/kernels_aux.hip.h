@@ -10,54 +10,15 @@
 namespace vslam {
 
 // ---- K-D0: cv::resize(img, Size(), 2, 2, INTER_LINEAR) on CV_8U (GaussPyramid.cpp:110) ----
-// One thread = 8 consecutive destination pixels of one row.  Clamped source reads reproduce
-// OpenCV's border rule exactly because the two 11-bit weights always sum to 2048.
-// Requires cols % 4 == 0 (dst row pitch 2*cols is then a multiple of 8).
-__global__ __launch_bounds__(256) void k_resize_linear2x_v8(const uint8_t* __restrict__ src, size_t sframe,
-                                                             uint8_t* __restrict__ dst, size_t dframe, int rows,
-                                                             int cols) {
-    const int k = blockIdx.x * 256 + threadIdx.x;  // group of 8 dst px = 4 src px
-    const int dy = blockIdx.y;
-    if (4 * k >= cols) return;
-    const int sy = (dy >> 1) - 1 + (dy & 1);
-    const int b1 = (dy & 1) ? 512 : 1536, b0 = 2048 - b1;
-    const uint8_t* r0 = src + blockIdx.z * sframe + (size_t)clampi(sy, 0, rows - 1) * cols;
-    const uint8_t* r1 = src + blockIdx.z * sframe + (size_t)clampi(sy + 1, 0, rows - 1) * cols;
-    // source pixels 4k-1 .. 4k+4 of both rows
-    int s0[6], s1[6];
-    const uint32_t w0 = *reinterpret_cast<const uint32_t*>(r0 + 4 * k), w1 = *reinterpret_cast<const uint32_t*>(r1 + 4 * k);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        s0[i + 1] = (w0 >> (8 * i)) & 255;
-        s1[i + 1] = (w1 >> (8 * i)) & 255;
-    }
-    const int xl = max(4 * k - 1, 0), xr = min(4 * k + 4, cols - 1);
-    s0[0] = r0[xl], s0[5] = r0[xr], s1[0] = r1[xl], s1[5] = r1[xr];
-    uint32_t o[2] = {0, 0};
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        // dx = 8k + j: source pair (i, i+1) with i = (j>>1) - 1 + (j&1) relative to 4k, i.e. s[i+1], s[i+2]
-        const int i = (j >> 1) + (j & 1);  // index into s[] of the first sample
-        const int a1 = (j & 1) ? 512 : 1536, a0 = 2048 - a1;
-        const int h0 = s0[i] * a0 + s0[i + 1] * a1;
-        const int h1 = s1[i] * a0 + s1[i + 1] * a1;
-        const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
-        o[j >> 2] |= (uint32_t)min(v, 255) << (8 * (j & 3));
-    }
-    *reinterpret_cast<uint2*>(dst + blockIdx.z * dframe + (size_t)dy * (2 * cols) + 8 * k) = make_uint2(o[0], o[1]);
-}
-
-
-// ---- K-D0 (sliding form): the same operator, 3.4 instead of 17 VALU instructions per pixel ----
-// A thread owns 4 source columns (= 8 destination columns) and walks down a segment of source
+// Sliding form, ~3.4 VALU instructions per pixel.  A thread owns 4 source columns (= 8 destination columns) and walks down a segment of source
 // rows; per source row the horizontal pass is done ONCE in 16-bit lanes and reused by the four
 // destination rows it feeds.  With s = source pixels, the 11-bit fixed-point steps collapse to
 //   A = s_i + 3 s_{i+1}  (or 3 s_i + s_{i+1})            h = 512 A,  h >> 4 = 32 A
 //   (512*32A) >> 16 = A >> 2,   (1536*32A) >> 16 = (3A) >> 2
 //   dst(2m)   = ((A(m-1) >> 2) + ((3 A(m)) >> 2) + 2) >> 2
 //   dst(2m+1) = (((3 A(m)) >> 2) + (A(m+1) >> 2) + 2) >> 2
-// which is bit-identical to the literal formula of k_resize_linear2x_v8 (clamped reads at the
-// borders).  Requires cols % 4 == 0.  grid = (ceil(cols/4/256), ceil(rows/seg), frames).
+// which is bit-identical to the literal formula (k_resize_linear2x in kernels_generic.hip.h;
+// clamped reads at the borders reproduce OpenCV's border rule because the weights sum to 2048).  Requires cols % 4 == 0.  grid = (ceil(cols/4/256), ceil(rows/seg), frames).
 typedef unsigned short us2r_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pk_lshr_u16(uint32_t a, int sh) {
     return __builtin_bit_cast(uint32_t, (us2r_t)(__builtin_bit_cast(us2r_t, a) >> (unsigned short)sh));

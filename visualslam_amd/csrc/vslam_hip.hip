@@ -79,7 +79,7 @@ static int fail(vslam_ctx* c, int code, const std::string& msg) {
 static const char* const kKernelNames =
     "k_harris_fused\nk_harris_post\nk_compact_harris\nk_resize_linear2x\nk_blur_h_generic\nk_blur_v_generic\n"
     "k_dog5\nk_resize_nearest_half\nk_extrema\nk_compact_dog\nk_pyr_octave\n"
-    "k_gauss_v_strip\nk_gauss_h_strip\nk_resize_linear2x_v8\nk_resize_linear2x_slide\nk_resize_nearest_half_v4\nk_extrema_w3\n"
+    "k_gauss_v_strip\nk_gauss_h_strip\nk_resize_linear2x_slide\nk_resize_nearest_half_v4\nk_extrema_w3\n"
     "k_harris_strip\nk_compact_harris_strip\nk_level_gradients";
 
 // Launch on the context stream; bracket with events when the bench hook names this kernel.
