@@ -152,6 +152,11 @@ def main():
     if args.gpus != world and rank == 0:
         print(f"note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
 
+    # one rank per node compiles (a no-op when the in-tree .so is current); the others wait
+    if local_rank == 0:
+        capi.build()
+    if use_dist:
+        dist.barrier()
     capi.build()
     rows, cols, n = args.rows, args.cols, args.frames
     ctx = capi.Context(local_rank, torch.cuda.current_stream().cuda_stream)
