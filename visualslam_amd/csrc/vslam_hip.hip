@@ -82,15 +82,30 @@ static const char* const kKernelNames =
     "k_gauss_v_strip\nk_gauss_h_strip\nk_resize_linear2x_slide\nk_resize_nearest_half_v4\nk_extrema_w3\n"
     "k_harris_strip\nk_compact_harris_strip\nk_level_gradients";
 
-// Launch on the context stream; bracket with events when the bench hook names this kernel.
-#define LAUNCH(ctx, name, kern, grid, block, ...)                                                \
-    do {                                                                                         \
-        const bool timed_ = !(ctx)->timing_name.empty() && (ctx)->timing_name == (name);        \
-        std::pair<hipEvent_t, hipEvent_t>* ev_ = timed_ ? timing_slot(ctx) : nullptr;           \
-        if (ev_) (void)hipEventRecord(ev_->first, (ctx)->stream);                                \
-        hipLaunchKernelGGL(kern, grid, block, 0, (ctx)->stream, __VA_ARGS__);                    \
-        if (ev_) (void)hipEventRecord(ev_->second, (ctx)->stream);                               \
-        HIPCHK(ctx, hipGetLastError());                                                          \
+static std::pair<hipEvent_t, hipEvent_t>* timing_slot(vslam_ctx* c);
+
+// Brackets the launches made inside its scope with HIP events on the context stream when the
+// bench hook (vslam_kernel_timing_enable) names this kernel.
+struct TimedScope {
+    vslam_ctx* c;
+    std::pair<hipEvent_t, hipEvent_t>* ev;
+    TimedScope(vslam_ctx* ctx, const char* name)
+        : c(ctx), ev(!ctx->timing_name.empty() && ctx->timing_name == name ? timing_slot(ctx) : nullptr) {
+        if (ev) (void)hipEventRecord(ev->first, c->stream);
+    }
+    ~TimedScope() {
+        if (ev) (void)hipEventRecord(ev->second, c->stream);
+    }
+};
+
+// Launch on the context stream (no dynamic LDS).
+#define LAUNCH(ctx, name, kern, grid, block, ...)                                 \
+    do {                                                                          \
+        {                                                                         \
+            TimedScope ts_(ctx, name);                                            \
+            hipLaunchKernelGGL(kern, grid, block, 0, (ctx)->stream, __VA_ARGS__); \
+        }                                                                         \
+        HIPCHK(ctx, hipGetLastError());                                           \
     } while (0)
 
 static std::pair<hipEvent_t, hipEvent_t>* timing_slot(vslam_ctx* c) {
@@ -248,12 +263,11 @@ static int launch_h_strip(vslam_ctx* c, const uint16_t* h, size_t hframe, uint8_
     const size_t lds = (size_t)SH * pw * 4;
     HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gauss_h_strip<SH>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const bool timed = c->timing_name == "k_gauss_h_strip";
-    std::pair<hipEvent_t, hipEvent_t>* ev = timed ? timing_slot(c) : nullptr;
-    if (ev) (void)hipEventRecord(ev->first, c->stream);
-    hipLaunchKernelGGL(k_gauss_h_strip<SH>, dim3(1, (rows + SH - 1) / SH, nf), dim3(256), lds, c->stream, h, hframe, oct,
-                       pframe, rows, cols, pw, taps, next_base, nframe, nrows, ncols);
-    if (ev) (void)hipEventRecord(ev->second, c->stream);
+    {
+        TimedScope ts(c, "k_gauss_h_strip");
+        hipLaunchKernelGGL(k_gauss_h_strip<SH>, dim3(1, (rows + SH - 1) / SH, nf), dim3(256), lds, c->stream, h, hframe, oct,
+                           pframe, rows, cols, pw, taps, next_base, nframe, nrows, ncols);
+    }
     HIPCHK(c, hipGetLastError());
     return VSLAM_OK;
 }
@@ -273,14 +287,11 @@ static int enqueue_strip_octave(vslam_ctx* c, double sigma0, int o, const OctPla
     HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gauss_v_strip),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)v_lds));
     {
-        const bool timed = c->timing_name == "k_gauss_v_strip";
-        std::pair<hipEvent_t, hipEvent_t>* ev = timed ? timing_slot(c) : nullptr;
-        if (ev) (void)hipEventRecord(ev->first, c->stream);
+        TimedScope ts(c, "k_gauss_v_strip");
         hipLaunchKernelGGL(k_gauss_v_strip, dim3((cols + STRIP_W - 1) / STRIP_W, 1, nf), dim3(256), v_lds, c->stream, base,
                            bframe, h, 6 * P, rows, cols, RM, rhq, taps);
-        if (ev) (void)hipEventRecord(ev->second, c->stream);
-        HIPCHK(c, hipGetLastError());
     }
+    HIPCHK(c, hipGetLastError());
     const int pw = (cols / 2 + nmax / 2 + 8 + 3) & ~3;
     switch (pl.sh) {
         case 16: return launch_h_strip<16>(c, h, 6 * P, oct, pframe, rows, cols, pw, nf, taps, next_base, nframe, nrows, ncols);
@@ -387,12 +398,11 @@ static int enqueue_pyr_octave(vslam_ctx* c, double sigma0, int o, const OctPlan&
     }
     const PyrTaps<CFG>* taps = static_cast<const PyrTaps<CFG>*>(it->second);
     const dim3 grid((cols + CFG::TW - 1) / CFG::TW, (rows + CFG::TH - 1) / CFG::TH, nf);
-    const bool timed = c->timing_name == "k_pyr_octave";
-    std::pair<hipEvent_t, hipEvent_t>* ev = timed ? timing_slot(c) : nullptr;
-    if (ev) (void)hipEventRecord(ev->first, c->stream);
-    hipLaunchKernelGGL(k_pyr_octave<CFG>, grid, dim3(256), CFG::LDS_BYTES, c->stream, base, bframe, oct_out, pframe, rows,
-                       cols, taps, next_base, nframe, nrows, ncols);
-    if (ev) (void)hipEventRecord(ev->second, c->stream);
+    {
+        TimedScope ts(c, "k_pyr_octave");
+        hipLaunchKernelGGL(k_pyr_octave<CFG>, grid, dim3(256), CFG::LDS_BYTES, c->stream, base, bframe, oct_out, pframe, rows,
+                           cols, taps, next_base, nframe, nrows, ncols);
+    }
     HIPCHK(c, hipGetLastError());
     return VSLAM_OK;
 }
