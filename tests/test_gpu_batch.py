@@ -192,3 +192,17 @@ def test_batch_tiny_frames(env, shape, n_oct):
     p, L, out = run_batch(ctx, torch, frames, n_octaves=n_oct)
     for f in range(3):
         check_frame(p, L, out, f, frames[f], n_oct)
+
+
+def test_serial_stream_mode_matches_oracle():
+    # the default run forks the Harris / extrema chains onto auxiliary streams; the single-stream
+    # mode (VSLAM_AUX_STREAMS=0, read once per process) must give the same results
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VSLAM_AUX_STREAMS="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "__graft_entry__.py"), "smoke"], capture_output=True, text=True,
+                       timeout=600, env=env, cwd=root)
+    assert r.returncode == 0 and "smoke ok" in r.stdout, r.stdout + r.stderr
