@@ -206,3 +206,26 @@ def test_serial_stream_mode_matches_oracle():
     r = subprocess.run([sys.executable, os.path.join(root, "__graft_entry__.py"), "smoke"], capture_output=True, text=True,
                        timeout=600, env=env, cwd=root)
     assert r.returncode == 0 and "smoke ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_batch_random_shapes(env):
+    # seeded sweep over frame sizes (multiples of 4/8/16 and ragged ones) through every dispatch
+    # path of the batch: specialised and generic kernels must agree with the oracle everywhere
+    ctx, torch = env
+    rng = np.random.default_rng(20261003)
+    shapes = set()
+    while len(shapes) < 14:
+        r = int(rng.integers(2, 150))
+        c = int(rng.integers(2, 300))
+        if rng.random() < 0.6:
+            c = max(8, c // 8 * 8)
+        shapes.add((r, c))
+    for rows, cols in sorted(shapes):
+        n_oct = max(1, min(3, oracle.auto_num_octaves(2 * rows, 2 * cols) + 2))
+        while n_oct > 1 and min(rows, cols) * 2 >> (n_oct - 1) < 2:
+            n_oct -= 1
+        frames = synth.frames_np(2, rows, cols, stream_id=rows * 1000 + cols)
+        frames[1] = synth.frame_np(rows, cols, kind="noise")
+        p, L, out = run_batch(ctx, torch, frames, n_octaves=n_oct)
+        for f in range(2):
+            check_frame(p, L, out, f, frames[f], n_oct)
