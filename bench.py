@@ -234,6 +234,18 @@ def main():
                 "algorithmic_bytes_per_frame": algo.get(kname, 0),
                 "algorithmic_bytes_per_launch": algo.get(kname, 0) * n * args.steps / launches,
             }
+        # secondary view of the same kernel: it is bound by VALU issue of the packed dot
+        # instructions, not by HBM.  Algorithmic dot instructions per pixel =
+        # sum over levels of n/4 (v_dot4_u32_u8, vertical) + n/2 (v_dot2_u32_u16, horizontal) with
+        # the zero-trimmed kernel widths n; peak = 32.8e12 lane-instr/s measured by
+        # tools/ubench_valu.hip (4.3 cycles per wave64 dot instruction per SIMD).
+        valu = None
+        if roof and kname == "k_pyr_octave" and args.octaves >= 2 and (rows, cols) == (1080, 1920):
+            widths = [[9, 13, 15, 19, 23, 29], [19, 23, 29, 37, 45, 57]]
+            per_frame = sum(0.75 * sum(w) * L.rows[o] * L.cols[o] for o, w in enumerate(widths))
+            ach = per_frame * n * args.steps / (kms * 1e-3)
+            valu = {"bound": "valu-dot", "achieved": ach / 1e12, "peak": 32.8, "unit": "T lane-instr/s",
+                    "frac": ach / 32.8e12, "algorithmic_dot_instr_per_frame": per_frame}
         line = {
             "metric": "frames/sec @1080p (Harris + DoG keypoint detection)",
             "value": fps,
@@ -261,6 +273,7 @@ def main():
                 "frac_of_peak": bytes_frame * fps / world / 1e9 / HBM_PEAK_GBPS,
             },
             "roofline": roof,
+            "roofline_valu": valu,
             "cpu_baseline": cpu_baseline(rows, cols, args.octaves, args.cpu_sample) if (world == 1 and args.cpu_sample > 0) else None,
         }
         print(json.dumps(line))
