@@ -29,8 +29,7 @@ def kernel_algorithmic_bytes(L, rows, cols):
     N = rows * cols
     P = [L.rows[o] * L.cols[o] for o in range(L.n_octaves)]
     return {
-        "k_harris_fused": 5 * N,                 # u8 frame in, f32 response out
-        "k_harris_post": N,                      # u8 NMS mask out
+        "k_harris_strip": 6 * N,                 # u8 frame in, f32 response + u8 NMS mask out (one pass)
         "k_resize_linear2x_slide": N,               # DoG path's read of the frame
         "k_pyr_octave": 11 * sum(P[:2]),         # 6 Gaussian + 5 DoG images of octaves 0-1 (LDS-tiled)
         "k_gauss_h_strip": 11 * sum(P[2:]),      # the same for the coarse octaves (strip kernels)
