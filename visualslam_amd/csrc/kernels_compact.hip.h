@@ -1,0 +1,201 @@
+// Deterministic ordered compaction of ballot flag words into keypoint lists, any batch size:
+//   k_flag_count   : one 256-thread block per chunk of 256 flag entries -> chunk totals
+//   k_chunk_scan   : one block per frame: exclusive scan of its chunk totals, frame total
+//   k_flag_scatter : per chunk again: in-block exclusive scan (wave shuffles + LDS) and emission
+// List order = entry order, and inside an entry ascending bit order, which is the reference's
+// loop order (row-major pixels for Harris; octave, level, i, j for the DoG lattice).  Three
+// short launches instead of one serial workgroup per frame: a single 1080p frame compacts in
+// ~20 us instead of 250 us, and a 256-frame batch spreads over the whole chip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "kernels_generic.hip.h"
+#include "kernels_harris_strip.hip.h"
+
+namespace vslam {
+
+constexpr int CMP_CHUNK = 256;  // entries per workgroup
+
+// Entry kinds: what one flag entry is and how its set bits turn into list records.
+struct HarrisStripEntries {  // entry = (row, strip): 4 ballot words (pixel slot k = 0..3), lane-major order
+    const unsigned long long* flags;
+    size_t fframe;
+    int rows, cols, nstrips;
+    const float* resp;
+    size_t rframe;
+    vslam_kp* out;
+    __device__ size_t count() const { return (size_t)rows * nstrips; }
+    __device__ unsigned int load(int f, size_t e, unsigned long long (&w)[4]) const {
+        const unsigned long long* F = flags + f * fframe + e * 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) w[k] = F[k];
+        return __popcll(w[0]) + __popcll(w[1]) + __popcll(w[2]) + __popcll(w[3]);
+    }
+    __device__ void emit(int f, size_t e, const unsigned long long (&w)[4], unsigned int pos, unsigned int cap) const {
+        const int r = (int)(e / nstrips), strip = (int)(e % nstrips);
+        unsigned long long m = w[0] | w[1] | w[2] | w[3];
+        while (m) {
+            const int l = __ffsll((long long)m) - 1;
+            m &= m - 1;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if ((w[k] >> l) & 1ull) {
+                    if (pos < cap) {
+                        const int c = strip * HS_STRIP_W + 4 * (l - 2) + k;
+                        vslam_kp kp;
+                        kp.row = r;
+                        kp.col = c;
+                        kp.response = resp[f * rframe + (size_t)r * cols + c];
+                        out[(size_t)f * cap + pos] = kp;
+                    }
+                    ++pos;
+                }
+        }
+    }
+};
+
+struct HarrisWordEntries {  // entry = 64 consecutive pixels of a row (fallback Harris path)
+    const unsigned long long* flags;
+    size_t fframe;
+    int rows, cols, wpr;
+    const float* resp;
+    size_t rframe;
+    vslam_kp* out;
+    __device__ size_t count() const { return (size_t)rows * wpr; }
+    __device__ unsigned int load(int f, size_t e, unsigned long long (&w)[4]) const {
+        w[0] = flags[f * fframe + e];
+        return __popcll(w[0]);
+    }
+    __device__ void emit(int f, size_t e, const unsigned long long (&w)[4], unsigned int pos, unsigned int cap) const {
+        const int r = (int)(e / wpr), c0 = (int)(e % wpr) * 64;
+        unsigned long long m = w[0];
+        while (m) {
+            const int b = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            if (pos < cap) {
+                vslam_kp kp;
+                kp.row = r;
+                kp.col = c0 + b;
+                kp.response = resp[f * rframe + (size_t)r * cols + c0 + b];
+                out[(size_t)f * cap + pos] = kp;
+            }
+            ++pos;
+        }
+    }
+};
+
+struct DogEntries {  // entry = one 64-site word of the (octave, level, lattice row) bitmask layout
+    const unsigned long long* lflags;
+    size_t bframe;
+    const uint8_t* pyr;
+    size_t pframe;
+    ExtGeom g;
+    int o_begin, o_end;
+    vslam_point* out;
+    __device__ size_t first() const { return g.bits_off[o_begin]; }
+    __device__ size_t count() const {
+        return g.bits_off[o_end - 1] + (size_t)3 * g.lat_rows[o_end - 1] * g.wpr[o_end - 1] - g.bits_off[o_begin];
+    }
+    __device__ unsigned int load(int f, size_t e, unsigned long long (&w)[4]) const {
+        w[0] = lflags[f * bframe + first() + e];
+        return __popcll(w[0]);
+    }
+    __device__ void emit(int f, size_t e, const unsigned long long (&w)[4], unsigned int pos, unsigned int cap) const {
+        const size_t wi = first() + e;
+        int o = o_begin;
+        while (o + 1 < o_end && wi >= g.bits_off[o + 1]) ++o;
+        const size_t wl = wi - g.bits_off[o];
+        const int wpr = g.wpr[o], lr = g.lat_rows[o];
+        const int level = (int)(wl / ((size_t)lr * wpr)) + 1;
+        const int li = (int)((wl / wpr) % lr), lj0 = (int)(wl % wpr) * 64;
+        const size_t P = (size_t)g.rows[o] * g.cols[o];
+        const uint8_t* dog = pyr + f * pframe + g.oct_off[o] + (size_t)VSLAM_NUM_LEVELS * P;
+        unsigned long long m = w[0];
+        while (m) {
+            const int b = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            if (pos < cap) {
+                const int i = g.pad + li * g.window, j = g.pad + (lj0 + b) * g.window;
+                vslam_point pt;
+                pt.row = i;
+                pt.col = j;
+                pt.value = dog[(size_t)level * P + (size_t)(i - g.pad) * g.cols[o] + (j - g.pad)];
+                pt.padding = g.pad;
+                pt.octave = o;
+                pt.level = level;
+                out[(size_t)f * cap + pos] = pt;
+            }
+            ++pos;
+        }
+    }
+};
+
+// Block-wide exclusive scan for 256 threads; `total` = block sum.
+__device__ __forceinline__ unsigned int block_excl_scan_256(unsigned int v, unsigned int* wsum, unsigned int& total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned int inc = v;
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned int t = __shfl_up(inc, off);
+        if (lane >= off) inc += t;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    unsigned int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const unsigned int s = wsum[w];
+        if (w < wave) base += s;
+        tot += s;
+    }
+    total = tot;
+    return base + inc - v;
+}
+
+// grid = (chunks, 1, frames)
+template <class E>
+__global__ __launch_bounds__(256) void k_flag_count(const E ent, unsigned int* __restrict__ chunk_tot, int nchunks) {
+    __shared__ unsigned int wsum[4];
+    const int f = blockIdx.z;
+    const size_t e = (size_t)blockIdx.x * CMP_CHUNK + threadIdx.x;
+    unsigned long long w[4] = {0, 0, 0, 0};
+    const unsigned int cnt = e < ent.count() ? ent.load(f, e, w) : 0u;
+    unsigned int total;
+    block_excl_scan_256(cnt, wsum, total);
+    if (threadIdx.x == 0) chunk_tot[(size_t)f * nchunks + blockIdx.x] = total;
+}
+
+// grid = (frames); turns chunk totals into exclusive offsets (in place) and writes the frame total.
+// append != 0: the list continues after counts[f] records already written by an earlier call.
+__global__ __launch_bounds__(256) void k_chunk_scan(unsigned int* __restrict__ chunk_tot, int nchunks,
+                                                     unsigned int* __restrict__ counts, int append) {
+    __shared__ unsigned int wsum[4];
+    const int f = blockIdx.x;
+    unsigned int* T = chunk_tot + (size_t)f * nchunks;
+    unsigned int running = append ? counts[f] : 0u;
+    for (int base = 0; base < nchunks; base += 256) {
+        const int i = base + threadIdx.x;
+        const unsigned int v = i < nchunks ? T[i] : 0u;
+        unsigned int total;
+        const unsigned int ex = block_excl_scan_256(v, wsum, total);
+        if (i < nchunks) T[i] = running + ex;
+        running += total;
+        __syncthreads();  // wsum reuse
+    }
+    if (threadIdx.x == 0) counts[f] = running;
+}
+
+// grid = (chunks, 1, frames)
+template <class E>
+__global__ __launch_bounds__(256) void k_flag_scatter(const E ent, const unsigned int* __restrict__ chunk_off, int nchunks,
+                                                       unsigned int cap) {
+    __shared__ unsigned int wsum[4];
+    const int f = blockIdx.z;
+    const size_t e = (size_t)blockIdx.x * CMP_CHUNK + threadIdx.x;
+    unsigned long long w[4] = {0, 0, 0, 0};
+    const unsigned int cnt = e < ent.count() ? ent.load(f, e, w) : 0u;
+    unsigned int total;
+    const unsigned int ex = block_excl_scan_256(cnt, wsum, total);
+    if (cnt) ent.emit(f, e, w, chunk_off[(size_t)f * nchunks + blockIdx.x] + ex, cap);
+}
+
+}  // namespace vslam

@@ -320,107 +320,4 @@ __global__ __launch_bounds__(256) void k_extrema(const uint8_t* __restrict__ pyr
     }
 }
 
-// ---- deterministic ordered compaction: popcount -> block scan -> scatter ------------------
-
-// Exclusive scan of one value per thread over a 1024-thread block; returns the block total
-// through `total`.  Wave scan by shuffles, wave totals through LDS.
-__device__ __forceinline__ unsigned int block_excl_scan_1024(unsigned int v, unsigned int* wsum,
-                                                             unsigned int& total) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    unsigned int inc = v;
-    for (int off = 1; off < 64; off <<= 1) {
-        const unsigned int t = __shfl_up(inc, off);
-        if (lane >= off) inc += t;
-    }
-    __syncthreads();  // wsum reuse across calls
-    if (lane == 63) wsum[wave] = inc;
-    __syncthreads();
-    unsigned int base = 0, tot = 0;
-    for (int w = 0; w < 16; ++w) {
-        const unsigned int s = wsum[w];
-        if (w < wave) base += s;
-        tot += s;
-    }
-    total = tot;
-    return base + inc - v;
-}
-
-// One 1024-thread block per frame walks the frame's flag words in list order.
-__global__ __launch_bounds__(1024) void k_compact_harris(const unsigned long long* __restrict__ flags, int wpr,
-                                                          size_t fframe, int rows, int cols,
-                                                          const float* __restrict__ resp, size_t rstep_elems,
-                                                          size_t rframe, vslam_kp* __restrict__ out,
-                                                          unsigned int cap, unsigned int* __restrict__ counts) {
-    __shared__ unsigned int wsum[16];
-    const int f = blockIdx.x;
-    const unsigned long long* F = flags + f * fframe;
-    const size_t nwords = (size_t)rows * wpr;
-    unsigned int running = 0;
-    for (size_t base = 0; base < nwords; base += 1024) {
-        const size_t w = base + threadIdx.x;
-        unsigned long long bitsw = w < nwords ? F[w] : 0ull;
-        unsigned int total;
-        unsigned int pos = running + block_excl_scan_1024((unsigned int)__popcll(bitsw), wsum, total);
-        const int r = (int)(w / wpr), c0 = (int)(w % wpr) * 64;
-        while (bitsw) {
-            const int b = __ffsll((long long)bitsw) - 1;
-            bitsw &= bitsw - 1;
-            if (pos < cap) {
-                vslam_kp kp;
-                kp.row = r;
-                kp.col = c0 + b;
-                kp.response = resp[f * rframe + (size_t)r * rstep_elems + c0 + b];
-                out[(size_t)f * cap + pos] = kp;
-            }
-            ++pos;
-        }
-        running += total;
-    }
-    if (threadIdx.x == 0) counts[f] = running;
-}
-
-__global__ __launch_bounds__(1024) void k_compact_dog(const unsigned long long* __restrict__ lflags, size_t bframe,
-                                                       const uint8_t* __restrict__ pyr, size_t pframe, ExtGeom g,
-                                                       int o_begin, int o_end, vslam_point* __restrict__ out,
-                                                       unsigned int cap, unsigned int* __restrict__ counts, int append) {
-    __shared__ unsigned int wsum[16];
-    const int f = blockIdx.x;
-    // append: continue the frame's list where the previous launch (lower octaves) stopped, so the
-    // octaves can be compacted one by one while later octaves are still being computed
-    unsigned int running = append ? counts[f] : 0;
-    for (int o = o_begin; o < o_end; ++o) {
-        const unsigned long long* F = lflags + f * bframe + g.bits_off[o];
-        const int wpr = g.wpr[o], lr = g.lat_rows[o];
-        const size_t nwords = (size_t)3 * lr * wpr;
-        const size_t P = (size_t)g.rows[o] * g.cols[o];
-        const uint8_t* dog = pyr + f * pframe + g.oct_off[o] + (size_t)VSLAM_NUM_LEVELS * P;
-        for (size_t base = 0; base < nwords; base += 1024) {
-            const size_t w = base + threadIdx.x;
-            unsigned long long bitsw = w < nwords ? F[w] : 0ull;
-            unsigned int total;
-            unsigned int pos = running + block_excl_scan_1024((unsigned int)__popcll(bitsw), wsum, total);
-            const int level = (int)(w / ((size_t)lr * wpr)) + 1;
-            const int li = (int)((w / wpr) % lr), lj0 = (int)(w % wpr) * 64;
-            while (bitsw) {
-                const int b = __ffsll((long long)bitsw) - 1;
-                bitsw &= bitsw - 1;
-                if (pos < cap) {
-                    const int i = g.pad + li * g.window, j = g.pad + (lj0 + b) * g.window;
-                    vslam_point pt;
-                    pt.row = i;
-                    pt.col = j;
-                    pt.value = dog[(size_t)level * P + (size_t)(i - g.pad) * g.cols[o] + (j - g.pad)];
-                    pt.padding = g.pad;
-                    pt.octave = o;
-                    pt.level = level;
-                    out[(size_t)f * cap + pos] = pt;
-                }
-                ++pos;
-            }
-            running += total;
-        }
-    }
-    if (threadIdx.x == 0) counts[f] = running;
-}
-
 }  // namespace vslam

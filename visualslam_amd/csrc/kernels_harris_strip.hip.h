@@ -11,7 +11,7 @@
 // wave_shr:1 / wave_shl:1).  Nothing goes through LDS or back through HBM: the frame is read
 // once (+ 4 % strip overlap) and response / mask / NMS2 map are written once, as 16-byte and
 // 4-byte per-lane stores.  Keypoint flags leave as wave ballots (one 64-bit word per pixel
-// slot k = 0..3 of the strip row), compacted in row-major order by k_compact_harris_strip.
+// slot k = 0..3 of the strip row), compacted in row-major order by kernels_compact.hip.h.
 //
 // Lanes 0,1 and 62,63 of a wave only feed their neighbours (each stage invalidates one more
 // edge pixel), so a strip produces 60 lanes x 4 = 240 output columns; strips start every 240.
@@ -209,54 +209,6 @@ __global__ __launch_bounds__(256) void k_harris_strip(const HarrisStripArgs a) {
             Ry[k] = Rb[k], nby[k] = nbn[k];
         }
     }
-}
-
-// Row-major compaction of the strip flags: one 1024-thread block per frame, one (row, strip)
-// entry of 4 ballot words per thread; inside an entry the order is lane, then pixel slot.
-__global__ __launch_bounds__(1024) void k_compact_harris_strip(const unsigned long long* __restrict__ flags,
-                                                                size_t fframe, int rows, int cols, int nstrips,
-                                                                const float* __restrict__ resp, size_t rframe,
-                                                                vslam_kp* __restrict__ out, unsigned int cap,
-                                                                unsigned int* __restrict__ counts) {
-    __shared__ unsigned int wsum[16];
-    const int f = blockIdx.x;
-    const unsigned long long* F = flags + f * fframe;
-    const size_t nent = (size_t)rows * nstrips;
-    unsigned int running = 0;
-    for (size_t base = 0; base < nent; base += 1024) {
-        const size_t e = base + threadIdx.x;
-        unsigned long long w[4] = {0, 0, 0, 0};
-        if (e < nent) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) w[k] = F[e * 4 + k];
-        }
-        const unsigned int cnt = __popcll(w[0]) + __popcll(w[1]) + __popcll(w[2]) + __popcll(w[3]);
-        unsigned int total;
-        unsigned int pos = running + block_excl_scan_1024(cnt, wsum, total);
-        if (cnt) {
-            const int r = (int)(e / nstrips), strip = (int)(e % nstrips);
-            unsigned long long m = w[0] | w[1] | w[2] | w[3];
-            while (m) {
-                const int l = __ffsll((long long)m) - 1;
-                m &= m - 1;
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if ((w[k] >> l) & 1ull) {
-                        if (pos < cap) {
-                            const int c = strip * HS_STRIP_W + 4 * (l - 2) + k;
-                            vslam_kp kp;
-                            kp.row = r;
-                            kp.col = c;
-                            kp.response = resp[f * rframe + (size_t)r * cols + c];
-                            out[(size_t)f * cap + pos] = kp;
-                        }
-                        ++pos;
-                    }
-            }
-        }
-        running += total;
-    }
-    if (threadIdx.x == 0) counts[f] = running;
 }
 
 }  // namespace vslam

@@ -18,6 +18,7 @@
 #include "kernels_strip.hip.h"
 #include "kernels_aux.hip.h"
 #include "kernels_harris_strip.hip.h"
+#include "kernels_compact.hip.h"
 #include "vslam_internal.h"
 
 using namespace vslam;
@@ -77,10 +78,10 @@ static int fail(vslam_ctx* c, int code, const std::string& msg) {
     } while (0)
 
 static const char* const kKernelNames =
-    "k_harris_fused\nk_harris_post\nk_compact_harris\nk_resize_linear2x\nk_blur_h_generic\nk_blur_v_generic\n"
-    "k_dog5\nk_resize_nearest_half\nk_extrema\nk_compact_dog\nk_pyr_octave\n"
+    "k_harris_fused\nk_harris_post\nk_resize_linear2x\nk_blur_h_generic\nk_blur_v_generic\n"
+    "k_dog5\nk_resize_nearest_half\nk_extrema\nk_pyr_octave\n"
     "k_gauss_v_strip\nk_gauss_h_strip\nk_resize_linear2x_slide\nk_resize_nearest_half_v4\nk_extrema_w3\n"
-    "k_harris_strip\nk_compact_harris_strip\nk_level_gradients";
+    "k_harris_strip\nk_flag_count\nk_chunk_scan\nk_flag_scatter\nk_level_gradients";
 
 static std::pair<hipEvent_t, hipEvent_t>* timing_slot(vslam_ctx* c);
 
@@ -315,6 +316,23 @@ static int enqueue_blur(vslam_ctx* c, const uint8_t* src, size_t sstep, size_t s
     return VSLAM_OK;
 }
 
+// count -> scan -> scatter over the flag entries of nf frames (kernels_compact.hip.h).
+// chunk_ws: scratch of nf * chunks u32.
+template <class E>
+static int enqueue_compaction(vslam_ctx* c, const E& ent, size_t entries, int nf, unsigned int* chunk_ws, unsigned int cap,
+                              unsigned int* counts, int append) {
+    const int nchunks = (int)((entries + CMP_CHUNK - 1) / CMP_CHUNK);
+    if (nchunks == 0) {
+        if (!append) HIPCHK(c, hipMemsetAsync(counts, 0, sizeof(unsigned int) * (size_t)nf, c->stream));
+        return VSLAM_OK;
+    }
+    LAUNCH(c, "k_flag_count", k_flag_count<E>, dim3(nchunks, 1, nf), dim3(256), ent, chunk_ws, nchunks);
+    LAUNCH(c, "k_chunk_scan", k_chunk_scan, dim3(nf), dim3(256), chunk_ws, nchunks, counts, append);
+    LAUNCH(c, "k_flag_scatter", k_flag_scatter<E>, dim3(nchunks, 1, nf), dim3(256), ent, chunk_ws, nchunks, cap);
+    return VSLAM_OK;
+}
+static inline size_t compaction_ws_elems(size_t entries, int nf) { return (size_t)nf * ((entries + CMP_CHUNK - 1) / CMP_CHUNK) + 64; }
+
 static void fill_geom(const vslam_params& p, const vslam_batch_layout& L, ExtGeom& g) {
     std::memset(&g, 0, sizeof(g));
     g.n_oct = L.n_octaves;
@@ -338,6 +356,7 @@ struct DogScratch {
     size_t base_off[VSLAM_MAX_OCTAVES] = {};
     uint16_t* h = nullptr;  // nf * P0 u16
     unsigned long long* lflags = nullptr;
+    unsigned int* cws = nullptr;  // compaction chunk totals / offsets
 };
 
 // u16 scratch elements per frame: 6 row-sum images for a strip octave, 1 for a generic octave,
@@ -357,7 +376,7 @@ static size_t dog_scratch_bytes(const vslam_batch_layout& L, double sigma0, int 
     size_t sum_p = 0;
     for (int o = 0; o < L.n_octaves; ++o) sum_p += (size_t)L.rows[o] * L.cols[o];
     return ws_need((size_t)nf * sum_p) + ws_need((size_t)nf * dog_h_elems(L, sigma0) * 2 + 256) +
-           ws_need((size_t)nf * L.bits_frame_words * 8);
+           ws_need((size_t)nf * L.bits_frame_words * 8) + ws_need(4 * compaction_ws_elems(L.bits_frame_words, nf));
 }
 
 static int dog_scratch_take(vslam_ctx* c, const vslam_batch_layout& L, double sigma0, int nf, DogScratch& s) {
@@ -370,7 +389,8 @@ static int dog_scratch_take(vslam_ctx* c, const vslam_batch_layout& L, double si
     s.bases = ws_take<uint8_t>(c, (size_t)nf * sum_p);
     s.h = ws_take<uint16_t>(c, (size_t)nf * dog_h_elems(L, sigma0) + 128);
     s.lflags = ws_take<unsigned long long>(c, (size_t)nf * L.bits_frame_words);
-    if (!s.bases || !s.h || !s.lflags) return fail(c, VSLAM_ERR_NOMEM, "workspace sizing error (dog)");
+    s.cws = ws_take<unsigned int>(c, compaction_ws_elems(L.bits_frame_words, nf));
+    if (!s.bases || !s.h || !s.lflags || !s.cws) return fail(c, VSLAM_ERR_NOMEM, "workspace sizing error (dog)");
     return VSLAM_OK;
 }
 
@@ -477,8 +497,8 @@ static int enqueue_dog(vslam_ctx* c, const vslam_params& p, const vslam_batch_la
         // stream it overlaps the next octave's kernels instead of forming a serial tail
         if (do_extrema && points && counts) {
             StreamSwap sw(c, side ? side : c->stream);
-            LAUNCH(c, "k_compact_dog", k_compact_dog, dim3(nf), dim3(1024), s.lflags, L.bits_frame_words, pyr, pframe, g, o,
-                   o + 1, points, p.dog_cap, counts, o > 0 ? 1 : 0);
+            DogEntries ent{s.lflags, L.bits_frame_words, pyr, pframe, g, o, o + 1, points};
+            TRY(enqueue_compaction(c, ent, (size_t)3 * L.lat_rows[o] * L.lat_words[o], nf, s.cws, p.dog_cap, counts, o > 0 ? 1 : 0));
         }
     }
     return VSLAM_OK;
@@ -495,7 +515,7 @@ static size_t harris_flag_words(int rows, int cols) {
 // response kernel + the post-processing kernel.
 static int enqueue_harris(vslam_ctx* c, const uint8_t* frames, size_t fstep, size_t fframe, int rows, int cols,
                           int nf, float k, float* resp, uint8_t* mask, float* nms2, unsigned long long* hflags,
-                          vslam_kp* kps, unsigned int cap, unsigned int* counts) {
+                          vslam_kp* kps, unsigned int cap, unsigned int* counts, unsigned int* chunk_ws) {
     const size_t N = (size_t)rows * cols;
     if (cols % 4 == 0 && fstep == (size_t)cols && fframe % 4 == 0) {
         HarrisStripArgs a;
@@ -516,9 +536,10 @@ static int enqueue_harris(vslam_ctx* c, const uint8_t* frames, size_t fstep, siz
         a.seg = (int)std::min<long>(rows, std::max<long>(16, (rows + want_seg - 1) / want_seg));
         const int nseg = (rows + a.seg - 1) / a.seg;
         LAUNCH(c, "k_harris_strip", k_harris_strip, dim3((a.nstrips * nseg + 3) / 4, 1, nf), dim3(256), a);
-        if (hflags && kps && counts)
-            LAUNCH(c, "k_compact_harris_strip", k_compact_harris_strip, dim3(nf), dim3(1024), hflags, a.fframe, rows, cols,
-                   a.nstrips, resp, N, kps, cap, counts);
+        if (hflags && kps && counts) {
+            HarrisStripEntries ent{hflags, a.fframe, rows, cols, a.nstrips, resp, N, kps};
+            TRY(enqueue_compaction(c, ent, (size_t)rows * a.nstrips, nf, chunk_ws, cap, counts, 0));
+        }
         return VSLAM_OK;
     }
     LAUNCH(c, "k_harris_fused", k_harris_fused, dim3((cols + HT_W - 1) / HT_W, (rows + HT_H - 1) / HT_H, nf),
@@ -527,9 +548,10 @@ static int enqueue_harris(vslam_ctx* c, const uint8_t* frames, size_t fstep, siz
         const int wpr = (cols + 63) / 64;
         LAUNCH(c, "k_harris_post", k_harris_post, grid_rows(cols, rows, nf), dim3(256), resp, (size_t)cols, N, rows, cols,
                mask, (size_t)cols, N, nms2, (size_t)cols, N, hflags, wpr, (size_t)rows * wpr);
-        if (hflags && kps && counts)
-            LAUNCH(c, "k_compact_harris", k_compact_harris, dim3(nf), dim3(1024), hflags, wpr, (size_t)rows * wpr, rows,
-                   cols, resp, (size_t)cols, N, kps, cap, counts);
+        if (hflags && kps && counts) {
+            HarrisWordEntries ent{hflags, (size_t)rows * wpr, rows, cols, wpr, resp, N, kps};
+            TRY(enqueue_compaction(c, ent, (size_t)rows * wpr, nf, chunk_ws, cap, counts, 0));
+        }
     }
     return VSLAM_OK;
 }
@@ -754,7 +776,7 @@ int vslam_harris_response_u8(vslam_ctx* c, const uint8_t* img, int rows, int col
     uint8_t* d_img = ws_take<uint8_t>(c, P);
     float* d_r = ws_take<float>(c, P);
     TRY(h2d(c, d_img, cols, img, step, cols, rows));
-    TRY(enqueue_harris(c, d_img, cols, P, rows, cols, 1, k, d_r, nullptr, nullptr, nullptr, nullptr, 0, nullptr));
+    TRY(enqueue_harris(c, d_img, cols, P, rows, cols, 1, k, d_r, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr));
     TRY(d2h(c, resp, resp_step, d_r, 4 * (size_t)cols, 4 * (size_t)cols, rows));
     return vslam_ctx_sync(c);
 }
@@ -817,14 +839,16 @@ int vslam_harris_keypoints_u8(vslam_ctx* c, const uint8_t* img, int rows, int co
     ARGCHK(c, img && count && rows > 0 && cols > 0 && step >= (size_t)cols && (out || cap == 0), "harris_keypoints: bad arguments");
     const size_t P = (size_t)rows * cols;
     const unsigned int dcap = (unsigned int)std::min<size_t>(cap, 0x7fffffff);
-    TRY(ws_reserve(c, ws_need(P) + ws_need(4 * P) + ws_need(harris_flag_words(rows, cols) * 8) + ws_need(sizeof(vslam_kp) * (size_t)dcap) + 256));
+    TRY(ws_reserve(c, ws_need(P) + ws_need(4 * P) + ws_need(harris_flag_words(rows, cols) * 8) + ws_need(sizeof(vslam_kp) * (size_t)dcap) + 256 +
+                          ws_need(4 * compaction_ws_elems(harris_flag_words(rows, cols), 1))));
     uint8_t* d_img = ws_take<uint8_t>(c, P);
     float* d_r = ws_take<float>(c, P);
     unsigned long long* d_f = ws_take<unsigned long long>(c, harris_flag_words(rows, cols));
     vslam_kp* d_k = ws_take<vslam_kp>(c, dcap);
     unsigned int* d_n = ws_take<unsigned int>(c, 1);
+    unsigned int* d_cws = ws_take<unsigned int>(c, compaction_ws_elems(harris_flag_words(rows, cols), 1));
     TRY(h2d(c, d_img, cols, img, step, cols, rows));
-    TRY(enqueue_harris(c, d_img, cols, P, rows, cols, 1, k, d_r, nullptr, nullptr, d_f, d_k, dcap, d_n));
+    TRY(enqueue_harris(c, d_img, cols, P, rows, cols, 1, k, d_r, nullptr, nullptr, d_f, d_k, dcap, d_n, d_cws));
     unsigned int n = 0;
     HIPCHK(c, hipMemcpyAsync(&n, d_n, 4, hipMemcpyDeviceToHost, c->stream));
     TRY(vslam_ctx_sync(c));
@@ -981,18 +1005,19 @@ int vslam_dog_extrema(vslam_ctx* c, const vslam_pyramid* py, int octave, int win
     ExtGeom g;
     fill_geom(p, L, g);
     const size_t words = L.bits_frame_words;
-    TRY(ws_reserve(c, 2 * ws_need(words * 8) + ws_need(sizeof(vslam_point) * (size_t)p.dog_cap) + 256));
+    TRY(ws_reserve(c, 2 * ws_need(words * 8) + ws_need(sizeof(vslam_point) * (size_t)p.dog_cap) + 256 + ws_need(4 * compaction_ws_elems(words, 1))));
     unsigned long long* d_bits = ws_take<unsigned long long>(c, words);
     unsigned long long* d_lf = ws_take<unsigned long long>(c, words);
     vslam_point* d_pts = ws_take<vslam_point>(c, p.dog_cap);
     unsigned int* d_n = ws_take<unsigned int>(c, 1);
+    unsigned int* d_cws = ws_take<unsigned int>(c, compaction_ws_elems(words, 1));
     HIPCHK(c, hipMemsetAsync(d_n, 0, 4, c->stream));
     const size_t ow = (size_t)3 * L.lat_rows[octave] * L.lat_words[octave];
     if (ow) {
         LAUNCH(c, "k_extrema", k_extrema, dim3((L.lat_cols[octave] + 255) / 256, L.lat_rows[octave], 3), dim3(256),
                py->d_block, L.pyramid_frame_bytes, g, octave, d_bits, d_lf, words);
-        LAUNCH(c, "k_compact_dog", k_compact_dog, dim3(1), dim3(1024), d_lf, words, py->d_block, L.pyramid_frame_bytes, g,
-               octave, octave + 1, d_pts, p.dog_cap, d_n, 0);
+        DogEntries ent{d_lf, words, py->d_block, L.pyramid_frame_bytes, g, octave, octave + 1, d_pts};
+        TRY(enqueue_compaction(c, ent, ow, 1, d_cws, p.dog_cap, d_n, 0));
     }
     unsigned int n = 0;
     HIPCHK(c, hipMemcpyAsync(&n, d_n, 4, hipMemcpyDeviceToHost, c->stream));
@@ -1025,12 +1050,15 @@ int vslam_detect_batch_dev(vslam_ctx* c, const vslam_params* pp, const uint8_t* 
     const int chunk = std::min(n_frames, 256);
     size_t need = 0;
     if (dog) need += dog_scratch_bytes(L, p.sigma0, chunk);
-    if (harris) need += (out->response ? 0 : ws_need((size_t)chunk * N * 4)) + ws_need((size_t)chunk * harris_flag_words(p.rows, p.cols) * 8);
+    if (harris)
+        need += (out->response ? 0 : ws_need((size_t)chunk * N * 4)) + ws_need((size_t)chunk * harris_flag_words(p.rows, p.cols) * 8) +
+                ws_need(4 * compaction_ws_elems(harris_flag_words(p.rows, p.cols), chunk));
     TRY(ws_reserve(c, need));
     DogScratch s;
     if (dog) TRY(dog_scratch_take(c, L, p.sigma0, chunk, s));
     float* resp_ws = (harris && !out->response) ? ws_take<float>(c, (size_t)chunk * N) : nullptr;
     unsigned long long* hflags = harris ? ws_take<unsigned long long>(c, (size_t)chunk * harris_flag_words(p.rows, p.cols)) : nullptr;
+    unsigned int* hcws = harris ? ws_take<unsigned int>(c, compaction_ws_elems(harris_flag_words(p.rows, p.cols), chunk)) : nullptr;
     // Fork (VSLAM_AUX_STREAMS=0 disables): the Harris chain and the extrema/compaction chain run on
     // the context's auxiliary streams beside the octave kernels.  Measured on MI355X: +2.8 %
     // (11.2k vs 10.9k frames/s) -- small, because every kernel of the batch is VALU-issue-bound
@@ -1058,7 +1086,7 @@ int vslam_detect_batch_dev(vslam_ctx* c, const vslam_params* pp, const uint8_t* 
                                out->nms_mask ? out->nms_mask + (size_t)f0 * N : nullptr,
                                out->nms2 ? out->nms2 + (size_t)f0 * N : nullptr, want_kps ? hflags : nullptr,
                                want_kps ? out->harris_kps + (size_t)f0 * p.harris_cap : nullptr, p.harris_cap,
-                               want_kps ? out->harris_counts + f0 : nullptr));
+                               want_kps ? out->harris_counts + f0 : nullptr, hcws));
         }
         if (dog) {
             const bool ext = out->extrema_bits || (out->dog_points && out->dog_counts);
