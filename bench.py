@@ -125,6 +125,8 @@ def main():
     ap.add_argument("--cols", type=int, default=1920)
     ap.add_argument("--octaves", type=int, default=4)
     ap.add_argument("--kernel", default=None, help="kernel to time with HIP events for the roofline object")
+    ap.add_argument("--localize", type=int, default=0,
+                    help="1: DoG list = FeaturePointLocalization survivors (SURVEY 8f row 2) instead of the contrast-8 candidate list")
     ap.add_argument("--cpu-sample", type=int, default=6, help="frames in the CPU baseline sample (0 = skip)")
     args = ap.parse_args()
 
@@ -159,7 +161,7 @@ def main():
     capi.build()
     rows, cols, n = args.rows, args.cols, args.frames
     ctx = capi.Context(local_rank, torch.cuda.current_stream().cuda_stream)
-    p = capi.default_params(rows, cols, n_octaves=args.octaves)
+    p = capi.default_params(rows, cols, n_octaves=args.octaves, localize=args.localize)
     L = capi.batch_layout(p)
 
     # one camera stream per GPU: stream_id = rank
@@ -261,7 +263,7 @@ def main():
             "config": {
                 "workload": f"batch of {n} synthetic {cols}x{rows} frames per GPU, Harris(k=0.04)+NMS and DoG pyramid "
                             f"{args.octaves} octaves x (6 Gaussian, 5 DoG) + extrema, fused (BASELINE config 4)",
-                "frames_per_gpu": n, "rows": rows, "cols": cols, "octaves": args.octaves,
+                "frames_per_gpu": n, "rows": rows, "cols": cols, "octaves": args.octaves, "localize": args.localize,
                 "parallelism": f"frames sharded 1 stream/GPU x{world}; RCCL all-gather of counts only",
             },
             "keypoints_per_sec": kp_per_step * args.steps / dt,

@@ -186,6 +186,19 @@ int vslam_pyramid_get_gradients(const vslam_pyramid* pyr, int octave, int level,
 int vslam_dog_extrema(vslam_ctx* ctx, const vslam_pyramid* pyr, int octave, int window, int min_contrast,
                       uint64_t* bits, vslam_point* out, size_t cap, size_t* count);
 
+/* The same function through its call to FeaturePointLocalization (Diff_of_Gauss.cpp:290,
+ * :223-251): exactly the points the reference appends to `keypoints`, in its order, with the
+ * value rewritten at :246.  The contrast test is evaluated for EVERY candidate with the
+ * reference's own arithmetic (A*A^T is singular; cv::invert's closed form decides, see
+ * kernels_localize.hip.h) - no min_contrast shortcut. */
+int vslam_dog_keypoints(vslam_ctx* ctx, const vslam_pyramid* pyr, int octave, int window, vslam_point* out,
+                        size_t cap, size_t* count);
+/* bool FeaturePointLocalization(vector<Mat>& dogs_padded, vector<SLAM::point>&, int level,
+ * SLAM::point&), Diff_of_Gauss.cpp:223-251, for n independent candidates.  diffs = n x
+ * (d_x, d_y, d_scale, value) as read at :226-228 and from point.value; keep[i] = the function's
+ * return value, value[i] = point.value afterwards (unchanged when not kept). */
+int vslam_localize_points(vslam_ctx* ctx, const int* diffs, size_t n, int* keep, int* value);
+
 /* ------------------------------------------- device-resident batched detection */
 
 typedef struct {
@@ -196,6 +209,8 @@ typedef struct {
     int do_harris;       /* run the Harris path */
     int extrema_window;  /* 3, Diff_of_Gauss.cpp:772 */
     int min_contrast;    /* list threshold on the 8-bit DoG value; 8 */
+    int localize;        /* 1: dog_points = FeaturePointLocalization survivors (vslam_dog_keypoints),
+                          * min_contrast unused; 0 (default): candidates with value >= min_contrast */
     uint32_t harris_cap; /* per-frame capacity of the Harris keypoint list */
     uint32_t dog_cap;    /* per-frame capacity of the DoG point list */
 } vslam_params;

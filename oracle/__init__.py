@@ -100,8 +100,18 @@ def lib():
         L.vo_extrema_lattice.restype = None
         L.vo_dog_extrema.argtypes = [C.POINTER(_Pyr), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
         L.vo_dog_extrema.restype = C.c_size_t
+        L.vo_feature_point_localization.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
+        L.vo_dog_keypoints.argtypes = [C.POINTER(_Pyr), C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+        L.vo_dog_keypoints.restype = C.c_size_t
         _lib = L
     return _lib
+
+
+def feature_point_localization(d_x, d_y, d_scale, value):
+    """(kept, new_value) of FeaturePointLocalization for one candidate."""
+    nv = C.c_int(0)
+    k = lib().vo_feature_point_localization(int(d_x), int(d_y), int(d_scale), int(value), C.byref(nv))
+    return bool(k), nv.value
 
 
 def _u8(a):
@@ -283,6 +293,14 @@ class Pyramid:
         if n:
             lib().vo_dog_extrema(self._p, octave, window, min_contrast, None, pts.ctypes.data, n)
         return mask, pts
+
+    def keypoints(self, octave, window=3):
+        """initialKeypointDetection incl. FeaturePointLocalization: points[POINT_DTYPE]."""
+        n = lib().vo_dog_keypoints(self._p, octave, window, None, 0)
+        pts = np.zeros(n, POINT_DTYPE)
+        if n:
+            lib().vo_dog_keypoints(self._p, octave, window, pts.ctypes.data, n)
+        return pts
 
     def close(self):
         if self._p:

@@ -524,6 +524,112 @@ void vo_extrema_lattice(int rows, int cols, int window, int* lat_rows, int* lat_
     *lat_cols = cols > pad ? (cols - pad + window - 1) / window : 0;
 }
 
+/* (int)float the way the reference's x86-64 build performs it (cvttss2si): out-of-range and NaN
+ * inputs give INT_MIN ("integer indefinite"); the C standard leaves them undefined. */
+static int cvtt_f32_i32(float x) {
+    if (!(x > -2147483904.0f && x < 2147483648.0f)) return INT32_MIN;
+    return (int)x;
+}
+
+/* FeaturePointLocalization, Diff_of_Gauss.cpp:223-251, on the three finite differences it takes
+ * at :226-228 and the candidate's own DoG value.  OpenCV arithmetic as recalled (SURVEY
+ * Appendix B-6, all of it unverifiable here):
+ *   :233  A = (d_x, d_y, d_scale) / 255.0f, three f32 divisions
+ *   :238  B = A * A^T is an outer product: gemm's n == 1 branch rounds each exact product once
+ *   :239  Mat::inv() = cv::invert(DECOMP_LU), closed form for 3x3 CV_32F: determinant by cofactor
+ *         expansion in f64 on the f32 entries; exactly 0 -> all-zero result, otherwise each f64
+ *         cofactor * (1/det) narrowed to f32.  B has rank 1, so whenever one difference is 0 the
+ *         determinant is exactly 0; with three non-zero differences it is rounding noise and the
+ *         "inverse" is large and arbitrary - the reference's behaviour, reproduced as is.
+ *   :239  unary minus: exact
+ *   :240  z_hat = B_inverse * A takes gemm's small-matrix path (len 3 == rows of the result):
+ *         f32 products summed left to right in f32
+ *   :241  0.5f * A_T * z_hat is gemm with alpha 0.5: products and sum in f64, * 0.5 in f64,
+ *         narrowed to f32; then the f32 addition of value / 255.0f
+ *   :245  keep iff dog_zhat > 0.03f; :246 value = (int)(dog_zhat * 255.0f)
+ * Returns 1 and stores the new value if the point is kept, else 0. */
+int vo_feature_point_localization(int d_x, int d_y, int d_scale, int value, int* new_value) {
+    const float a[3] = {(float)d_x / 255.0f, (float)d_y / 255.0f, (float)d_scale / 255.0f};
+    float B[3][3], Bi[3][3];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) B[i][j] = (float)((double)a[i] * (double)a[j]);
+#define M(i, j) ((double)B[i][j])
+    double d = M(0, 0) * (M(1, 1) * M(2, 2) - M(1, 2) * M(2, 1)) - M(0, 1) * (M(1, 0) * M(2, 2) - M(1, 2) * M(2, 0)) +
+               M(0, 2) * (M(1, 0) * M(2, 1) - M(1, 1) * M(2, 0));
+    if (d != 0.) {
+        d = 1. / d;
+        Bi[0][0] = (float)((M(1, 1) * M(2, 2) - M(1, 2) * M(2, 1)) * d);
+        Bi[0][1] = (float)((M(0, 2) * M(2, 1) - M(0, 1) * M(2, 2)) * d);
+        Bi[0][2] = (float)((M(0, 1) * M(1, 2) - M(0, 2) * M(1, 1)) * d);
+        Bi[1][0] = (float)((M(1, 2) * M(2, 0) - M(1, 0) * M(2, 2)) * d);
+        Bi[1][1] = (float)((M(0, 0) * M(2, 2) - M(0, 2) * M(2, 0)) * d);
+        Bi[1][2] = (float)((M(0, 2) * M(1, 0) - M(0, 0) * M(1, 2)) * d);
+        Bi[2][0] = (float)((M(1, 0) * M(2, 1) - M(1, 1) * M(2, 0)) * d);
+        Bi[2][1] = (float)((M(0, 1) * M(2, 0) - M(0, 0) * M(2, 1)) * d);
+        Bi[2][2] = (float)((M(0, 0) * M(1, 1) - M(0, 1) * M(1, 0)) * d);
+    } else {
+        memset(Bi, 0, sizeof Bi);
+    }
+#undef M
+    float z[3];
+    for (int i = 0; i < 3; i++) {
+        float t = (-Bi[i][0]) * a[0];
+        t = t + (-Bi[i][1]) * a[1];
+        t = t + (-Bi[i][2]) * a[2];
+        z[i] = t;
+    }
+    double s = 0.;
+    for (int k = 0; k < 3; k++) s += (double)z[k] * (double)a[k];
+    const float half_quad = (float)(s * 0.5);
+    const float dog_zhat = (float)value / 255.0f + half_quad;
+    if (dog_zhat > 0.03f) {
+        if (new_value) *new_value = cvtt_f32_i32(dog_zhat * 255.0f);
+        return 1;
+    }
+    return 0;
+}
+
+/* initialKeypointDetection as the reference runs it, Diff_of_Gauss.cpp:254-297 including the
+ * FeaturePointLocalization call at :290: the keypoints vector it appends to. */
+size_t vo_dog_keypoints(const vo_pyramid* p, int octave, int window, vo_point* out, size_t cap) {
+    if (!p || octave < 0 || octave >= p->n_octaves || window < 3 || (window & 1) == 0) return 0;
+    int rows = p->rows[octave], cols = p->cols[octave];
+    int padding = (window - 1) / 2;
+    size_t n = 0;
+#define DP(l, u, v) \
+    ((int)p->dog[octave][l][(size_t)clampi((u) - padding, 0, rows - 1) * cols + clampi((v) - padding, 0, cols - 1)])
+    for (int level = 1; level < VO_NUM_DOGS - 1; level++)
+        for (int i = padding; i < rows; i += window)
+            for (int j = padding; j < cols; j += window) {
+                int this_pixel = DP(level, i, j);
+                int mn = 256, mx = -1;
+                for (int u = i - padding; u < i + padding; u++)
+                    for (int v = j - padding; v < j + padding; v++)
+                        for (int l = level - 1; l <= level + 1; l++) {
+                            int t = DP(l, u, v);
+                            if (t < mn) mn = t;
+                            if (t > mx) mx = t;
+                        }
+                if (this_pixel != mn && this_pixel != mx) continue;
+                int d_x = DP(level, i, j - 1) - DP(level, i, j + 1);         /* :226 */
+                int d_y = DP(level, i - 1, j) - DP(level, i + 1, j);         /* :227 */
+                int d_scale = DP(level - 1, i, j) - DP(level + 1, i, j);     /* :228 */
+                int nv;
+                if (!vo_feature_point_localization(d_x, d_y, d_scale, this_pixel, &nv)) continue;
+                if (out && n < cap) {
+                    out[n].row = i;
+                    out[n].col = j;
+                    out[n].value = nv; /* :246 */
+                    out[n].padding = padding;
+                    out[n].octave = octave;
+                    out[n].level = level;
+                }
+                n++;
+            }
+#undef DP
+    return n;
+}
+
 size_t vo_dog_extrema(const vo_pyramid* p, int octave, int window, int min_contrast, uint8_t* mask,
                       vo_point* out, size_t cap) {
     if (!p || octave < 0 || octave >= p->n_octaves || window < 3 || (window & 1) == 0) return 0;

@@ -146,6 +146,13 @@ void vo_extrema_lattice(int rows, int cols, int window, int* lat_rows, int* lat_
 size_t vo_dog_extrema(const vo_pyramid* p, int octave, int window, int min_contrast, uint8_t* mask,
                       vo_point* out, size_t cap);
 
+/* FeaturePointLocalization (Diff_of_Gauss.cpp:223-251) on its three finite differences and
+ * the candidate value; returns 1 (and the value written at :246) when the point is kept. */
+int vo_feature_point_localization(int d_x, int d_y, int d_scale, int value, int* new_value);
+/* initialKeypointDetection including the FeaturePointLocalization call (Diff_of_Gauss.cpp:254-297):
+ * the keypoints the reference appends, in its loop order.  Returns the total; writes <= cap. */
+size_t vo_dog_keypoints(const vo_pyramid* p, int octave, int window, vo_point* out, size_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -45,6 +45,7 @@ def make(name):
         m, pts = p.extrema(o, 3, 8)
         d[f"ext_mask_{o}"] = m
         d[f"ext_pts_{o}"] = pts
+        d[f"kp_pts_{o}"] = p.keypoints(o, 3)  # through FeaturePointLocalization (section 8f row 2)
     return d
 
 

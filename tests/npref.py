@@ -90,3 +90,47 @@ def extrema_mask(dogs, window=3):
         this = P[level][np.ix_(ii, jj)]
         out.append(((this == vals.min(0)) | (this == vals.max(0))).astype(np.uint8))
     return np.stack(out), ii, jj
+
+
+def localize(d_x, d_y, d_s, value):
+    """FeaturePointLocalization (Diff_of_Gauss.cpp:223-251) written with numpy matrices instead
+    of the oracle's unrolled scalars: (keep, new_value).  Same rounding points (SURVEY B-6)."""
+    f32, f64 = np.float32, np.float64
+    a = np.array([d_x, d_y, d_s], f32) / f32(255.0)
+    B = np.outer(a, a).astype(f32)  # f32 * f32 rounded once
+    Bd = B.astype(f64)
+
+    def cof(r0, c0, r1, c1, r2, c2, r3, c3):
+        return Bd[r0, c0] * Bd[r1, c1] - Bd[r2, c2] * Bd[r3, c3]
+
+    det = Bd[0, 0] * cof(1, 1, 2, 2, 1, 2, 2, 1) - Bd[0, 1] * cof(1, 0, 2, 2, 1, 2, 2, 0) + Bd[0, 2] * cof(1, 0, 2, 1, 1, 1, 2, 0)
+    inv = np.zeros((3, 3), f32)
+    if det != 0.0:
+        with np.errstate(all="ignore"):
+            d = f64(1.0) / det
+            # adjugate: inv[i][j] = cofactor(j, i) / det, expanded exactly as cv::invert writes it
+            idx = {
+                (0, 0): (1, 1, 2, 2, 1, 2, 2, 1), (0, 1): (0, 2, 2, 1, 0, 1, 2, 2), (0, 2): (0, 1, 1, 2, 0, 2, 1, 1),
+                (1, 0): (1, 2, 2, 0, 1, 0, 2, 2), (1, 1): (0, 0, 2, 2, 0, 2, 2, 0), (1, 2): (0, 2, 1, 0, 0, 0, 1, 2),
+                (2, 0): (1, 0, 2, 1, 1, 1, 2, 0), (2, 1): (0, 1, 2, 0, 0, 0, 2, 1), (2, 2): (0, 0, 1, 1, 0, 1, 1, 0),
+            }
+            for (i, j), t in idx.items():
+                inv[i, j] = f32(cof(*t) * d)
+    with np.errstate(all="ignore"):
+        ninv = -inv
+        z = np.zeros(3, f32)
+        for i in range(3):
+            t = f32(ninv[i, 0] * a[0])
+            t = f32(t + f32(ninv[i, 1] * a[1]))
+            t = f32(t + f32(ninv[i, 2] * a[2]))
+            z[i] = t
+        s = f64(0.0)
+        for k in range(3):
+            s = s + f64(z[k]) * f64(a[k])
+        zhat = f32(f32(value) / f32(255.0) + f32(s * 0.5))
+        if not zhat > f32(0.03):
+            return False, value
+        x = f32(zhat * f32(255.0))
+    if not (x > -2147483904.0 and x < 2147483648.0):
+        return True, -(2 ** 31)
+    return True, int(x)

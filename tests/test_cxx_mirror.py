@@ -46,7 +46,7 @@ def test_executables_run(built, exe, arg):
     if exe == "Harris":
         assert out["keypoints_stagewise"] == out["keypoints_fused"] > 0
     if exe == "DoG":
-        assert len(out["octaves"]) == 4 and out["keypoints"] > 0
+        assert len(out["octaves"]) == 4 and out["keypoints"] > 0 and out["per_point_mismatch"] == 0
     if exe == "Pyramid_Test":
         assert out["failures"] == 0
 
@@ -75,3 +75,5 @@ def test_cxx_results_match_oracle(built, tmp_path):
     want_oct = [len(pyr.extrema(o, 3, 8)[1]) for o in range(4)]
     got = json.loads(r.stdout.strip().splitlines()[-1])
     assert [o["candidates"] for o in got["octaves"]] == want_oct
+    assert [o["keypoints"] for o in got["octaves"]] == [len(pyr.keypoints(o, 3)) for o in range(4)]
+    assert got["per_point_mismatch"] == 0

@@ -67,6 +67,8 @@ def check_frame(p, L, out, f, img, n_oct):
         for l in range(5):
             assert (block[off + (6 + l) * P: off + (7 + l) * P].reshape(r, c) == want.dog(o, l)).all(), ("dog", o, l)
         wm, wp = want.extrema(o, p.extrema_window, p.min_contrast)
+        if p.localize:  # list = FeaturePointLocalization survivors
+            wp = want.keypoints(o, p.extrema_window)
         lr, lc, wpr = L.lat_rows[o], L.lat_cols[o], L.lat_words[o]
         words = out["extrema_bits"][f][L.bits_offset[o]: L.bits_offset[o] + 3 * lr * wpr].view(np.uint64)
         gm = np.unpackbits(words.view(np.uint8).reshape(3, lr, wpr * 8), axis=-1, bitorder="little")[..., :lc]
@@ -96,6 +98,17 @@ def test_batch_ragged_size_and_small_caps(env):
     p, L, out = run_batch(ctx, torch, frames, n_octaves=2, harris_cap=5, dog_cap=7, min_contrast=0)
     for f in range(2):
         check_frame(p, L, out, f, frames[f], 2)
+
+
+@pytest.mark.parametrize("shape,n_oct,window", [((96, 160), 3, 3), ((75, 131), 2, 3), ((60, 80), 2, 5), ((270, 480), 4, 3)])
+def test_batch_localized_keypoints(env, shape, n_oct, window):
+    # localize=1: dog_points is initialKeypointDetection's real output (fast and generic kernels)
+    ctx, torch = env
+    frames = synth.frames_np(3, *shape, stream_id=11)
+    frames[1] = synth.frame_np(*shape, kind="noise")
+    p, L, out = run_batch(ctx, torch, frames, n_octaves=n_oct, localize=1, extrema_window=window)
+    for f in range(3):
+        check_frame(p, L, out, f, frames[f], n_oct)
 
 
 def test_config1_640x480_plumbing(env):

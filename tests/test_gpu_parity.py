@@ -171,6 +171,9 @@ def check_pyramid(ctx, img, n_oct, sigma0=1.6):
                 gm, gp, n = got.extrema(o, 3, mc)
                 assert same(gm, wm), ("mask", o)
                 assert n == len(wp) and same(gp, wp), ("points", o, mc)
+            wk = want.keypoints(o, 3)
+            gk, nk = got.keypoints(o, 3)
+            assert nk == len(wk) and same(gk, wk), ("localized keypoints", o)
     finally:
         got.close()
         want.close()
@@ -189,6 +192,10 @@ def test_pyramid_other_sigma_and_window(ctx):
     wm, wp = want.extrema(0, 5, 8)  # windowSize 5: pad 2, 4x4x3 window, stride 5
     gm, gp, n = got.extrema(0, 5, 8)
     assert same(gm, wm) and n == len(wp) and same(gp, wp)
+    for o in range(2):
+        wk = want.keypoints(o, 5)
+        gk, nk = got.keypoints(o, 5)
+        assert nk == len(wk) and same(gk, wk)
     with pytest.raises(capi.VslamError):
         got.extrema(0, 4, 8)
     with pytest.raises(capi.VslamError):
@@ -239,6 +246,32 @@ def test_golden_fixtures(ctx, name):
         assert same(np.stack([p.dog(o, l) for l in range(5)]), g[f"dog_{o}"])
         m, pts, cnt = p.extrema(o, 3, 8)
         assert same(m, g[f"ext_mask_{o}"]) and cnt == len(g[f"ext_pts_{o}"]) and same(pts, g[f"ext_pts_{o}"])
+        kp, nk = p.keypoints(o, 3)
+        assert nk == len(g[f"kp_pts_{o}"]) and same(kp, g[f"kp_pts_{o}"])
+
+
+def test_feature_point_localization_bit_exact(ctx):
+    # the singular-matrix contrast test must round like the oracle for
+    # every combination, including the ones whose outcome is rounding noise
+    r = np.arange(-12, 13)
+    grid = np.stack(np.meshgrid(r, r, r, [0, 5, 7, 8, 9, 40, 255], indexing="ij"), -1).reshape(-1, 4)
+    rng = np.random.default_rng(7)
+    rnd = np.concatenate([rng.integers(-255, 256, (200000, 3)), rng.integers(0, 256, (200000, 1))], 1)
+    d = np.concatenate([grid, rnd]).astype(np.int32)
+    keep, val = ctx.localize_points(d)
+    wk = np.zeros(len(d), bool)
+    wv = d[:, 3].copy()
+    for i, (a, b, c, v) in enumerate(d.tolist()):
+        k, nv = oracle.feature_point_localization(a, b, c, v)
+        wk[i] = k
+        if k:
+            wv[i] = nv
+    assert (keep == wk).all(), int((keep != wk).sum())
+    assert (val == wv).all(), int((val != wv).sum())
+    three = (d[:, :3] != 0).all(1)
+    assert 0 < keep[three].sum() < three.sum()  # the noisy branch is exercised both ways
+    k0, v0 = ctx.localize_points(np.zeros((0, 4), np.int32))
+    assert len(k0) == 0 and len(v0) == 0
 
 
 @pytest.mark.parametrize("shape,n_oct", [((40, 56), 2), ((33, 47), 2), ((1, 5), 1)])

@@ -278,3 +278,53 @@ def test_process_gradients_oracle():
     three_four[1, 2], three_four[2, 1] = 3, 4  # centre pixel: gx = 3, gy = 4 -> magnitude 5
     _, _, m, o = oracle.level_gradients(three_four)
     assert m[1, 1] == 5.0 and abs(o[1, 1] - math.degrees(math.atan2(4, 3))) < 0.02
+
+
+def test_feature_point_localization_oracle():
+    # SURVEY section 8f row 2.  Analytic cases: with at most two non-zero differences det(A A^T)
+    # is exactly 0, cv::invert yields zeros, and the test reduces to value/255 > 0.03 <=> value >= 8;
+    # the stored value is (int)((value/255f)*255f), which may lose one count to f32 rounding.
+    fpl = oracle.feature_point_localization
+    for v in range(256):
+        want = int(np.float32(np.float32(v) / np.float32(255)) * np.float32(255))
+        for d in ((0, 0, 0), (9, 0, 0), (0, -200, 31), (255, 0, -255), (-7, 13, 0)):
+            k, nv = fpl(*d, v)
+            assert k == (v >= 8), (d, v)
+            if k:
+                assert nv == want and v - 1 <= nv <= v
+    # three non-zero differences: outcome is rounding noise; pin it against the numpy restatement
+    rng = np.random.default_rng(3)
+    cases = [(a, b, c, v) for a in (-3, 1, 2) for b in (-5, 4) for c in (-1, 6, 90) for v in (0, 7, 8, 30)]
+    cases += [tuple(int(t) for t in rng.integers(-255, 256, 3)) + (int(rng.integers(0, 256)),) for _ in range(3000)]
+    kept = big = 0
+    for a, b, c, v in cases:
+        got = fpl(a, b, c, v)
+        want = npref.localize(a, b, c, v)
+        assert got[0] == want[0] and (not got[0] or got[1] == want[1]), ((a, b, c, v), got, want)
+        kept += got[0]
+        big += got[0] and abs(got[1]) > 255
+    assert 0 < kept < len(cases)
+    # symmetric in the sign of A (B and the quadratic form are even)
+    assert fpl(3, -4, 5, 20) == fpl(-3, 4, -5, 20)
+
+
+def test_dog_keypoints_oracle_consistency():
+    # vo_dog_keypoints = candidate mask sites, in loop order, filtered by the scalar function
+    img = synth.frame_np(45, 62, kind="noise")
+    P = oracle.Pyramid(img, 2, 1.6)
+    for o, window in ((0, 3), (1, 3), (0, 5)):
+        mask, _ = P.extrema(o, window, 0)
+        kp = P.keypoints(o, window)
+        pad = (window - 1) // 2
+        dogs = [np.pad(P.dog(o, l).astype(int), pad, mode="edge") for l in range(5)]
+        want = []
+        for L in range(3):
+            for li, lj in zip(*np.nonzero(mask[L])):
+                i, j, lev = pad + li * window, pad + lj * window, L + 1
+                d = dogs[lev]
+                k, nv = oracle.feature_point_localization(d[i, j - 1] - d[i, j + 1], d[i - 1, j] - d[i + 1, j],
+                                                          dogs[lev - 1][i, j] - dogs[lev + 1][i, j], d[i, j])
+                if k:
+                    want.append((i, j, nv, pad, o, lev))
+        assert [tuple(r) for r in kp.tolist()] == want
+    P.close()

@@ -35,7 +35,7 @@ class Params(C.Structure):
     _fields_ = [
         ("rows", C.c_int), ("cols", C.c_int), ("n_octaves", C.c_int), ("sigma0", C.c_double),
         ("harris_k", C.c_float), ("do_harris", C.c_int), ("extrema_window", C.c_int),
-        ("min_contrast", C.c_int), ("harris_cap", C.c_uint32), ("dog_cap", C.c_uint32),
+        ("min_contrast", C.c_int), ("localize", C.c_int), ("harris_cap", C.c_uint32), ("dog_cap", C.c_uint32),
     ]
 
 
@@ -101,6 +101,8 @@ SIGNATURES = {
     "vslam_pyramid_get_dog": (_I, [_P, _I, _I, _P, _Z]),
     "vslam_pyramid_get_gradients": (_I, [_P, _I, _I, _P, _P, _P, _P, _Z]),
     "vslam_dog_extrema": (_I, [_P, _P, _I, _I, _I, _P, _P, _Z, C.POINTER(_Z)]),
+    "vslam_dog_keypoints": (_I, [_P, _P, _I, _I, _P, _Z, C.POINTER(_Z)]),
+    "vslam_localize_points": (_I, [_P, _P, _Z, _P, _P]),
     "vslam_params_default": (None, [C.POINTER(Params), _I, _I]),
     "vslam_batch_layout_query": (_I, [C.POINTER(Params), C.POINTER(BatchLayout)]),
     "vslam_detect_batch_dev": (_I, [_P, C.POINTER(Params), _P, _Z, _I, C.POINTER(BatchOut)]),
@@ -325,6 +327,16 @@ class Context:
         return out[: min(n.value, cap)], n.value
 
     # ---- DoG
+    def localize_points(self, diffs):
+        """FeaturePointLocalization for n candidates: diffs int32 [n, 4] = (d_x, d_y, d_scale, value)
+        -> (keep bool [n], value int32 [n])."""
+        d = np.ascontiguousarray(diffs, dtype=np.int32).reshape(-1, 4)
+        n = d.shape[0]
+        keep = np.zeros(n, np.int32)
+        val = np.zeros(n, np.int32)
+        self._chk(lib().vslam_localize_points(self._h, d.ctypes.data, n, keep.ctypes.data, val.ctypes.data), "vslam_localize_points")
+        return keep.astype(bool), val
+
     def pyramid(self, img, n_octaves: int = 4, sigma0: float = 1.6):
         return Pyramid(self, img, n_octaves, sigma0)
 
@@ -397,6 +409,13 @@ class Pyramid:
         self.ctx._chk(lib().vslam_dog_extrema(self.ctx._h, self._h, octave, window, min_contrast, bits.ctypes.data, pts.ctypes.data, cap, C.byref(n)), "vslam_dog_extrema")
         mask = np.unpackbits(bits.view(np.uint8), axis=-1, bitorder="little")[..., :lc] if lc else np.zeros((3, lr, 0), np.uint8)
         return mask, pts[: min(n.value, cap)], n.value
+
+    def keypoints(self, octave: int, window: int = 3, cap: int = 1 << 22):
+        """initialKeypointDetection incl. FeaturePointLocalization: (points, total count)."""
+        pts = np.zeros(cap, POINT_DTYPE)
+        n = C.c_size_t()
+        self.ctx._chk(lib().vslam_dog_keypoints(self.ctx._h, self._h, octave, window, pts.ctypes.data, cap, C.byref(n)), "vslam_dog_keypoints")
+        return pts[: min(n.value, cap)], n.value
 
     def close(self):
         if getattr(self, "_h", None):

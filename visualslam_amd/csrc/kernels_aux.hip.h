@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include "kernels_generic.hip.h"
+#include "kernels_localize.hip.h"
 
 namespace vslam {
 
@@ -105,26 +106,40 @@ __device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
 constexpr int EXT_SPAN = 768;            // image columns per workgroup (256 sites x stride 3)
 constexpr int EXT_PITCH = EXT_SPAN + 16; // 16 guard bytes in front: column -1 of the span
 
+// LOC: the list flags are FeaturePointLocalization's verdict (Diff_of_Gauss.cpp:290) instead of
+// the min_contrast threshold; that needs padded (i+1, j) and (i, j+1) of the three middle levels
+// as well, so three more rows (unpadded 3li+1, clamped) are staged: 13 rows, 10 KB.
+template <bool LOC>
 __global__ __launch_bounds__(256) void k_extrema_w3(const uint8_t* __restrict__ pyr, size_t pframe, ExtGeom g, int o,
                                                      unsigned long long* __restrict__ bits,
                                                      unsigned long long* __restrict__ lflags, size_t bframe) {
-    __shared__ __attribute__((aligned(16))) uint8_t srow[10 * EXT_PITCH + 16];  // [level 0..4][row 0..1][EXT_PITCH]
+    constexpr int NROW = LOC ? 13 : 10;
+    __shared__ __attribute__((aligned(16))) uint8_t srow[NROW * EXT_PITCH + 16];  // [level 0..4][row 0..1], then [level 1..3] row 2
+    __shared__ uint2 queue[LOC ? 768 : 1];       // sites whose localization needs the full inverse
+    __shared__ uint8_t qkeep[LOC ? 768 : 1];     // their verdicts, by (level-1)*256 + thread
+    __shared__ unsigned int qn;
+    if (LOC) {
+        if (threadIdx.x == 0) qn = 0;
+        qkeep[threadIdx.x] = 0, qkeep[256 + threadIdx.x] = 0, qkeep[512 + threadIdx.x] = 0;
+    }
     const int li = blockIdx.y, f = blockIdx.z;
     const int rows = g.rows[o], cols = g.cols[o];
     const size_t P = (size_t)rows * cols;
     const uint8_t* dog = pyr + f * pframe + g.oct_off[o] + (size_t)VSLAM_NUM_LEVELS * P;
     const int ya = max(3 * li - 1, 0), yb = 3 * li;  // padded rows i-1, i with i = 1 + 3li -> unpadded 3li-1, 3li
+    const int yc = min(3 * li + 1, rows - 1);        // padded row i+1
     const int c0 = blockIdx.x * EXT_SPAN - 16;       // image column of staged byte 0
-    constexpr int C16 = EXT_PITCH / 16, NV = 10 * C16;  // 49 x 10 sixteen-byte pieces
+    constexpr int C16 = EXT_PITCH / 16, NV = NROW * C16;  // 49 sixteen-byte pieces per staged row
 #pragma unroll
     for (int i = 0; i < (NV + 255) / 256; ++i) {
         const int it = threadIdx.x + 256 * i;
         if (it < NV) {
             const int rl = it / C16, x16 = it - rl * C16;  // rl = level*2 + row
             const int c = c0 + 16 * x16;
+            const int lev = rl < 10 ? (rl >> 1) : rl - 9, y = rl < 10 ? ((rl & 1) ? yb : ya) : yc;
             if (c >= 0 && c < cols)
                 *reinterpret_cast<uint4*>(srow + rl * EXT_PITCH + 16 * x16) =
-                    *reinterpret_cast<const uint4*>(dog + (size_t)(rl >> 1) * P + (size_t)((rl & 1) ? yb : ya) * cols + c);
+                    *reinterpret_cast<const uint4*>(dog + (size_t)lev * P + (size_t)y * cols + c);
         }
     }
     if (blockIdx.x == 0 && threadIdx.x < 10)  // column -1 replicates column 0 (padOctave)
@@ -153,8 +168,46 @@ __global__ __launch_bounds__(256) void k_extrema_w3(const uint8_t* __restrict__ 
         for (int L = 1; L <= 3; ++L) {
             const uint32_t lo = min(mn[L - 1], min(mn[L], mn[L + 1])), hi = max(mx[L - 1], max(mx[L], mx[L + 1]));
             cand[L - 1] = self[L] == lo || self[L] == hi;
-            listed[L - 1] = cand[L - 1] && (int)self[L] >= g.min_contrast;
+            if (!LOC) listed[L - 1] = cand[L - 1] && (int)self[L] >= g.min_contrast;
         }
+        if (LOC) {
+            const int xj = xa + 1;                                            // byte offset of column 3lj
+            const int xr = xj + ((3 * lj + 1 < cols) ? 1 : 0);                // padded (., j+1): replicate at the edge
+#pragma unroll
+            for (int L = 1; L <= 3; ++L) {
+                if (cand[L - 1]) {
+                    const uint8_t* r0 = srow + (2 * L) * EXT_PITCH;           // padded row i-1
+                    const uint8_t* r1 = r0 + EXT_PITCH;                       // padded row i
+                    const uint8_t* r2 = srow + (9 + L) * EXT_PITCH;           // padded row i+1
+                    const int d_x = (int)r1[xa] - (int)r1[xr];                // Diff_of_Gauss.cpp:226
+                    const int d_y = (int)r0[xj] - (int)r2[xj];                // :227
+                    const int d_s = (int)self[L - 1] - (int)self[L + 1];      // :228
+                    if (d_x == 0 || d_y == 0 || d_s == 0) {
+                        int nv;  // exactly singular: the test is value/255 > 0.03f
+                        listed[L - 1] = feature_point_localization(d_x, d_y, d_s, (int)self[L], nv);
+                    } else {
+                        // the f64 closed-form inverse is ~10x the rest of this kernel per call: queue
+                        // the site so that the workgroup evaluates its queue densely afterwards
+                        const unsigned int q = atomicAdd(&qn, 1u);
+                        queue[q] = make_uint2((uint32_t)(d_x + 256) | ((uint32_t)(d_y + 256) << 10) | ((uint32_t)(d_s + 256) << 20),
+                                              self[L] | ((uint32_t)((L - 1) * 256 + threadIdx.x) << 8));
+                    }
+                }
+            }
+        }
+    }
+    if (LOC) {
+        __syncthreads();
+        const unsigned int n = qn;
+        for (unsigned int q = threadIdx.x; q < n; q += 256) {
+            const uint2 e = queue[q];
+            int nv;
+            qkeep[e.y >> 8] = feature_point_localization((int)(e.x & 1023u) - 256, (int)((e.x >> 10) & 1023u) - 256,
+                                                         (int)(e.x >> 20) - 256, (int)(e.y & 255u), nv);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int L = 0; L < 3; ++L) listed[L] = listed[L] || qkeep[L * 256 + threadIdx.x];
     }
 #pragma unroll
     for (int L = 0; L < 3; ++L) {

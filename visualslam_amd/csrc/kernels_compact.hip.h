@@ -130,6 +130,26 @@ struct DogEntries {  // entry = one 64-site word of the (octave, level, lattice 
     }
 };
 
+// localize mode: rewrite the value of every listed point the way FeaturePointLocalization does
+// at Diff_of_Gauss.cpp:246.  One thread per list record (dense, unlike the per-word emit loop).
+// grid = (ceil(cap/256), frames); octaves [o_begin, o_end) only - the list is appended per octave.
+__global__ __launch_bounds__(256) void k_points_localize_value(vslam_point* __restrict__ pts, const unsigned int* __restrict__ counts,
+                                                               unsigned int cap, const uint8_t* __restrict__ pyr, size_t pframe,
+                                                               ExtGeom g, int o_begin, int o_end) {
+    const int f = blockIdx.y;
+    const unsigned int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= min(counts[f], cap)) return;
+    vslam_point& pt = pts[(size_t)f * cap + i];
+    const int o = pt.octave;
+    if (o < o_begin || o >= o_end) return;
+    const size_t P = (size_t)g.rows[o] * g.cols[o];
+    const uint8_t* dog = pyr + f * pframe + g.oct_off[o] + (size_t)VSLAM_NUM_LEVELS * P;
+    int d_x, d_y, d_s, nv;
+    dog_differences(dog, P, g.rows[o], g.cols[o], g.pad, pt.level, pt.row, pt.col, d_x, d_y, d_s);
+    feature_point_localization(d_x, d_y, d_s, pt.value, nv);
+    pt.value = nv;
+}
+
 // Block-wide exclusive scan for 256 threads; `total` = block sum.
 __device__ __forceinline__ unsigned int block_excl_scan_256(unsigned int v, unsigned int* wsum, unsigned int& total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

@@ -6,6 +6,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "kernels_localize.hip.h"
+
 #include <cfloat>
 #include <cstdint>
 
@@ -275,11 +277,23 @@ __global__ __launch_bounds__(256) void k_harris_post(const float* __restrict__ r
 
 struct ExtGeom {
     int n_oct, window, pad, min_contrast;
+    int localize;  // list = FeaturePointLocalization survivors (min_contrast unused)
     int rows[VSLAM_MAX_OCTAVES], cols[VSLAM_MAX_OCTAVES];
     int lat_rows[VSLAM_MAX_OCTAVES], lat_cols[VSLAM_MAX_OCTAVES], wpr[VSLAM_MAX_OCTAVES];
     unsigned long long oct_off[VSLAM_MAX_OCTAVES];   // byte offset of the octave in a pyramid frame block
     unsigned long long bits_off[VSLAM_MAX_OCTAVES];  // word offset of the octave in a bits frame block
 };
+
+// The three finite differences of FeaturePointLocalization (Diff_of_Gauss.cpp:226-228) at padded
+// (i, j) of DoG `level`; padOctave's replicate border = clamped addressing.
+__device__ __forceinline__ void dog_differences(const uint8_t* __restrict__ dog, size_t P, int rows, int cols, int pad,
+                                                int level, int i, int j, int& d_x, int& d_y, int& d_s) {
+    const int r = clampi(i - pad, 0, rows - 1), c = clampi(j - pad, 0, cols - 1);
+    const uint8_t* D = dog + (size_t)level * P;
+    d_x = (int)D[(size_t)r * cols + clampi(j - 1 - pad, 0, cols - 1)] - (int)D[(size_t)r * cols + clampi(j + 1 - pad, 0, cols - 1)];
+    d_y = (int)D[(size_t)clampi(i - 1 - pad, 0, rows - 1) * cols + c] - (int)D[(size_t)clampi(i + 1 - pad, 0, rows - 1) * cols + c];
+    d_s = (int)D[(size_t)r * cols + c - P] - (int)D[(size_t)r * cols + c + P];
+}
 
 // One thread per lattice site; a wave's 64 candidate flags leave as one ballot word, which
 // IS the bitmask layout of include/vslam.h.  blockIdx.z = frame*3 + (level-1).
@@ -310,7 +324,13 @@ __global__ __launch_bounds__(256) void k_extrema(const uint8_t* __restrict__ pyr
         }
         const int self = dog[(size_t)level * P + (size_t)(i - pad) * cols + (j - pad)];
         cand = self == mn || self == mx;
-        listed = cand && self >= g.min_contrast;
+        if (!g.localize) {
+            listed = cand && self >= g.min_contrast;
+        } else if (cand) {
+            int d_x, d_y, d_s, nv;
+            dog_differences(dog, P, rows, cols, pad, level, i, j, d_x, d_y, d_s);
+            listed = feature_point_localization(d_x, d_y, d_s, self, nv);
+        }
     }
     const unsigned long long wc = __ballot(cand), wl = __ballot(listed);
     if ((threadIdx.x & 63) == 0 && (lj >> 6) < g.wpr[o]) {

@@ -80,7 +80,7 @@ static int fail(vslam_ctx* c, int code, const std::string& msg) {
 static const char* const kKernelNames =
     "k_harris_fused\nk_harris_post\nk_resize_linear2x\nk_blur_h_generic\nk_blur_v_generic\n"
     "k_dog5\nk_resize_nearest_half\nk_extrema\nk_pyr_octave\n"
-    "k_gauss_v_strip\nk_gauss_h_strip\nk_resize_linear2x_slide\nk_resize_nearest_half_v4\nk_extrema_w3\n"
+    "k_gauss_v_strip\nk_gauss_h_strip\nk_resize_linear2x_slide\nk_resize_nearest_half_v4\nk_extrema_w3\nk_localize_points\nk_points_localize_value\n"
     "k_harris_strip\nk_flag_count\nk_chunk_scan\nk_flag_scatter\nk_level_gradients";
 
 static std::pair<hipEvent_t, hipEvent_t>* timing_slot(vslam_ctx* c);
@@ -339,6 +339,7 @@ static void fill_geom(const vslam_params& p, const vslam_batch_layout& L, ExtGeo
     g.window = p.extrema_window;
     g.pad = (p.extrema_window - 1) / 2;
     g.min_contrast = p.min_contrast;
+    g.localize = p.localize;
     for (int o = 0; o < L.n_octaves; ++o) {
         g.rows[o] = L.rows[o];
         g.cols[o] = L.cols[o];
@@ -485,10 +486,13 @@ static int enqueue_dog(vslam_ctx* c, const vslam_params& p, const vslam_batch_la
                 HIPCHK(c, hipStreamWaitEvent(side, c->ev_oct[o], 0));
                 es = side;
             }
-            if (p.extrema_window == 3 && cols % 16 == 0)
-                hipLaunchKernelGGL(k_extrema_w3, dim3((L.lat_words[o] + 3) / 4, L.lat_rows[o], nf), dim3(256), 0, es, pyr, pframe, g, o,
-                                   bits, s.lflags, L.bits_frame_words);
-            else
+            if (p.extrema_window == 3 && cols % 16 == 0) {
+                const dim3 eg((L.lat_words[o] + 3) / 4, L.lat_rows[o], nf);
+                if (p.localize)
+                    hipLaunchKernelGGL(k_extrema_w3<true>, eg, dim3(256), 0, es, pyr, pframe, g, o, bits, s.lflags, L.bits_frame_words);
+                else
+                    hipLaunchKernelGGL(k_extrema_w3<false>, eg, dim3(256), 0, es, pyr, pframe, g, o, bits, s.lflags, L.bits_frame_words);
+            } else
                 hipLaunchKernelGGL(k_extrema, dim3((L.lat_cols[o] + 255) / 256, L.lat_rows[o], nf * 3), dim3(256), 0, es, pyr,
                                    pframe, g, o, bits, s.lflags, L.bits_frame_words);
             HIPCHK(c, hipGetLastError());
@@ -499,6 +503,9 @@ static int enqueue_dog(vslam_ctx* c, const vslam_params& p, const vslam_batch_la
             StreamSwap sw(c, side ? side : c->stream);
             DogEntries ent{s.lflags, L.bits_frame_words, pyr, pframe, g, o, o + 1, points};
             TRY(enqueue_compaction(c, ent, (size_t)3 * L.lat_rows[o] * L.lat_words[o], nf, s.cws, p.dog_cap, counts, o > 0 ? 1 : 0));
+            if (p.localize && o == L.n_octaves - 1 && p.dog_cap)
+                LAUNCH(c, "k_points_localize_value", k_points_localize_value, dim3((p.dog_cap + 255) / 256, nf), dim3(256), points, counts,
+                       p.dog_cap, pyr, pframe, g, 0, L.n_octaves);
         }
     }
     return VSLAM_OK;
@@ -990,8 +997,8 @@ int vslam_pyramid_get_gradients(const vslam_pyramid* py, int octave, int level, 
     return vslam_ctx_sync(c);
 }
 
-int vslam_dog_extrema(vslam_ctx* c, const vslam_pyramid* py, int octave, int window, int min_contrast, uint64_t* bits,
-                      vslam_point* out, size_t cap, size_t* count) {
+static int dog_points_host(vslam_ctx* c, const vslam_pyramid* py, int octave, int window, int min_contrast, int localize,
+                           uint64_t* bits, vslam_point* out, size_t cap, size_t* count) {
     TRY(bind_device(c));
     ARGCHK(c, py && py->ctx == c && count && (out || cap == 0), "initialKeypointDetection: bad arguments");
     if (octave < 0 || octave >= py->layout.n_octaves) return fail(c, VSLAM_ERR_RANGE, "octave out of range");
@@ -999,6 +1006,7 @@ int vslam_dog_extrema(vslam_ctx* c, const vslam_pyramid* py, int octave, int win
     vslam_params p = py->params;
     p.extrema_window = window;
     p.min_contrast = min_contrast;
+    p.localize = localize;
     p.dog_cap = (uint32_t)std::min<size_t>(cap, 0x7fffffff);
     vslam_batch_layout L;
     if (make_layout(&p, &L) != VSLAM_OK) return fail(c, VSLAM_ERR_INVALID, "bad extrema parameters");
@@ -1014,10 +1022,21 @@ int vslam_dog_extrema(vslam_ctx* c, const vslam_pyramid* py, int octave, int win
     HIPCHK(c, hipMemsetAsync(d_n, 0, 4, c->stream));
     const size_t ow = (size_t)3 * L.lat_rows[octave] * L.lat_words[octave];
     if (ow) {
-        LAUNCH(c, "k_extrema", k_extrema, dim3((L.lat_cols[octave] + 255) / 256, L.lat_rows[octave], 3), dim3(256),
-               py->d_block, L.pyramid_frame_bytes, g, octave, d_bits, d_lf, words);
+        if (window == 3 && L.cols[octave] % 16 == 0) {
+            const dim3 eg((L.lat_words[octave] + 3) / 4, L.lat_rows[octave], 1);
+            if (localize)
+                LAUNCH(c, "k_extrema_w3", k_extrema_w3<true>, eg, dim3(256), py->d_block, L.pyramid_frame_bytes, g, octave, d_bits, d_lf, words);
+            else
+                LAUNCH(c, "k_extrema_w3", k_extrema_w3<false>, eg, dim3(256), py->d_block, L.pyramid_frame_bytes, g, octave, d_bits, d_lf, words);
+        } else {
+            LAUNCH(c, "k_extrema", k_extrema, dim3((L.lat_cols[octave] + 255) / 256, L.lat_rows[octave], 3), dim3(256),
+                   py->d_block, L.pyramid_frame_bytes, g, octave, d_bits, d_lf, words);
+        }
         DogEntries ent{d_lf, words, py->d_block, L.pyramid_frame_bytes, g, octave, octave + 1, d_pts};
         TRY(enqueue_compaction(c, ent, ow, 1, d_cws, p.dog_cap, d_n, 0));
+        if (localize && p.dog_cap)
+            LAUNCH(c, "k_points_localize_value", k_points_localize_value, dim3((p.dog_cap + 255) / 256, 1), dim3(256), d_pts, d_n, p.dog_cap,
+                   py->d_block, L.pyramid_frame_bytes, g, octave, octave + 1);
     }
     unsigned int n = 0;
     HIPCHK(c, hipMemcpyAsync(&n, d_n, 4, hipMemcpyDeviceToHost, c->stream));
@@ -1027,6 +1046,33 @@ int vslam_dog_extrema(vslam_ctx* c, const vslam_pyramid* py, int octave, int win
     *count = n;
     const size_t m = std::min<size_t>(n, p.dog_cap);
     if (m) HIPCHK(c, hipMemcpy(out, d_pts, m * sizeof(vslam_point), hipMemcpyDeviceToHost));
+    return VSLAM_OK;
+}
+
+int vslam_dog_extrema(vslam_ctx* c, const vslam_pyramid* py, int octave, int window, int min_contrast, uint64_t* bits,
+                      vslam_point* out, size_t cap, size_t* count) {
+    return dog_points_host(c, py, octave, window, min_contrast, 0, bits, out, cap, count);
+}
+
+int vslam_dog_keypoints(vslam_ctx* c, const vslam_pyramid* py, int octave, int window, vslam_point* out, size_t cap,
+                        size_t* count) {
+    return dog_points_host(c, py, octave, window, 0, 1, nullptr, out, cap, count);
+}
+
+int vslam_localize_points(vslam_ctx* c, const int* diffs, size_t n, int* keep, int* value) {
+    TRY(bind_device(c));
+    ARGCHK(c, (diffs && keep && value) || n == 0, "FeaturePointLocalization: bad arguments");
+    ARGCHK(c, n <= 0x7fffffff, "FeaturePointLocalization: too many points");
+    if (n == 0) return VSLAM_OK;
+    TRY(ws_reserve(c, ws_need(16 * n) + ws_need(8 * n)));
+    int4* d_in = ws_take<int4>(c, n);
+    int2* d_out = ws_take<int2>(c, n);
+    HIPCHK(c, hipMemcpyAsync(d_in, diffs, 16 * n, hipMemcpyHostToDevice, c->stream));
+    LAUNCH(c, "k_localize_points", k_localize_points, dim3((unsigned)((n + 255) / 256)), dim3(256), d_in, (int)n, d_out);
+    std::vector<int2> h(n);
+    HIPCHK(c, hipMemcpyAsync(h.data(), d_out, 8 * n, hipMemcpyDeviceToHost, c->stream));
+    TRY(vslam_ctx_sync(c));
+    for (size_t i = 0; i < n; ++i) keep[i] = h[i].x, value[i] = h[i].y;
     return VSLAM_OK;
 }
 

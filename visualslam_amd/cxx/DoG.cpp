@@ -1,5 +1,6 @@
 // Headless counterpart of the reference's `DoG` executable up to the end of the hot path
-// (Diff_of_Gauss.cpp:727-785): build the pyramid, run initialKeypointDetection per octave.
+// (Diff_of_Gauss.cpp:727-785): build the pyramid, run initialKeypointDetection (with its
+// FeaturePointLocalization filter) per octave.
 //   usage: DoG [image.pgm | WxH]
 #include <chrono>
 #include <cstdio>
@@ -18,15 +19,29 @@ int main(int argc, char** argv) {
         GaussPyramid pyramid{img, numOctaves, pyr_sigma};  // :746
         const int windowSize = 3;       // :772
         std::vector<SLAM::point> all;
+        size_t perPointMismatch = 0;
         std::printf("{\"exe\": \"DoG\", \"rows\": %d, \"cols\": %d, \"octaves\": [", img.rows, img.cols);
         for (int octave = 0; octave < pyramid.getNumOctaves(); ++octave) {  // :780
-            std::vector<SLAM::point> keypoints;
+            std::vector<SLAM::point> keypoints, candidates;
             initialKeypointDetection(keypoints, pyramid, octave, windowSize);  // :785
-            std::printf("%s{\"octave\": %d, \"candidates\": %zu}", octave ? ", " : "", octave, keypoints.size());
+            scaleSpaceCandidates(candidates, pyramid, octave, windowSize);
+            std::printf("%s{\"octave\": %d, \"candidates\": %zu, \"keypoints\": %zu}", octave ? ", " : "", octave, candidates.size(),
+                        keypoints.size());
+            if (octave == pyramid.getNumOctaves() - 1) {
+                // the per-point entry point on the coarsest octave must reproduce the fused result
+                std::vector<SLAM::point> all_candidates, one_by_one;
+                scaleSpaceCandidates(all_candidates, pyramid, octave, windowSize, 0);
+                std::vector<Mat> dogs_padded = GaussPyramid::padOctave((windowSize - 1) / 2, pyramid.octaveDiff(octave));  // :260
+                for (auto& pt : all_candidates) FeaturePointLocalization(dogs_padded, one_by_one, pt.level, pt);          // :290
+                perPointMismatch = one_by_one.size() != keypoints.size();
+                for (size_t i = 0; i < one_by_one.size() && !perPointMismatch; ++i)
+                    perPointMismatch += one_by_one[i].row != keypoints[i].row || one_by_one[i].col != keypoints[i].col ||
+                                        one_by_one[i].value != keypoints[i].value || one_by_one[i].level != keypoints[i].level;
+            }
             all.insert(all.end(), keypoints.begin(), keypoints.end());
         }
         const auto t1 = std::chrono::steady_clock::now();
-        std::printf("], \"keypoints\": %zu, \"ms\": %.3f}\n", all.size(), std::chrono::duration<double, std::milli>(t1 - t0).count());
+        std::printf("], \"keypoints\": %zu, \"per_point_mismatch\": %zu, \"ms\": %.3f}\n", all.size(), perPointMismatch, std::chrono::duration<double, std::milli>(t1 - t0).count());
         return 0;
     } catch (const std::exception& e) {
         std::fprintf(stderr, "DoG: %s\n", e.what());

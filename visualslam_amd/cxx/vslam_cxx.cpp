@@ -254,16 +254,46 @@ std::vector<Mat> GaussPyramid::padOctave(int padding, const std::vector<Mat>& im
     return padded;
 }
 
-void initialKeypointDetection(std::vector<SLAM::point>& keypoints, GaussPyramid& pyramid, int octave, int windowSize, int minContrast) {
+template <class F>
+static void append_points(std::vector<SLAM::point>& dst, F&& call) {
     vslam_ctx* c = default_context();
     size_t n = 0;
     std::vector<vslam_point> buf(1 << 16);
-    check(vslam_dog_extrema(c, pyramid.handle(), octave, windowSize, minContrast, nullptr, buf.data(), buf.size(), &n), c, "initialKeypointDetection");
+    check(call(c, buf.data(), buf.size(), &n), c, "initialKeypointDetection");
     if (n > buf.size()) {
         buf.resize(n);
-        check(vslam_dog_extrema(c, pyramid.handle(), octave, windowSize, minContrast, nullptr, buf.data(), buf.size(), &n), c,
-              "initialKeypointDetection");
+        check(call(c, buf.data(), buf.size(), &n), c, "initialKeypointDetection");
     }
     for (size_t i = 0; i < n; ++i)
-        keypoints.emplace_back(buf[i].row, buf[i].col, buf[i].value, buf[i].padding, buf[i].octave, buf[i].level);
+        dst.emplace_back(buf[i].row, buf[i].col, buf[i].value, buf[i].padding, buf[i].octave, buf[i].level);
+}
+
+void initialKeypointDetection(std::vector<SLAM::point>& keypoints, GaussPyramid& pyramid, int octave, int windowSize) {
+    append_points(keypoints, [&](vslam_ctx* c, vslam_point* out, size_t cap, size_t* n) {
+        return vslam_dog_keypoints(c, pyramid.handle(), octave, windowSize, out, cap, n);
+    });
+}
+
+void scaleSpaceCandidates(std::vector<SLAM::point>& candidates, GaussPyramid& pyramid, int octave, int windowSize, int minContrast) {
+    append_points(candidates, [&](vslam_ctx* c, vslam_point* out, size_t cap, size_t* n) {
+        return vslam_dog_extrema(c, pyramid.handle(), octave, windowSize, minContrast, nullptr, out, cap, n);
+    });
+}
+
+bool FeaturePointLocalization(std::vector<cv::Mat>& dogs_padded, std::vector<SLAM::point>& keypoints, int level, SLAM::point& point) {
+    vslam_ctx* c = default_context();
+    if (level < 1 || level + 1 >= (int)dogs_padded.size()) throw vslam::Error(VSLAM_ERR_RANGE, "FeaturePointLocalization: level out of range");
+    const cv::Mat& d = dogs_padded[level];
+    const int i = point.row, j = point.col;
+    if (i < 1 || j < 1 || i + 1 >= d.rows || j + 1 >= d.cols) throw vslam::Error(VSLAM_ERR_RANGE, "FeaturePointLocalization: point outside the padded image");
+    const int q[4] = {(int)d.at<cv::uchar>(i, j - 1) - (int)d.at<cv::uchar>(i, j + 1),                                    // :226
+                      (int)d.at<cv::uchar>(i - 1, j) - (int)d.at<cv::uchar>(i + 1, j),                                    // :227
+                      (int)dogs_padded[level - 1].at<cv::uchar>(i, j) - (int)dogs_padded[level + 1].at<cv::uchar>(i, j),  // :228
+                      point.value};
+    int keep = 0, value = point.value;
+    check(vslam_localize_points(c, q, 1, &keep, &value), c, "FeaturePointLocalization");
+    if (!keep) return false;
+    point.value = value;  // :246
+    keypoints.emplace_back(point);
+    return true;
 }

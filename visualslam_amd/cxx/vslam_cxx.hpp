@@ -9,6 +9,7 @@
 //   class GaussPyramid                                         include/src/GaussPyramid/GaussPyramid.hpp:14
 //   struct SLAM::point                                         Diff_of_Gauss.cpp:27
 //   void initialKeypointDetection(std::vector<SLAM::point>&, GaussPyramid&, int, int)
+//   bool FeaturePointLocalization(std::vector<Mat>&, std::vector<SLAM::point>&, int, SLAM::point&)
 //                                                              Diff_of_Gauss.cpp:254
 // plus the OpenCV calls on the path (vslamcv::GaussianBlur / Sobel / convertScaleAbs / resize).
 // StructureMatrix (:10) is a per-pixel helper used only inside HarrisCorner and is subsumed by
@@ -102,9 +103,16 @@ private:
     const std::vector<cv::Mat>& grads(int octave, int kind);
 };
 
-// Appends the scale-space extrema candidates of one octave in the reference's loop order.
-// The reference filters each candidate through FeaturePointLocalization (a "next" row); here
-// candidates with DoG value >= minContrast are appended (8 reproduces the
-// degenerate-case contrast test 0.03*255).
-void initialKeypointDetection(std::vector<SLAM::point>& keypoints, GaussPyramid& pyramid, int octave, int windowSize,
-                              int minContrast = 8);
+// void initialKeypointDetection(...), Diff_of_Gauss.cpp:254-297, as the reference runs it: every
+// lattice candidate goes through FeaturePointLocalization (:290) and the survivors are appended
+// in the reference's loop order with the value rewritten at :246 (vslam_dog_keypoints).
+void initialKeypointDetection(std::vector<SLAM::point>& keypoints, GaussPyramid& pyramid, int octave, int windowSize);
+// The candidate stage alone (up to :287): candidates with DoG value >= minContrast (SURVEY 8a;
+// 8 = the contrast test for the degenerate, exactly-singular cases).
+void scaleSpaceCandidates(std::vector<SLAM::point>& candidates, GaussPyramid& pyramid, int octave, int windowSize,
+                          int minContrast = 8);
+// bool FeaturePointLocalization(...), Diff_of_Gauss.cpp:223-251: reads the three finite
+// differences from the padded DoG stack (:226-228) on the host, evaluates the contrast test on
+// the GPU (vslam_localize_points), updates point.value and appends the point when kept.
+bool FeaturePointLocalization(std::vector<cv::Mat>& dogs_padded, std::vector<SLAM::point>& keypoints, int level,
+                              SLAM::point& point);
