@@ -199,6 +199,25 @@ int vslam_dog_keypoints(vslam_ctx* ctx, const vslam_pyramid* pyr, int octave, in
  * return value, value[i] = point.value afterwards (unchanged when not kept). */
 int vslam_localize_points(vslam_ctx* ctx, const int* diffs, size_t n, int* keep, int* value);
 
+/* void filterKeypoints(GaussPyramid&, int octave, vector<SLAM::point>& keypoints,
+ * vector<SLAM::point>& reducedKeypoints), Diff_of_Gauss.cpp:301-372, with computeEdgeResponse
+ * (:79-109) and orientationHistogram (:112-133): edge rejection tr^2/det < 12.1 on the level's
+ * Sobel gradients, then the 36-bin histogram of the 16x16 window of the 8-padded magnitude /
+ * orientation images, magnitudes weighted by GaussianBlur(sigma = 1.5 * sigma(octave, level))
+ * evaluated as the reference does on a non-isolated ROI (parent pixels, reflect-101 at the
+ * parent's edge).  kps: the octave's keypoints (vslam_dog_keypoints output: 1-padded
+ * coordinates, level 1..3).  out: one SLAM::point{row, col, angle = bin*10, 0, octave, level}
+ * per histogram bin above 0.8 * max, in keypoint order then ascending bin.  *count = total
+ * (may exceed cap).  A keypoint the reference would throw on (level outside 0..5, window
+ * outside the padded image, other octave) gives VSLAM_ERR_RANGE. */
+int vslam_filter_keypoints(vslam_ctx* ctx, const vslam_pyramid* pyr, int octave, const vslam_point* kps, size_t n,
+                           vslam_point* out, size_t cap, size_t* count);
+/* float computeEdgeResponse(const SLAM::point&, const Mat& grad_x, const Mat& grad_y),
+ * Diff_of_Gauss.cpp:79-109, for n points whose gradient windows the caller has gathered in the
+ * reference's loop order (:93-94): gx_windows / gy_windows = n x window_elems f32. */
+int vslam_edge_response_windows(vslam_ctx* ctx, const float* gx_windows, const float* gy_windows, int window_elems,
+                                size_t n, float* response);
+
 /* ------------------------------------------- device-resident batched detection */
 
 typedef struct {

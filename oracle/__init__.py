@@ -103,8 +103,30 @@ def lib():
         L.vo_feature_point_localization.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
         L.vo_dog_keypoints.argtypes = [C.POINTER(_Pyr), C.c_int, C.c_int, C.c_void_p, C.c_size_t]
         L.vo_dog_keypoints.restype = C.c_size_t
+        L.vo_gauss_ksize_f32.argtypes = [C.c_double]
+        L.vo_gauss_kernel_f32.argtypes = [C.c_int, C.c_double, C.c_void_p]
+        L.vo_compute_edge_response.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_int]
+        L.vo_compute_edge_response.restype = C.c_float
+        L.vo_filter_keypoints.argtypes = [C.POINTER(_Pyr), C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        L.vo_filter_keypoints.restype = C.c_size_t
         _lib = L
     return _lib
+
+
+def gauss_ksize_f32(sigma):
+    return lib().vo_gauss_ksize_f32(float(sigma))
+
+
+def gauss_kernel_f32(n, sigma):
+    k = np.zeros(n, np.float32)
+    if lib().vo_gauss_kernel_f32(n, float(sigma), k.ctypes.data) != 0:
+        raise ValueError("bad kernel size")
+    return k
+
+
+def compute_edge_response(gx, gy, row, col, padding=1):
+    gx, gy = _f32(gx), _f32(gy)
+    return float(lib().vo_compute_edge_response(gx.ctypes.data, gy.ctypes.data, gx.shape[0], gx.shape[1], gx.shape[1], row, col, padding))
 
 
 def feature_point_localization(d_x, d_y, d_scale, value):
@@ -301,6 +323,17 @@ class Pyramid:
         if n:
             lib().vo_dog_keypoints(self._p, octave, window, pts.ctypes.data, n)
         return pts
+
+    def filter_keypoints(self, octave, kps):
+        """filterKeypoints for one octave: oriented keypoints[POINT_DTYPE] (value = angle in degrees)."""
+        kps = np.ascontiguousarray(kps, dtype=POINT_DTYPE)
+        n = lib().vo_filter_keypoints(self._p, octave, kps.ctypes.data, len(kps), None, 0)
+        if n == C.c_size_t(-1).value:
+            raise ValueError("filterKeypoints: keypoint outside the pyramid data")
+        out = np.zeros(n, POINT_DTYPE)
+        if n:
+            lib().vo_filter_keypoints(self._p, octave, kps.ctypes.data, len(kps), out.ctypes.data, n)
+        return out
 
     def close(self):
         if self._p:

@@ -39,10 +39,7 @@ int vo_gauss_ksize_u8(double sigma) { return (int)cv_round(sigma * 3 * 2 + 1) | 
 
 /* getGaussianKernelBitExact + getGaussianKernelFixedPoint_ED (OpenCV >= 4.5.1
  * smooth.dispatch.cpp), double arithmetic with libm exp instead of softfloat. */
-int vo_gauss_taps_q8(int n, double sigma, uint16_t* taps) {
-    if (n <= 0 || (n & 1) == 0 || n > 4096) return -1;
-    double* kf = (double*)malloc(sizeof(double) * (size_t)n);
-    if (!kf) return -1;
+static void gauss_kernel_f64(int n, double sigma, double* kf) {
     int n2 = (n - 1) / 2;
     if (sigma <= 0 && n == 1) {
         kf[0] = 1.0;
@@ -77,6 +74,26 @@ int vo_gauss_taps_q8(int n, double sigma, uint16_t* taps) {
         }
         kf[n2] = 1.0 * mul1;
     }
+}
+
+int vo_gauss_ksize_f32(double sigma) { return (int)cv_round(sigma * 4 * 2 + 1) | 1; }
+
+/* getGaussianKernel(n, sigma, CV_32F): the bit-exact f64 kernel narrowed to f32. */
+int vo_gauss_kernel_f32(int n, double sigma, float* k) {
+    if (n <= 0 || (n & 1) == 0 || n > (1 << 20) || !k) return -1;
+    double* kf = (double*)malloc(sizeof(double) * (size_t)n);
+    if (!kf) return -1;
+    gauss_kernel_f64(n, sigma, kf);
+    for (int i = 0; i < n; i++) k[i] = (float)kf[i];
+    free(kf);
+    return 0;
+}
+
+int vo_gauss_taps_q8(int n, double sigma, uint16_t* taps) {
+    if (n <= 0 || (n & 1) == 0 || n > 4096) return -1;
+    double* kf = (double*)malloc(sizeof(double) * (size_t)n);
+    if (!kf) return -1;
+    gauss_kernel_f64(n, sigma, kf);
     /* error diffusion from the outermost tap inwards; centre takes the remainder */
     double err = 0.0;
     long isum = 0;
@@ -587,6 +604,162 @@ int vo_feature_point_localization(int d_x, int d_y, int d_scale, int value, int*
         return 1;
     }
     return 0;
+}
+
+/* computeEdgeResponse, Diff_of_Gauss.cpp:79-109: f32 sums of gradient products over the
+ * half-open window [y-p, y+p) x [x-p, x+p) of the UNPADDED gradient images addressed with the
+ * keypoint's PADDED coordinates (:93-94; Appendix B), cv::determinant of the 2x2 CV_32F matrix
+ * (f64 products, :105), cv::trace (f64 sum, :106), tr*tr/det in f32 (:107).  With the
+ * reference's windowSize 3 every access is inside the image; for larger paddings the reference
+ * reads out of bounds, which is clamped here. */
+float vo_compute_edge_response(const float* gx, const float* gy, int rows, int cols, size_t step_elems, int row,
+                               int col, int padding) {
+    float Ix2 = 0, Iy2 = 0, IxIy = 0;
+    for (int u = row - padding; u < row + padding; u++)
+        for (int v = col - padding; v < col + padding; v++) {
+            const size_t o = (size_t)clampi(u, 0, rows - 1) * step_elems + clampi(v, 0, cols - 1);
+            Ix2 += gx[o] * gx[o];
+            Iy2 += gy[o] * gy[o];
+            IxIy += gx[o] * gy[o];
+        }
+    const float det = (float)((double)Ix2 * (double)Iy2 - (double)IxIy * (double)IxIy);
+    const float tr = (float)(0.0 + (double)Ix2 + (double)Iy2);
+    return (tr * tr) / det;
+}
+
+/* GaussianBlur(roi, dst, Size(0,0), sigma, 0, BORDER_DEFAULT) on a CV_32F window that is a ROI
+ * of a larger Mat (Diff_of_Gauss.cpp:341-348).  BORDER_ISOLATED is not set, so pixels outside the
+ * window come from the parent and reflect-101 applies at the PARENT's edges.  Separable f32
+ * filter in OpenCV's order: row filter s = k[0]*S[0]; s += k[i]*S[i] left to right; symmetric
+ * column filter s = k[c]*S[0]; s += k[c+i]*(S[+i] + S[-i]) (mul and add rounded separately: SSE
+ * baseline; an AVX2/FMA3 dispatch would fuse them - unverifiable here). */
+static int blur_f32_roi(const float* parent, int prows, int pcols, int x0, int y0, int w, int h, const float* k,
+                        int n, float* dst) {
+    const int R = n / 2;
+    float* rb = (float*)malloc(sizeof(float) * (size_t)(h + 2 * R) * (size_t)w);
+    int* cx = (int*)malloc(sizeof(int) * (size_t)(w + 2 * R));
+    if (!rb || !cx) {
+        free(rb);
+        free(cx);
+        return -1;
+    }
+    for (int i = 0; i < w + 2 * R; i++) cx[i] = vo_reflect101(x0 + i - R, pcols);
+    for (int rr = 0; rr < h + 2 * R; rr++) {
+        const float* S = parent + (size_t)vo_reflect101(y0 + rr - R, prows) * pcols;
+        for (int c = 0; c < w; c++) {
+            float s0 = k[0] * S[cx[c]];
+            for (int i = 1; i < n; i++) s0 += k[i] * S[cx[c + i]];
+            rb[(size_t)rr * w + c] = s0;
+        }
+    }
+    for (int r = 0; r < h; r++)
+        for (int c = 0; c < w; c++) {
+            float s0 = k[R] * rb[(size_t)(r + R) * w + c];
+            for (int i = 1; i <= R; i++) s0 += k[R + i] * (rb[(size_t)(r + R + i) * w + c] + rb[(size_t)(r + R - i) * w + c]);
+            dst[(size_t)r * w + c] = s0;
+        }
+    free(rb);
+    free(cx);
+    return 0;
+}
+
+static float* pad_replicate_f32(const float* img, int rows, int cols, int pad) {
+    const int pr = rows + 2 * pad, pc = cols + 2 * pad;
+    float* o = (float*)malloc(sizeof(float) * (size_t)pr * pc);
+    if (!o) return NULL;
+    for (int r = 0; r < pr; r++)
+        for (int c = 0; c < pc; c++)
+            o[(size_t)r * pc + c] = img[(size_t)clampi(r - pad, 0, rows - 1) * cols + clampi(c - pad, 0, cols - 1)];
+    return o;
+}
+
+/* filterKeypoints, Diff_of_Gauss.cpp:301-372 (+ orientationHistogram :112-133): edge rejection
+ * tr^2/det < 12.1 on the level's Sobel gradients, then the 36-bin orientation histogram of the
+ * 16x16 window Rect(x, y, 16, 16) of the 8-padded magnitude / orientation images, magnitudes
+ * weighted by GaussianBlur(sigma = 1.5 * sigma(octave, level)); every bin above 0.8 * max
+ * appends SLAM::point{y, x, bin*10, 0, octave, level}.  Returns the total (writes <= cap), or
+ * (size_t)-1 for a keypoint the reference could not process (level / window outside the data). */
+size_t vo_filter_keypoints(const vo_pyramid* p, int octave, const vo_point* kps, size_t n, vo_point* out, size_t cap) {
+    if (!p || octave < 0 || octave >= p->n_octaves || (!kps && n)) return (size_t)-1;
+    const int rows = p->rows[octave], cols = p->cols[octave];
+    const int windowSize = 16, padding = windowSize / 2; /* :304-305 */
+    const size_t P = (size_t)rows * cols;
+    float *gx[VO_NUM_LEVELS] = {0}, *gy[VO_NUM_LEVELS] = {0}, *pmag[VO_NUM_LEVELS] = {0}, *porient[VO_NUM_LEVELS] = {0};
+    float* kern[VO_NUM_LEVELS] = {0};
+    int kn[VO_NUM_LEVELS] = {0};
+    size_t total = 0;
+    int bad = 0;
+    const float r = 10.0f, threshold = ((r + 1.0f) * (r + 1.0f)) / r; /* :331-332 */
+    const int size = 36;                                              /* :352 */
+    const float reductionCoeff = (float)size / 360.0f;                /* :114 */
+    for (size_t q = 0; q < n && !bad; q++) {
+        const int x = kps[q].col, y = kps[q].row, level = kps[q].level;
+        if (level < 0 || level >= VO_NUM_LEVELS || x < 0 || y < 0 || x > cols || y > rows || kps[q].octave != octave) {
+            bad = 1; /* vector::at / Rect outside the padded Mat: the reference throws */
+            break;
+        }
+        if (!gx[level]) { /* processGradients for this level (GaussPyramid.cpp:65-104), padOctave (:322-323) */
+            gx[level] = (float*)malloc(4 * P);
+            gy[level] = (float*)malloc(4 * P);
+            float* mag = (float*)malloc(4 * P);
+            float* ori = (float*)malloc(4 * P);
+            if (!gx[level] || !gy[level] || !mag || !ori) abort();
+            vo_level_gradients(p->gauss[octave][level], rows, cols, (size_t)cols, gx[level], gy[level], mag, ori, 4 * (size_t)cols);
+            pmag[level] = pad_replicate_f32(mag, rows, cols, padding);
+            porient[level] = pad_replicate_f32(ori, rows, cols, padding);
+            free(mag);
+            free(ori);
+            const double sigma = 1.5 * p->sigma[octave][level]; /* :346 */
+            kn[level] = vo_gauss_ksize_f32(sigma);
+            kern[level] = (float*)malloc(4 * (size_t)kn[level]);
+            if (!pmag[level] || !porient[level] || !kern[level]) abort();
+            vo_gauss_kernel_f32(kn[level], sigma, kern[level]);
+        }
+        const float response = vo_compute_edge_response(gx[level], gy[level], rows, cols, (size_t)cols, y, x, kps[q].padding);
+        if (!(response < threshold)) continue; /* :335 */
+        float magWeighted[16 * 16];
+        if (blur_f32_roi(pmag[level], rows + 2 * padding, cols + 2 * padding, x, y, windowSize, windowSize, kern[level], kn[level],
+                         magWeighted) != 0)
+            abort();
+        float histo[36];
+        for (int b = 0; b < size; b++) histo[b] = 0.0f;
+        const int pc = cols + 2 * padding;
+        for (int i = 0; i < windowSize && !bad; i++)
+            for (int j = 0; j < windowSize; j++) {
+                const float orientation = porient[level][(size_t)(y + i) * pc + (x + j)];
+                const int index = (int)(orientation * reductionCoeff); /* :126 */
+                if (index < 0 || index >= size) {
+                    bad = 1; /* histo.at(index) throws */
+                    break;
+                }
+                histo[index] += magWeighted[i * windowSize + j];
+            }
+        if (bad) break;
+        float maxPeak = histo[0];
+        for (int b = 1; b < size; b++)
+            if (histo[b] > maxPeak) maxPeak = histo[b];
+        const float peakThreshold = maxPeak * 0.8f; /* :358 */
+        for (int b = 0; b < size; b++)
+            if (histo[b] > peakThreshold) { /* :362 */
+                if (out && total < cap) {
+                    out[total].row = y;
+                    out[total].col = x;
+                    out[total].value = b * 10;
+                    out[total].padding = 0;
+                    out[total].octave = kps[q].octave;
+                    out[total].level = level;
+                }
+                total++;
+            }
+    }
+    for (int l = 0; l < VO_NUM_LEVELS; l++) {
+        free(gx[l]);
+        free(gy[l]);
+        free(pmag[l]);
+        free(porient[l]);
+        free(kern[l]);
+    }
+    return bad ? (size_t)-1 : total;
 }
 
 /* initialKeypointDetection as the reference runs it, Diff_of_Gauss.cpp:254-297 including the

@@ -146,6 +146,16 @@ void vo_extrema_lattice(int rows, int cols, int window, int* lat_rows, int* lat_
 size_t vo_dog_extrema(const vo_pyramid* p, int octave, int window, int min_contrast, uint8_t* mask,
                       vo_point* out, size_t cap);
 
+/* Automatic kernel width for CV_32F input (cvRound(sigma*4*2+1)|1) and getGaussianKernel(n, sigma, CV_32F). */
+int vo_gauss_ksize_f32(double sigma);
+int vo_gauss_kernel_f32(int n, double sigma, float* k);
+/* computeEdgeResponse, Diff_of_Gauss.cpp:79-109 (tr^2/det of the 2x2 gradient-product sums). */
+float vo_compute_edge_response(const float* gx, const float* gy, int rows, int cols, size_t step_elems, int row,
+                               int col, int padding);
+/* filterKeypoints + orientationHistogram, Diff_of_Gauss.cpp:301-372,112-133, for one octave's
+ * keypoints (output of vo_dog_keypoints).  Returns the total, or (size_t)-1 on invalid keypoints. */
+size_t vo_filter_keypoints(const vo_pyramid* p, int octave, const vo_point* kps, size_t n, vo_point* out, size_t cap);
+
 /* FeaturePointLocalization (Diff_of_Gauss.cpp:223-251) on its three finite differences and
  * the candidate value; returns 1 (and the value written at :246) when the point is kept. */
 int vo_feature_point_localization(int d_x, int d_y, int d_scale, int value, int* new_value);

@@ -46,6 +46,7 @@ def make(name):
         d[f"ext_mask_{o}"] = m
         d[f"ext_pts_{o}"] = pts
         d[f"kp_pts_{o}"] = p.keypoints(o, 3)  # through FeaturePointLocalization (section 8f row 2)
+        d[f"oriented_pts_{o}"] = p.filter_keypoints(o, d[f"kp_pts_{o}"])  # filterKeypoints (row 3)
     return d
 
 

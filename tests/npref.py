@@ -134,3 +134,59 @@ def localize(d_x, d_y, d_s, value):
     if not (x > -2147483904.0 and x < 2147483648.0):
         return True, -(2 ** 31)
     return True, int(x)
+
+
+def filter_keypoints(gauss_level, kps_level, sigma_blur, kernel_f32):
+    """filterKeypoints (Diff_of_Gauss.cpp:301-372) for the keypoints of ONE Gaussian level, written
+    with whole-array numpy operations: gradients -> padded magnitude/orientation -> per-keypoint
+    window blur taken from np.pad(reflect) of the padded parent -> histogram -> peaks.
+    kps_level: iterable of (row, col, padding); returns [(row, col, angle)]."""
+    import oracle  # gradients only (tested on their own); the filtering below is independent
+
+    f32 = np.float32
+    gx, gy, mag, ori = oracle.level_gradients(gauss_level)
+    pmag = np.pad(mag, 8, mode="edge")
+    pori = np.pad(ori, 8, mode="edge")
+    k = np.asarray(kernel_f32, f32)
+    n = len(k)
+    R = n // 2
+    out = []
+    for (y, x, p) in kps_level:
+        ru = np.clip(np.arange(y - p, y + p), 0, gx.shape[0] - 1)  # out-of-image reads clamped, like the oracle
+        cv = np.clip(np.arange(x - p, x + p), 0, gx.shape[1] - 1)
+        win_x = gx[np.ix_(ru, cv)]
+        win_y = gy[np.ix_(ru, cv)]
+        ix2 = iy2 = ixy = f32(0)
+        for a, b in zip(win_x.ravel(), win_y.ravel()):
+            ix2 = f32(ix2 + f32(a * a))
+            iy2 = f32(iy2 + f32(b * b))
+            ixy = f32(ixy + f32(a * b))
+        with np.errstate(all="ignore"):
+            det = f32(np.float64(ix2) * np.float64(iy2) - np.float64(ixy) * np.float64(ixy))
+            tr = f32(np.float64(ix2) + np.float64(iy2))
+            resp = f32(f32(tr * tr) / det)
+        if not resp < f32(12.1):
+            continue
+        # parent rows/cols the window's blur touches, reflect-101 at the parent's edges
+        ext = pmag
+        while ext.shape[0] < pmag.shape[0] + 2 * R or ext.shape[1] < pmag.shape[1] + 2 * R:
+            pr = min(R - (ext.shape[0] - pmag.shape[0]) // 2, ext.shape[0] - 1)
+            pc = min(R - (ext.shape[1] - pmag.shape[1]) // 2, ext.shape[1] - 1)
+            ext = np.pad(ext, ((max(pr, 0),) * 2, (max(pc, 0),) * 2), mode="reflect")
+        oy = (ext.shape[0] - pmag.shape[0]) // 2
+        ox = (ext.shape[1] - pmag.shape[1]) // 2
+        strip = ext[oy + y - R: oy + y + 16 + R, ox + x - R: ox + x + 16 + R]
+        rowf = (k[0] * strip[:, 0:16]).astype(f32)
+        for i in range(1, n):
+            rowf = (rowf + (k[i] * strip[:, i:i + 16]).astype(f32)).astype(f32)
+        colf = (k[R] * rowf[R:R + 16]).astype(f32)
+        for i in range(1, R + 1):
+            colf = (colf + (k[R + i] * (rowf[R + i:R + i + 16] + rowf[R - i:R - i + 16]).astype(f32)).astype(f32)).astype(f32)
+        histo = np.zeros(36, f32)
+        wo = pori[y:y + 16, x:x + 16]
+        for i in range(16):
+            for j in range(16):
+                histo[int(f32(wo[i, j] * f32(f32(36) / f32(360))))] += colf[i, j]
+        thr = f32(histo.max() * f32(0.8))
+        out += [(y, x, 10 * b) for b in range(36) if histo[b] > thr]
+    return out

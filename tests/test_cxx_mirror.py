@@ -76,4 +76,5 @@ def test_cxx_results_match_oracle(built, tmp_path):
     got = json.loads(r.stdout.strip().splitlines()[-1])
     assert [o["candidates"] for o in got["octaves"]] == want_oct
     assert [o["keypoints"] for o in got["octaves"]] == [len(pyr.keypoints(o, 3)) for o in range(4)]
+    assert [o["oriented"] for o in got["octaves"]] == [len(pyr.filter_keypoints(o, pyr.keypoints(o, 3))) for o in range(4)]
     assert got["per_point_mismatch"] == 0

@@ -248,6 +248,8 @@ def test_golden_fixtures(ctx, name):
         assert same(m, g[f"ext_mask_{o}"]) and cnt == len(g[f"ext_pts_{o}"]) and same(pts, g[f"ext_pts_{o}"])
         kp, nk = p.keypoints(o, 3)
         assert nk == len(g[f"kp_pts_{o}"]) and same(kp, g[f"kp_pts_{o}"])
+        fk, nf = p.filter_keypoints(o, kp)
+        assert nf == len(g[f"oriented_pts_{o}"]) and same(fk, g[f"oriented_pts_{o}"])
 
 
 def test_feature_point_localization_bit_exact(ctx):
@@ -272,6 +274,54 @@ def test_feature_point_localization_bit_exact(ctx):
     assert 0 < keep[three].sum() < three.sum()  # the noisy branch is exercised both ways
     k0, v0 = ctx.localize_points(np.zeros((0, 4), np.int32))
     assert len(k0) == 0 and len(v0) == 0
+
+
+@pytest.mark.parametrize("shape,n_oct,kind", [((96, 160), 3, "noise"), ((75, 131), 2, "noise"), ((48, 64), 3, "checker"), ((135, 240), 4, "noise"), ((20, 24), 2, "noise")])
+def test_filter_keypoints_bit_exact(ctx, shape, n_oct, kind):
+    # edge rejection + blurred-magnitude orientation histogram; the list
+    # (positions, angles, order) must equal the oracle's.  Small images make the 1.5*sigma blur
+    # kernels wider than the padded image (multiple reflections).
+    img = frame(shape, kind, 6)
+    want, got = oracle.Pyramid(img, n_oct, 1.6), ctx.pyramid(img, n_oct, 1.6)
+    total = 0
+    for o in range(n_oct):
+        kp = want.keypoints(o, 3)
+        w = want.filter_keypoints(o, kp)
+        g, n = got.filter_keypoints(o, kp)
+        assert n == len(w) and same(g, w), (o, n, len(w))
+        g2, n2 = got.filter_keypoints(o, kp, cap=3)
+        assert n2 == len(w) and same(g2, w[:3])
+        total += n
+        # synthetic keypoints at the corners / edges of the padded coordinate range, all six levels
+        r, c = want.sizes[o]
+        extra = np.zeros(12, capi.POINT_DTYPE)
+        for i, (y, x) in enumerate([(0, 0), (r, c), (0, c), (r, 0), (1, 1), (r - 1, c - 1), (r // 2, 0), (0, c // 2), (r // 2, c // 2), (1, c), (r, 1), (2, 3)]):
+            extra[i] = (y, x, 50, 1, o, i % 6)
+        w = want.filter_keypoints(o, extra)
+        g, n = got.filter_keypoints(o, extra)
+        assert n == len(w) and same(g, w), ("extra", o)
+    assert total > 0 or kind == "checker"
+    e, n = got.filter_keypoints(0, np.zeros(0, capi.POINT_DTYPE))
+    assert n == 0 and len(e) == 0
+    bad = np.zeros(1, capi.POINT_DTYPE)
+    bad[0] = (1, 1, 0, 1, 0, 6)
+    with pytest.raises(capi.VslamError):
+        got.filter_keypoints(0, bad)
+    with pytest.raises(ValueError):
+        want.filter_keypoints(0, bad)
+    got.close()
+
+
+def test_edge_response_windows(ctx):
+    rng = np.random.default_rng(5)
+    gx = rng.integers(-255, 256, (5000, 4)).astype(np.float32)
+    gy = rng.integers(-255, 256, (5000, 4)).astype(np.float32)
+    gx[:50] = 0
+    gy[50:100] = gx[50:100]  # singular: det == 0 -> inf / nan
+    got = ctx.edge_response_windows(gx, gy)
+    want = np.array([oracle.compute_edge_response(a.reshape(2, 2), b.reshape(2, 2), 1, 1, 1) for a, b in zip(gx, gy)], np.float32)
+    assert got.tobytes() == want.tobytes()
+    assert not np.isfinite(got[:100]).any()  # tr^2 / 0
 
 
 @pytest.mark.parametrize("shape,n_oct", [((40, 56), 2), ((33, 47), 2), ((1, 5), 1)])

@@ -328,3 +328,52 @@ def test_dog_keypoints_oracle_consistency():
                     want.append((i, j, nv, pad, o, lev))
         assert [tuple(r) for r in kp.tolist()] == want
     P.close()
+
+
+def test_filter_keypoints_oracle():
+    # SURVEY section 8f row 3.  The C oracle against the whole-array numpy restatement
+    # (np.pad(mode="reflect") of the replicate-padded parent = the non-isolated ROI blur), on
+    # images small enough that the blur kernel exceeds the padded image at the coarse octave.
+    assert oracle.gauss_ksize_f32(1.5 * 1.6 * 2 ** (1 / 3)) == 25 and oracle.gauss_ksize_f32(1.5 * 12.8 * 4) == 615
+    k = oracle.gauss_kernel_f32(25, 3.0238105197476964)
+    assert k.dtype == np.float32 and (k == k[::-1]).all() and abs(float(k.astype(np.float64).sum()) - 1) < 1e-6 and k.argmax() == 12
+    img = synth.frame_np(40, 52, kind="noise")
+    P = oracle.Pyramid(img, 2, 1.6)
+    n_out = 0
+    for o in range(2):
+        kp = P.keypoints(o, 3)
+        r, c = P.sizes[o]
+        extra = np.zeros(6, oracle.POINT_DTYPE)
+        for i, (y, x, lev) in enumerate([(1, 1, 1), (r - 1, c - 1, 2), (r, c, 3), (0, 0, 0), (r // 2, c, 5), (4, 7, 4)]):
+            extra[i] = (y, x, 9, 1, o, lev)
+        kp = np.concatenate([kp, extra])
+        got = P.filter_keypoints(o, kp)
+        want = []
+        # keypoint order is preserved, so walk level groups in place
+        for q in kp:
+            sig = 1.5 * P.sigmas[o][q["level"]]
+            kern = oracle.gauss_kernel_f32(oracle.gauss_ksize_f32(sig), sig)
+            for (y, x, a) in npref.filter_keypoints(P.gauss(o, int(q["level"])), [(int(q["row"]), int(q["col"]), int(q["padding"]))], sig, kern):
+                want.append((y, x, a, 0, o, int(q["level"])))
+        assert [tuple(t) for t in got.tolist()] == want, o
+        n_out += len(want)
+    assert n_out > 20
+    # constant image: zero gradients -> tr^2/det = 0/0 = NaN -> nothing survives the edge test
+    Pc = oracle.Pyramid(synth.frame_np(32, 32, kind="constant"), 1, 1.6)
+    kp = np.zeros(3, oracle.POINT_DTYPE)
+    kp["row"], kp["col"], kp["level"], kp["padding"] = [1, 4, 7], [1, 4, 7], [1, 2, 3], 1
+    assert len(Pc.filter_keypoints(0, kp)) == 0
+    with pytest.raises(ValueError):
+        kp["level"][0] = 6
+        Pc.filter_keypoints(0, kp)
+    P.close()
+    Pc.close()
+
+
+def test_edge_response_oracle():
+    gx = np.array([[1, 2], [3, 4]], np.float32)
+    gy = np.array([[0, 1], [1, 0]], np.float32)
+    assert oracle.compute_edge_response(gx, gy, 1, 1, 1) == np.float32(np.float32(32 * 32) / np.float32(35))
+    # an ideal edge (gy == 0) has det 0: response +inf, rejected; a corner passes
+    assert oracle.compute_edge_response(gx, 0 * gy, 1, 1, 1) == np.inf
+    assert oracle.compute_edge_response(np.array([[5, 0], [0, 0]], np.float32), np.array([[0, 0], [0, 5]], np.float32), 1, 1, 1) == 4.0

@@ -103,6 +103,8 @@ SIGNATURES = {
     "vslam_dog_extrema": (_I, [_P, _P, _I, _I, _I, _P, _P, _Z, C.POINTER(_Z)]),
     "vslam_dog_keypoints": (_I, [_P, _P, _I, _I, _P, _Z, C.POINTER(_Z)]),
     "vslam_localize_points": (_I, [_P, _P, _Z, _P, _P]),
+    "vslam_filter_keypoints": (_I, [_P, _P, _I, _P, _Z, _P, _Z, C.POINTER(_Z)]),
+    "vslam_edge_response_windows": (_I, [_P, _P, _P, _I, _Z, _P]),
     "vslam_params_default": (None, [C.POINTER(Params), _I, _I]),
     "vslam_batch_layout_query": (_I, [C.POINTER(Params), C.POINTER(BatchLayout)]),
     "vslam_detect_batch_dev": (_I, [_P, C.POINTER(Params), _P, _Z, _I, C.POINTER(BatchOut)]),
@@ -337,6 +339,15 @@ class Context:
         self._chk(lib().vslam_localize_points(self._h, d.ctypes.data, n, keep.ctypes.data, val.ctypes.data), "vslam_localize_points")
         return keep.astype(bool), val
 
+    def edge_response_windows(self, gx_windows, gy_windows):
+        """computeEdgeResponse for n gathered windows: f32 [n, elems] each -> f32 [n]."""
+        gx = np.ascontiguousarray(gx_windows, dtype=np.float32)
+        gy = np.ascontiguousarray(gy_windows, dtype=np.float32)
+        assert gx.shape == gy.shape and gx.ndim == 2
+        out = np.zeros(gx.shape[0], np.float32)
+        self._chk(lib().vslam_edge_response_windows(self._h, gx.ctypes.data, gy.ctypes.data, gx.shape[1], gx.shape[0], out.ctypes.data), "vslam_edge_response_windows")
+        return out
+
     def pyramid(self, img, n_octaves: int = 4, sigma0: float = 1.6):
         return Pyramid(self, img, n_octaves, sigma0)
 
@@ -416,6 +427,14 @@ class Pyramid:
         n = C.c_size_t()
         self.ctx._chk(lib().vslam_dog_keypoints(self.ctx._h, self._h, octave, window, pts.ctypes.data, cap, C.byref(n)), "vslam_dog_keypoints")
         return pts[: min(n.value, cap)], n.value
+
+    def filter_keypoints(self, octave: int, kps, cap: int = 1 << 22):
+        """filterKeypoints for one octave: (oriented points, total count)."""
+        kps = np.ascontiguousarray(kps, dtype=POINT_DTYPE)
+        out = np.zeros(cap, POINT_DTYPE)
+        n = C.c_size_t()
+        self.ctx._chk(lib().vslam_filter_keypoints(self.ctx._h, self._h, octave, kps.ctypes.data, len(kps), out.ctypes.data, cap, C.byref(n)), "vslam_filter_keypoints")
+        return out[: min(n.value, cap)], n.value
 
     def close(self):
         if getattr(self, "_h", None):

@@ -130,6 +130,37 @@ struct DogEntries {  // entry = one 64-site word of the (octave, level, lattice 
     }
 };
 
+struct OrientEntries {  // entry = one keypoint of filterKeypoints: 36-bit mask of histogram peaks
+    const unsigned long long* masks;
+    const vslam_point* kps;
+    size_t n;
+    vslam_point* out;
+    __device__ size_t count() const { return n; }
+    __device__ unsigned int load(int, size_t e, unsigned long long (&w)[4]) const {
+        w[0] = masks[e];
+        return __popcll(w[0]);
+    }
+    __device__ void emit(int, size_t e, const unsigned long long (&w)[4], unsigned int pos, unsigned int cap) const {
+        const vslam_point kp = kps[e];
+        unsigned long long m = w[0];
+        while (m) {
+            const int b = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            if (pos < cap) {  // SLAM::point{y, x, angle, 0, octave, level}, Diff_of_Gauss.cpp:365
+                vslam_point pt;
+                pt.row = kp.row;
+                pt.col = kp.col;
+                pt.value = b * 10;
+                pt.padding = 0;
+                pt.octave = kp.octave;
+                pt.level = kp.level;
+                out[pos] = pt;
+            }
+            ++pos;
+        }
+    }
+};
+
 // localize mode: rewrite the value of every listed point the way FeaturePointLocalization does
 // at Diff_of_Gauss.cpp:246.  One thread per list record (dense, unlike the per-word emit loop).
 // grid = (ceil(cap/256), frames); octaves [o_begin, o_end) only - the list is appended per octave.

@@ -18,6 +18,7 @@
 #include "kernels_strip.hip.h"
 #include "kernels_aux.hip.h"
 #include "kernels_harris_strip.hip.h"
+#include "kernels_orient.hip.h"
 #include "kernels_compact.hip.h"
 #include "vslam_internal.h"
 
@@ -80,7 +81,7 @@ static int fail(vslam_ctx* c, int code, const std::string& msg) {
 static const char* const kKernelNames =
     "k_harris_fused\nk_harris_post\nk_resize_linear2x\nk_blur_h_generic\nk_blur_v_generic\n"
     "k_dog5\nk_resize_nearest_half\nk_extrema\nk_pyr_octave\n"
-    "k_gauss_v_strip\nk_gauss_h_strip\nk_resize_linear2x_slide\nk_resize_nearest_half_v4\nk_extrema_w3\nk_localize_points\nk_points_localize_value\n"
+    "k_gauss_v_strip\nk_gauss_h_strip\nk_resize_linear2x_slide\nk_resize_nearest_half_v4\nk_extrema_w3\nk_localize_points\nk_points_localize_value\nk_orient_keypoints\nk_edge_response_windows\nk_level_gradients\n"
     "k_harris_strip\nk_flag_count\nk_chunk_scan\nk_flag_scatter\nk_level_gradients";
 
 static std::pair<hipEvent_t, hipEvent_t>* timing_slot(vslam_ctx* c);
@@ -1074,6 +1075,105 @@ int vslam_localize_points(vslam_ctx* c, const int* diffs, size_t n, int* keep, i
     TRY(vslam_ctx_sync(c));
     for (size_t i = 0; i < n; ++i) keep[i] = h[i].x, value[i] = h[i].y;
     return VSLAM_OK;
+}
+
+int vslam_filter_keypoints(vslam_ctx* c, const vslam_pyramid* py, int octave, const vslam_point* kps, size_t n,
+                           vslam_point* out, size_t cap, size_t* count) {
+    TRY(bind_device(c));
+    ARGCHK(c, py && py->ctx == c && count && (kps || n == 0) && (out || cap == 0), "filterKeypoints: bad arguments");
+    if (octave < 0 || octave >= py->layout.n_octaves) return fail(c, VSLAM_ERR_RANGE, "octave out of range");
+    ARGCHK(c, n <= 0x7fffffff, "filterKeypoints: too many keypoints");
+    *count = 0;
+    if (n == 0) return VSLAM_OK;
+    const int rows = py->layout.rows[octave], cols = py->layout.cols[octave];
+    const size_t P = (size_t)rows * cols;
+    // what the reference would throw on (vector::at, Rect outside the padded Mat) is an error here
+    bool used[VSLAM_NUM_LEVELS] = {};
+    for (size_t i = 0; i < n; ++i) {
+        const vslam_point& k = kps[i];
+        if (k.level < 0 || k.level >= VSLAM_NUM_LEVELS || k.col < 0 || k.row < 0 || k.col > cols || k.row > rows || k.octave != octave)
+            return fail(c, VSLAM_ERR_RANGE, "filterKeypoints: keypoint outside the octave's data");
+        used[k.level] = true;
+    }
+    std::vector<float> taps[VSLAM_NUM_LEVELS];
+    int n_used = 0, max_r = 0;
+    size_t tap_elems = 0;
+    for (int l = 0; l < VSLAM_NUM_LEVELS; ++l) {
+        if (!used[l]) continue;
+        const double sigma = 1.5 * py->info.sigma[octave][l];  // Diff_of_Gauss.cpp:346
+        if (!gauss_kernel_f32(gauss_ksize_f32(sigma), sigma, taps[l])) return fail(c, VSLAM_ERR_INVALID, "filterKeypoints: bad blur kernel");
+        ++n_used;
+        max_r = std::max(max_r, (int)taps[l].size() / 2);
+        tap_elems += align_up(taps[l].size(), 64);
+    }
+    const size_t lds = orient_lds_bytes(max_r);
+    if (lds > 150 * 1024) return fail(c, VSLAM_ERR_UNSUPPORTED, "filterKeypoints: blur kernel too wide for the LDS strip");
+    const unsigned int ocap = (unsigned int)std::min<size_t>(cap, 0x7fffffff);
+    TRY(ws_reserve(c, ws_need(sizeof(vslam_point) * n) + ws_need(8 * n) + ws_need(sizeof(vslam_point) * (size_t)ocap) + 256 +
+                          ws_need(4 * compaction_ws_elems(n, 1)) + (size_t)n_used * 2 * ws_need(4 * P) + ws_need(4 * tap_elems)));
+    vslam_point* d_kps = ws_take<vslam_point>(c, n);
+    unsigned long long* d_masks = ws_take<unsigned long long>(c, n);
+    vslam_point* d_out = ws_take<vslam_point>(c, ocap);
+    unsigned int* d_n = ws_take<unsigned int>(c, 1);
+    unsigned int* d_cws = ws_take<unsigned int>(c, compaction_ws_elems(n, 1));
+    float* d_taps = ws_take<float>(c, tap_elems);
+    OrientLevels lv{};
+    HIPCHK(c, hipMemcpyAsync(d_kps, kps, sizeof(vslam_point) * n, hipMemcpyHostToDevice, c->stream));
+    size_t toff = 0;
+    for (int l = 0; l < VSLAM_NUM_LEVELS; ++l) {
+        if (!used[l]) continue;
+        float* d_mag = ws_take<float>(c, P);
+        float* d_ori = ws_take<float>(c, P);
+        const uint8_t* g = py->d_block + py->layout.octave_offset[octave] + (size_t)l * P;
+        // processGradients for the level (GaussPyramid.cpp:65-104): magnitude and orientation only
+        LAUNCH(c, "k_level_gradients", k_level_gradients, grid_rows(cols, rows), dim3(256), g, rows, cols, (float*)nullptr, (float*)nullptr,
+               d_mag, d_ori);
+        HIPCHK(c, hipMemcpyAsync(d_taps + toff, taps[l].data(), 4 * taps[l].size(), hipMemcpyHostToDevice, c->stream));
+        lv.gauss[l] = g;
+        lv.mag[l] = d_mag;
+        lv.orient[l] = d_ori;
+        lv.kern[l] = d_taps + toff;
+        lv.kn[l] = (int)taps[l].size();
+        toff += align_up(taps[l].size(), 64);
+    }
+    if (lds > 48 * 1024)
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_orient_keypoints), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    {
+        TimedScope ts(c, "k_orient_keypoints");
+        hipLaunchKernelGGL(k_orient_keypoints, dim3((unsigned)n), dim3(256), lds, c->stream, d_kps, (int)n, lv, rows, cols, d_masks);
+    }
+    HIPCHK(c, hipGetLastError());
+    OrientEntries ent{d_masks, d_kps, n, d_out};
+    TRY(enqueue_compaction(c, ent, n, 1, d_cws, ocap, d_n, 0));
+    unsigned int total = 0;
+    HIPCHK(c, hipMemcpyAsync(&total, d_n, 4, hipMemcpyDeviceToHost, c->stream));
+    TRY(vslam_ctx_sync(c));
+    *count = total;
+    const size_t m = std::min<size_t>(total, ocap);
+    if (m) HIPCHK(c, hipMemcpy(out, d_out, m * sizeof(vslam_point), hipMemcpyDeviceToHost));
+    return VSLAM_OK;
+}
+
+int vslam_edge_response_windows(vslam_ctx* c, const float* gx_windows, const float* gy_windows, int window_elems, size_t n,
+                                float* response) {
+    TRY(bind_device(c));
+    ARGCHK(c, window_elems >= 0 && ((gx_windows && gy_windows) || window_elems == 0 || n == 0) && (response || n == 0),
+           "computeEdgeResponse: bad arguments");
+    ARGCHK(c, n <= 0x7fffffff, "computeEdgeResponse: too many points");
+    if (n == 0) return VSLAM_OK;
+    const size_t we = (size_t)window_elems * n;
+    TRY(ws_reserve(c, 2 * ws_need(4 * we + 4) + ws_need(4 * n)));
+    float* d_gx = ws_take<float>(c, we + 1);
+    float* d_gy = ws_take<float>(c, we + 1);
+    float* d_r = ws_take<float>(c, n);
+    if (we) {
+        HIPCHK(c, hipMemcpyAsync(d_gx, gx_windows, 4 * we, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(d_gy, gy_windows, 4 * we, hipMemcpyHostToDevice, c->stream));
+    }
+    LAUNCH(c, "k_edge_response_windows", k_edge_response_windows, dim3((unsigned)((n + 255) / 256)), dim3(256), d_gx, d_gy, window_elems, (int)n,
+           d_r);
+    HIPCHK(c, hipMemcpyAsync(response, d_r, 4 * n, hipMemcpyDeviceToHost, c->stream));
+    return vslam_ctx_sync(c);
 }
 
 // ------------------------------------------------------------- device-resident batched path

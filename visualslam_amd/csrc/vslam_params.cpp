@@ -19,9 +19,8 @@ int gauss_ksize_u8(double sigma) { return (int)cv_round(sigma * 3 * 2 + 1) | 1; 
 // cv::getGaussianKernel as used by the CV_8U fixed-point GaussianBlur (OpenCV >= 4.5.1):
 // normalised double kernel, then 8.8 quantisation with error diffusion from the outermost
 // tap inwards; the centre tap takes the remainder so the taps sum to exactly 256.
-bool gauss_taps_q8(int n, double sigma, uint16_t* taps) {
-    if (n <= 0 || (n & 1) == 0 || n > VSLAM_MAX_KSIZE) return false;
-    std::vector<double> kf((size_t)n);
+static void gauss_kernel_f64(int n, double sigma, std::vector<double>& kf) {
+    kf.assign((size_t)n, 0.0);
     const int half = (n - 1) / 2;
     static const double k3[] = {0.25, 0.5, 0.25};
     static const double k5[] = {0.0625, 0.25, 0.375, 0.25, 0.0625};
@@ -47,6 +46,25 @@ bool gauss_taps_q8(int n, double sigma, uint16_t* taps) {
         for (int i = 0; i < half; ++i) kf[n - 1 - i] = kf[i] = kf[i] * inv;
         kf[half] = inv;
     }
+}
+
+int gauss_ksize_f32(double sigma) { return (int)cv_round(sigma * 4 * 2 + 1) | 1; }
+
+// cv::getGaussianKernel(n, sigma, CV_32F): the same normalised f64 kernel narrowed to f32 (the
+// kernel GaussianBlur builds for CV_32F images, Diff_of_Gauss.cpp:348).
+bool gauss_kernel_f32(int n, double sigma, std::vector<float>& out) {
+    if (n <= 0 || (n & 1) == 0 || n > (1 << 20)) return false;
+    std::vector<double> kf;
+    gauss_kernel_f64(n, sigma, kf);
+    out.resize((size_t)n);
+    for (int i = 0; i < n; ++i) out[(size_t)i] = (float)kf[(size_t)i];
+    return true;
+}
+
+bool gauss_taps_q8(int n, double sigma, uint16_t* taps) {
+    if (n <= 0 || (n & 1) == 0 || n > VSLAM_MAX_KSIZE) return false;
+    std::vector<double> kf;
+    gauss_kernel_f64(n, sigma, kf);
     double err = 0.0;
     long acc = 0;
     for (int i = 0; i < n / 2; ++i) {

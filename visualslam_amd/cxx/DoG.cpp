@@ -1,6 +1,6 @@
 // Headless counterpart of the reference's `DoG` executable up to the end of the hot path
 // (Diff_of_Gauss.cpp:727-785): build the pyramid, run initialKeypointDetection (with its
-// FeaturePointLocalization filter) per octave.
+// FeaturePointLocalization filter) and filterKeypoints per octave.
 //   usage: DoG [image.pgm | WxH]
 #include <chrono>
 #include <cstdio>
@@ -19,14 +19,24 @@ int main(int argc, char** argv) {
         GaussPyramid pyramid{img, numOctaves, pyr_sigma};  // :746
         const int windowSize = 3;       // :772
         std::vector<SLAM::point> all;
-        size_t perPointMismatch = 0;
+        size_t perPointMismatch = 0, oriented = 0;
         std::printf("{\"exe\": \"DoG\", \"rows\": %d, \"cols\": %d, \"octaves\": [", img.rows, img.cols);
         for (int octave = 0; octave < pyramid.getNumOctaves(); ++octave) {  // :780
-            std::vector<SLAM::point> keypoints, candidates;
+            std::vector<SLAM::point> keypoints, candidates, reducedKeypoints;
             initialKeypointDetection(keypoints, pyramid, octave, windowSize);  // :785
+            filterKeypoints(pyramid, octave, keypoints, reducedKeypoints);     // :787
             scaleSpaceCandidates(candidates, pyramid, octave, windowSize);
-            std::printf("%s{\"octave\": %d, \"candidates\": %zu, \"keypoints\": %zu}", octave ? ", " : "", octave, candidates.size(),
-                        keypoints.size());
+            std::printf("%s{\"octave\": %d, \"candidates\": %zu, \"keypoints\": %zu, \"oriented\": %zu}", octave ? ", " : "", octave,
+                        candidates.size(), keypoints.size(), reducedKeypoints.size());
+            if (!keypoints.empty()) {  // the per-point entry point agrees with the fused edge test on the first keypoint
+                const SLAM::point& k0 = keypoints.front();
+                const float r0 = computeEdgeResponse(k0, pyramid.octaveGradX(octave).at(k0.level), pyramid.octaveGradY(octave).at(k0.level));
+                const bool kept = !reducedKeypoints.empty() && reducedKeypoints.front().row == k0.row && reducedKeypoints.front().col == k0.col &&
+                                  reducedKeypoints.front().level == k0.level;
+                // kept implies r0 < 12.1; a rejected first keypoint may also fail for an empty histogram
+                if (kept && !(r0 < 12.1f)) ++perPointMismatch;
+            }
+            oriented += reducedKeypoints.size();
             if (octave == pyramid.getNumOctaves() - 1) {
                 // the per-point entry point on the coarsest octave must reproduce the fused result
                 std::vector<SLAM::point> all_candidates, one_by_one;
@@ -41,7 +51,7 @@ int main(int argc, char** argv) {
             all.insert(all.end(), keypoints.begin(), keypoints.end());
         }
         const auto t1 = std::chrono::steady_clock::now();
-        std::printf("], \"keypoints\": %zu, \"per_point_mismatch\": %zu, \"ms\": %.3f}\n", all.size(), perPointMismatch, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        std::printf("], \"keypoints\": %zu, \"oriented\": %zu, \"per_point_mismatch\": %zu, \"ms\": %.3f}\n", all.size(), oriented, perPointMismatch, std::chrono::duration<double, std::milli>(t1 - t0).count());
         return 0;
     } catch (const std::exception& e) {
         std::fprintf(stderr, "DoG: %s\n", e.what());

@@ -297,3 +297,34 @@ bool FeaturePointLocalization(std::vector<cv::Mat>& dogs_padded, std::vector<SLA
     keypoints.emplace_back(point);
     return true;
 }
+
+float computeEdgeResponse(const SLAM::point& keypoint, const cv::Mat& grad_x, const cv::Mat& grad_y) {
+    vslam_ctx* c = default_context();
+    const int x = keypoint.col, y = keypoint.row, p = keypoint.padding;
+    if (p < 0 || y - p < 0 || x - p < 0 || y + p > grad_x.rows || x + p > grad_x.cols || grad_y.rows != grad_x.rows || grad_y.cols != grad_x.cols)
+        throw vslam::Error(VSLAM_ERR_RANGE, "computeEdgeResponse: window outside the gradient images");
+    std::vector<float> wx, wy;
+    for (int u = y - p; u < y + p; ++u)      // :93
+        for (int v = x - p; v < x + p; ++v) {  // :94
+            wx.push_back(grad_x.at<float>(u, v));
+            wy.push_back(grad_y.at<float>(u, v));
+        }
+    float response = 0.f;
+    check(vslam_edge_response_windows(c, wx.data(), wy.data(), (int)wx.size(), 1, &response), c, "computeEdgeResponse");
+    return response;
+}
+
+void filterKeypoints(GaussPyramid& pyramid, int octave, std::vector<SLAM::point>& keypoints, std::vector<SLAM::point>& reducedKeypoints) {
+    vslam_ctx* c = default_context();
+    static_assert(sizeof(SLAM::point) == sizeof(vslam_point), "SLAM::point must stay binary compatible with vslam_point");
+    const vslam_point* in = reinterpret_cast<const vslam_point*>(keypoints.data());
+    size_t n = 0;
+    std::vector<vslam_point> buf(std::max<size_t>(64, 2 * keypoints.size()));
+    check(vslam_filter_keypoints(c, pyramid.handle(), octave, in, keypoints.size(), buf.data(), buf.size(), &n), c, "filterKeypoints");
+    if (n > buf.size()) {
+        buf.resize(n);
+        check(vslam_filter_keypoints(c, pyramid.handle(), octave, in, keypoints.size(), buf.data(), buf.size(), &n), c, "filterKeypoints");
+    }
+    for (size_t i = 0; i < n; ++i)
+        reducedKeypoints.emplace_back(buf[i].row, buf[i].col, buf[i].value, buf[i].padding, buf[i].octave, buf[i].level);
+}

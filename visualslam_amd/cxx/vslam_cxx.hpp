@@ -10,6 +10,8 @@
 //   struct SLAM::point                                         Diff_of_Gauss.cpp:27
 //   void initialKeypointDetection(std::vector<SLAM::point>&, GaussPyramid&, int, int)
 //   bool FeaturePointLocalization(std::vector<Mat>&, std::vector<SLAM::point>&, int, SLAM::point&)
+//   float computeEdgeResponse(const SLAM::point&, const Mat&, const Mat&)
+//   void filterKeypoints(GaussPyramid&, int, std::vector<SLAM::point>&, std::vector<SLAM::point>&)
 //                                                              Diff_of_Gauss.cpp:254
 // plus the OpenCV calls on the path (vslamcv::GaussianBlur / Sobel / convertScaleAbs / resize).
 // StructureMatrix (:10) is a per-pixel helper used only inside HarrisCorner and is subsumed by
@@ -116,3 +118,11 @@ void scaleSpaceCandidates(std::vector<SLAM::point>& candidates, GaussPyramid& py
 // the GPU (vslam_localize_points), updates point.value and appends the point when kept.
 bool FeaturePointLocalization(std::vector<cv::Mat>& dogs_padded, std::vector<SLAM::point>& keypoints, int level,
                               SLAM::point& point);
+// float computeEdgeResponse(const SLAM::point&, const Mat& grad_x, const Mat& grad_y),
+// Diff_of_Gauss.cpp:79-109: gathers the keypoint's window from the two CV_32F gradient images
+// on the host (:93-94) and evaluates tr^2/det on the GPU (vslam_edge_response_windows).
+float computeEdgeResponse(const SLAM::point& keypoint, const cv::Mat& grad_x, const cv::Mat& grad_y);
+// void filterKeypoints(GaussPyramid&, int octave, vector<SLAM::point>& keypoints,
+// vector<SLAM::point>& reducedKeypoints), Diff_of_Gauss.cpp:301-372 (vslam_filter_keypoints).
+void filterKeypoints(GaussPyramid& pyramid, int octave, std::vector<SLAM::point>& keypoints,
+                     std::vector<SLAM::point>& reducedKeypoints);
