@@ -128,6 +128,28 @@ def test_config2_and_3_full_1080p_frame(env):
     check_frame(p, L, out, 0, frames[0], 4)
 
 
+def test_full_1080p_frame_localized_and_oriented(env):
+    # SURVEY section 8f rows 2-3 at BASELINE's frame size: the fused localize mode of the batch path
+    # and the per-image filterKeypoints call against the oracle (noise frame: every stage populated)
+    ctx, torch = env
+    frames = synth.frame_np(1080, 1920, kind="noise")[None].copy()  # [None] alone leaves stride 0 on the new axis
+    p, L, out = run_batch(ctx, torch, frames, with_nms2=False, localize=1)
+    check_frame(p, L, out, 0, frames[0], 4)
+    want, got = oracle.Pyramid(frames[0], 4, 1.6), ctx.pyramid(frames[0], 4, 1.6)
+    n_oriented = 0
+    for o in range(4):
+        kp = want.keypoints(o, 3)
+        gk, nk = got.keypoints(o, 3)
+        assert nk == len(kp) and gk.tobytes() == kp.tobytes()
+        w = want.filter_keypoints(o, kp)
+        g, n = got.filter_keypoints(o, gk)
+        assert n == len(w) and g.tobytes() == w.tobytes(), o
+        n_oriented += n
+    assert n_oriented > 1000
+    got.close()
+    want.close()
+
+
 def test_full_size_batch_properties(env):
     # size-independent properties on a 1080p batch (no oracle run per frame):
     #  - identical frames give identical outputs wherever they sit in the batch (chunking,
