@@ -28,7 +28,11 @@ __global__ __launch_bounds__(256) void k(uint32_t* out, unsigned long long* cyc,
     if (OP == 11) asm volatile("v_and_b32 %0, %1, %0" : "+v"(a[i]) : "s"(s1));                        \
     if (OP == 12) asm volatile("v_cvt_f32_ubyte1 %0, %0" : "+v"(a[i]));                               \
     if (OP == 13) asm volatile("v_dot4c_i32_i8 %0, %1, %2" : "+v"(a[i]) : "v"(x), "v"(y));            \
-    if (OP == 14) asm volatile("v_mov_b32 %0, %1" : "+v"(a[i]) : "v"(x));
+    if (OP == 14) asm volatile("v_mov_b32 %0, %1" : "+v"(a[i]) : "v"(x));                             \
+    if (OP == 15) asm volatile("v_dot2c_i32_i16 %0, %1, %2" : "+v"(a[i]) : "v"(x), "v"(y));           \
+    if (OP == 16) asm volatile("v_dot4_u32_u8 %0, %1, %2, %0" : "+v"(a[i]) : "v"(x), "v"(y));         \
+    if (OP == 17) asm volatile("v_dot4c_i32_i8 %0, %1, %2" : "+v"(a[i]) : "s"(s1), "v"(y));           \
+    if (OP == 18) asm volatile("v_dot2c_i32_i16 %0, %1, %2" : "+v"(a[i]) : "s"(s1), "v"(y));
         OPS(ONE)
         x += s0;
     }
@@ -69,7 +73,11 @@ int main() {
     run<6>("v_perm_b32 (VOP3)");
     run<4>("v_dot4_u32_u8 (VOP3P)");
     run<13>("v_dot4c_i32_i8 (VOP2)");
+    run<16>("v_dot4_u32_u8 v,v (VOP3P)");
+    run<17>("v_dot4c_i32_i8 s,v (VOP2)");
     run<5>("v_dot2_u32_u16 (VOP3P)");
+    run<15>("v_dot2c_i32_i16 (VOP2)");
+    run<18>("v_dot2c_i32_i16 s,v (VOP2)");
     run<9>("v_pk_add_u16 (VOP3P)");
     run<7>("v_fmac_f32 (VOP2)");
     run<8>("v_fma_f32 (VOP3)");
