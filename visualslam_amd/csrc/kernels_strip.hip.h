@@ -32,7 +32,7 @@ struct StripTaps {
 };
 
 // ------------------------------------------------------------------------------ vertical pass
-// grid = (ceil(cols/64), 1, frames); dynamic LDS = rhq * 64 * 4 bytes, rhq = (rows4 + 2*RM + 16)/4.
+// grid = (ceil(cols/64), level split 1|2|3|6, frames); dynamic LDS = rhq * 64 * 4 bytes, rhq = (rows4 + 2*RM + 16)/4.
 // Requires cols % 4 == 0.  h: [frame][level][rows][cols] u16.
 __global__ __launch_bounds__(256) void k_gauss_v_strip(const uint8_t* __restrict__ base, size_t bframe,
                                                         uint16_t* __restrict__ h, size_t hframe, int rows, int cols,
@@ -64,7 +64,9 @@ __global__ __launch_bounds__(256) void k_gauss_v_strip(const uint8_t* __restrict
     }
     __syncthreads();
 
-    for (int l = 0; l < VSLAM_NUM_LEVELS; ++l) {
+    // gridDim.y splits the six levels over workgroups (each re-stages the strip): a single frame
+    // has only cols/64 strips, far too few workgroups for 256 CUs
+    for (int l = blockIdx.y; l < VSLAM_NUM_LEVELS; l += gridDim.y) {
         const int n = taps->n[l], r = n >> 1;
         const int M = (n + 3 + 3) >> 2;            // dwords covering bytes [0, 3 + n)
         const int phi = ((r - RM) % 4 + 4) % 4;    // item rows start where the window is dword aligned

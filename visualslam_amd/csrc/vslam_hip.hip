@@ -323,12 +323,19 @@ static int enqueue_strip_octave(vslam_ctx* c, double sigma0, int o, const OctPla
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)v_lds));
     {
         TimedScope ts(c, "k_gauss_v_strip");
-        hipLaunchKernelGGL(k_gauss_v_strip, dim3((cols + STRIP_W - 1) / STRIP_W, 1, nf), dim3(256), v_lds, c->stream, base,
-                           bframe, h, 6 * P, rows, cols, RM, rhq, taps);
+        // small batches: split the six levels over workgroups until the launch has >= 256 of them
+        const int strips = (cols + STRIP_W - 1) / STRIP_W;
+        const int want = (256 + strips * nf - 1) / (strips * nf);
+        const int lsplit = want >= 6 ? 6 : want >= 3 ? 3 : want >= 2 ? 2 : 1;
+        hipLaunchKernelGGL(k_gauss_v_strip, dim3(strips, lsplit, nf), dim3(256), v_lds, c->stream, base, bframe, h, 6 * P, rows, cols,
+                           RM, rhq, taps);
     }
     HIPCHK(c, hipGetLastError());
     const int pw = (cols / 2 + nmax / 2 + 8 + 3) & ~3;
-    switch (pl.sh) {
+    // small batches: shorter row strips, more workgroups
+    int sh = pl.sh;
+    while (sh > 4 && (long)((rows + sh - 1) / sh) * nf < 256) sh >>= 1;
+    switch (sh) {
         case 16: return launch_h_strip<16>(c, h, 6 * P, oct, pframe, rows, cols, pw, nf, taps, next_base, nframe, nrows, ncols);
         case 8: return launch_h_strip<8>(c, h, 6 * P, oct, pframe, rows, cols, pw, nf, taps, next_base, nframe, nrows, ncols);
         default: return launch_h_strip<4>(c, h, 6 * P, oct, pframe, rows, cols, pw, nf, taps, next_base, nframe, nrows, ncols);
