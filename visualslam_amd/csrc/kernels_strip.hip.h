@@ -111,12 +111,12 @@ __global__ __launch_bounds__(256) void k_gauss_v_strip(const uint8_t* __restrict
 }
 
 // ---------------------------------------------------------------------------- horizontal pass
-// One level of one item (8 columns x 4 rows): DL = r & 1 (window offset inside the first pair).
-template <int DL>
+// One level of one item (8 columns x RI rows): DL = r & 1 (window offset inside the first pair).
+template <int DL, int RI>
 __device__ __forceinline__ void h_item_level(const uint32_t* __restrict__ hrow, int pw, int tx0, int nb,
-                                             const uint32_t* __restrict__ tp, uint32_t (&acc)[4][8]) {
+                                             const uint32_t* __restrict__ tp, uint32_t (&acc)[RI][8]) {
 #pragma unroll
-    for (int jr = 0; jr < 4; ++jr)
+    for (int jr = 0; jr < RI; ++jr)
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[jr][j] = 32768u;
     for (int b = 0; b < nb; ++b) {
@@ -125,7 +125,7 @@ __device__ __forceinline__ void h_item_level(const uint32_t* __restrict__ hrow, 
 #pragma unroll
         for (int i = 0; i < 16; ++i) T[i] = tp[8 * b + i];
 #pragma unroll
-        for (int jr = 0; jr < 4; ++jr) {
+        for (int jr = 0; jr < RI; ++jr) {
             const uint4 v = *reinterpret_cast<const uint4*>(hrow + jr * pw + (tx0 >> 1) + 4 * b);
             asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));  // stay one ds_read_b128
             const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
@@ -142,8 +142,10 @@ __device__ __forceinline__ void h_item_level(const uint32_t* __restrict__ hrow, 
 }
 
 // grid = (1, ceil(rows/SH), frames); dynamic LDS = SH * pw * 4 bytes, pw = (cols + 2*(rmax+1) + 8)/2
-// rounded up to a multiple of 4.  Requires cols % 8 == 0 and (cols/8)*(SH/4) <= 512.
-template <int SH>
+// rounded up to a multiple of 4.  Requires cols % 8 == 0 and (cols/8)*(SH/RI) <= 512.
+// RI = rows per item: 4 amortises the tap loads (batches); 1 spreads a small launch over all
+// 256 threads (a single frame is bound by the latency of one workgroup, not by throughput).
+template <int SH, int RI>
 __global__ __launch_bounds__(256) void k_gauss_h_strip(const uint16_t* __restrict__ h, size_t hframe,
                                                         uint8_t* __restrict__ oct_out, size_t pframe, int rows,
                                                         int cols, int pw, const StripTaps* __restrict__ taps,
@@ -155,8 +157,8 @@ __global__ __launch_bounds__(256) void k_gauss_h_strip(const uint16_t* __restric
     const int y0 = blockIdx.y * SH;
     const size_t P = (size_t)rows * cols;
     uint8_t* out = oct_out + blockIdx.z * pframe;
-    const int ncg = cols >> 3, items = ncg * (SH / 4);
-    uint32_t prev_e[2][4][2], prev_o[2][4][2];
+    const int ncg = cols >> 3, items = ncg * (SH / RI);
+    uint32_t prev_e[2][RI][2], prev_o[2][RI][2];
 
     for (int l = 0; l < VSLAM_NUM_LEVELS; ++l) {
         const int n = taps->n[l], r = n >> 1, dl = r & 1, PL = r + dl;
@@ -190,15 +192,15 @@ __global__ __launch_bounds__(256) void k_gauss_h_strip(const uint16_t* __restric
             const int it = tid + ii * 256;
             if (it < items) {
                 const int cg = it % ncg, rg = it / ncg;
-                uint32_t acc[4][8];
+                uint32_t acc[RI][8];
                 if (dl)
-                    h_item_level<1>(hp + (4 * rg) * pw, pw, 8 * cg, nb, tp, acc);
+                    h_item_level<1, RI>(hp + (RI * rg) * pw, pw, 8 * cg, nb, tp, acc);
                 else
-                    h_item_level<0>(hp + (4 * rg) * pw, pw, 8 * cg, nb, tp, acc);
+                    h_item_level<0, RI>(hp + (RI * rg) * pw, pw, 8 * cg, nb, tp, acc);
                 const int x = 8 * cg;
 #pragma unroll
-                for (int jr = 0; jr < 4; ++jr) {
-                    const int y = y0 + 4 * rg + jr;
+                for (int jr = 0; jr < RI; ++jr) {
+                    const int y = y0 + RI * rg + jr;
                     uint32_t g[2], d[2] = {0, 0};
 #pragma unroll
                     for (int hw = 0; hw < 2; ++hw) {

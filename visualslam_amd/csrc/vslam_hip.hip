@@ -292,15 +292,15 @@ static int get_strip_taps(vslam_ctx* c, double sigma0, int o, const OctPlan& pl,
     return VSLAM_OK;
 }
 
-template <int SH>
+template <int SH, int RI>
 static int launch_h_strip(vslam_ctx* c, const uint16_t* h, size_t hframe, uint8_t* oct, size_t pframe, int rows, int cols,
                           int pw, int nf, const StripTaps* taps, uint8_t* next_base, size_t nframe, int nrows, int ncols) {
     const size_t lds = (size_t)SH * pw * 4;
-    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gauss_h_strip<SH>),
+    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gauss_h_strip<SH, RI>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     {
         TimedScope ts(c, "k_gauss_h_strip");
-        hipLaunchKernelGGL(k_gauss_h_strip<SH>, dim3(1, (rows + SH - 1) / SH, nf), dim3(256), lds, c->stream, h, hframe, oct,
+        hipLaunchKernelGGL((k_gauss_h_strip<SH, RI>), dim3(1, (rows + SH - 1) / SH, nf), dim3(256), lds, c->stream, h, hframe, oct,
                            pframe, rows, cols, pw, taps, next_base, nframe, nrows, ncols);
     }
     HIPCHK(c, hipGetLastError());
@@ -335,10 +335,13 @@ static int enqueue_strip_octave(vslam_ctx* c, double sigma0, int o, const OctPla
     // small batches: shorter row strips, more workgroups
     int sh = pl.sh;
     while (sh > 4 && (long)((rows + sh - 1) / sh) * nf < 256) sh >>= 1;
+    // ... and, when even that leaves most threads without an item, one row per item
+    const bool fine = sh == 4 && (long)((rows + 3) / 4) * nf < 256 && (cols / 8) * 4 <= 512;
+    if (fine) return launch_h_strip<4, 1>(c, h, 6 * P, oct, pframe, rows, cols, pw, nf, taps, next_base, nframe, nrows, ncols);
     switch (sh) {
-        case 16: return launch_h_strip<16>(c, h, 6 * P, oct, pframe, rows, cols, pw, nf, taps, next_base, nframe, nrows, ncols);
-        case 8: return launch_h_strip<8>(c, h, 6 * P, oct, pframe, rows, cols, pw, nf, taps, next_base, nframe, nrows, ncols);
-        default: return launch_h_strip<4>(c, h, 6 * P, oct, pframe, rows, cols, pw, nf, taps, next_base, nframe, nrows, ncols);
+        case 16: return launch_h_strip<16, 4>(c, h, 6 * P, oct, pframe, rows, cols, pw, nf, taps, next_base, nframe, nrows, ncols);
+        case 8: return launch_h_strip<8, 4>(c, h, 6 * P, oct, pframe, rows, cols, pw, nf, taps, next_base, nframe, nrows, ncols);
+        default: return launch_h_strip<4, 4>(c, h, 6 * P, oct, pframe, rows, cols, pw, nf, taps, next_base, nframe, nrows, ncols);
     }
 }
 
