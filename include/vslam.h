@@ -240,7 +240,10 @@ typedef struct {
     int rows[VSLAM_MAX_OCTAVES], cols[VSLAM_MAX_OCTAVES];
     int lat_rows[VSLAM_MAX_OCTAVES], lat_cols[VSLAM_MAX_OCTAVES], lat_words[VSLAM_MAX_OCTAVES];
     /* pyramid block of one frame: for octave o, Gaussian l at octave_offset[o] + l*P_o and
-     * DoG l at octave_offset[o] + (6+l)*P_o, P_o = rows[o]*cols[o], dense rows. */
+     * DoG l at octave_offset[o] + (6+l)*P_o, P_o = rows[o]*pitch[o]; row r of a plane starts at
+     * r*pitch[o].  pitch[o] = cols[o] rounded up to a multiple of 16 (so it equals cols[o] for the
+     * usual frame sizes); the padding bytes are unspecified. */
+    int pitch[VSLAM_MAX_OCTAVES];
     size_t octave_offset[VSLAM_MAX_OCTAVES];
     size_t pyramid_frame_bytes;
     /* candidate bitmask block of one frame: octave o starts at word bits_offset[o] */
@@ -259,7 +262,7 @@ typedef struct {
     float* nms2;             /* [n][rows][cols]  NMS2(response, 5) map (optional) */
     vslam_kp* harris_kps;    /* [n][harris_cap] */
     uint32_t* harris_counts; /* [n] totals (may exceed cap) */
-    uint8_t* pyramid;        /* [n][pyramid_frame_bytes] */
+    uint8_t* pyramid;        /* [n][pyramid_frame_bytes], 16-byte aligned, planes pitched (layout.pitch) */
     uint64_t* extrema_bits;  /* [n][bits_frame_words] */
     vslam_point* dog_points; /* [n][dog_cap], order (octave, level, i, j) */
     uint32_t* dog_counts;    /* [n] totals (may exceed cap) */

@@ -73,6 +73,10 @@ def test_batch_layout_1080p(lib):
     assert L.pyramid_frame_bytes >= 11 * 11_016_000 and L.pyramid_frame_bytes % 256 == 0
     assert sum(3 * L.lat_rows[o] * L.lat_cols[o] for o in range(4)) == 3_672_000
     assert L.octave_offset[1] == 11 * 2160 * 3840
+    assert [L.pitch[o] for o in range(4)] == [3840, 1920, 960, 480]  # multiples of 16: pitch == cols
+    odd = capi.batch_layout(capi.default_params(1240, 1754))  # the reference's chessboard.png
+    assert [(odd.cols[o], odd.pitch[o]) for o in range(4)] == [(3508, 3520), (1754, 1760), (877, 880), (438, 448)]
+    assert odd.octave_offset[1] == 11 * 2480 * 3520 and odd.octave_offset[1] % 16 == 0
     bad = capi.default_params(0, 10)
     with pytest.raises(capi.VslamError):
         capi.batch_layout(bad)

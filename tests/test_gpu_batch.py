@@ -60,12 +60,14 @@ def check_frame(p, L, out, f, img, n_oct):
     for o in range(n_oct):
         r, c = want.sizes[o]
         assert (L.rows[o], L.cols[o]) == (r, c)
-        P = r * c
+        pitch = L.pitch[o]  # plane rows are pitched (cols rounded up to 16); the padding is unspecified
+        assert pitch % 16 == 0 and c <= pitch < c + 16
+        P = r * pitch
         off = L.octave_offset[o]
         for l in range(6):
-            assert (block[off + l * P: off + (l + 1) * P].reshape(r, c) == want.gauss(o, l)).all(), ("gauss", o, l)
+            assert (block[off + l * P: off + (l + 1) * P].reshape(r, pitch)[:, :c] == want.gauss(o, l)).all(), ("gauss", o, l)
         for l in range(5):
-            assert (block[off + (6 + l) * P: off + (7 + l) * P].reshape(r, c) == want.dog(o, l)).all(), ("dog", o, l)
+            assert (block[off + (6 + l) * P: off + (7 + l) * P].reshape(r, pitch)[:, :c] == want.dog(o, l)).all(), ("dog", o, l)
         wm, wp = want.extrema(o, p.extrema_window, p.min_contrast)
         if p.localize:  # list = FeaturePointLocalization survivors
             wp = want.keypoints(o, p.extrema_window)
@@ -175,7 +177,8 @@ def test_full_size_batch_properties(env):
     assert out["harris_counts"][c] == 0 and out["dog_counts"][c] == 0
     sites = 0
     for o in range(4):
-        P = L.rows[o] * L.cols[o]
+        P = L.rows[o] * L.pitch[o]  # 1080p: pitch == cols at every octave
+        assert L.pitch[o] == L.cols[o]
         off = L.octave_offset[o]
         assert (out["pyramid"][c][off: off + 6 * P] == 128).all()
         assert not out["pyramid"][c][off + 6 * P: off + 11 * P].any()
@@ -186,7 +189,7 @@ def test_full_size_batch_properties(env):
     # DoG is the saturating difference of adjacent Gaussians, everywhere
     blk = out["pyramid"][0]
     for o in range(4):
-        P = L.rows[o] * L.cols[o]
+        P = L.rows[o] * L.pitch[o]
         off = L.octave_offset[o]
         g = blk[off: off + 6 * P].reshape(6, P).astype(np.int16)
         d = blk[off + 6 * P: off + 11 * P].reshape(5, P)
@@ -212,6 +215,14 @@ def test_fast_paths_are_the_ones_that_run(env):
     for name, want in (("k_pyr_octave", 2), ("k_harris_strip", 1), ("k_gauss_h_strip", 2), ("k_resize_linear2x_slide", 1)):
         ctx.kernel_timing_enable(name)
         run_batch(ctx, torch, frames)
+        launches, ms = ctx.kernel_timing_read()
+        ctx.kernel_timing_enable(None)
+        assert launches >= want and ms > 0, (name, launches)
+    # widths that are not a multiple of 8 take the same kernels (pitched planes)
+    odd = synth.frames_np(1, 310, 438, stream_id=1)
+    for name, want in (("k_pyr_octave", 2), ("k_gauss_h_strip", 2)):
+        ctx.kernel_timing_enable(name)
+        run_batch(ctx, torch, odd)
         launches, ms = ctx.kernel_timing_read()
         ctx.kernel_timing_enable(None)
         assert launches >= want and ms > 0, (name, launches)

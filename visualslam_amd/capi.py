@@ -44,6 +44,7 @@ class BatchLayout(C.Structure):
         ("n_octaves", C.c_int),
         ("rows", C.c_int * MAX_OCTAVES), ("cols", C.c_int * MAX_OCTAVES),
         ("lat_rows", C.c_int * MAX_OCTAVES), ("lat_cols", C.c_int * MAX_OCTAVES), ("lat_words", C.c_int * MAX_OCTAVES),
+        ("pitch", C.c_int * MAX_OCTAVES),
         ("octave_offset", C.c_size_t * MAX_OCTAVES), ("pyramid_frame_bytes", C.c_size_t),
         ("bits_offset", C.c_size_t * MAX_OCTAVES), ("bits_frame_words", C.c_size_t),
         ("algorithmic_bytes_harris", C.c_size_t), ("algorithmic_bytes_dog", C.c_size_t),

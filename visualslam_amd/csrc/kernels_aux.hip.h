@@ -26,8 +26,8 @@ __device__ __forceinline__ uint32_t pk_lshr_u16(uint32_t a, int sh) {
 }
 
 __global__ __launch_bounds__(256) void k_resize_linear2x_slide(const uint8_t* __restrict__ src, size_t sframe,
-                                                                uint8_t* __restrict__ dst, size_t dframe, int rows,
-                                                                int cols, int seg) {
+                                                                uint8_t* __restrict__ dst, size_t dframe, int dpitch,
+                                                                int rows, int cols, int seg) {
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (4 * k >= cols) return;
     const int m0 = blockIdx.y * seg, m1 = min(m0 + seg, rows);
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void k_resize_linear2x_slide(const uint8_t* __
         uint32_t v[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = pk_lshr_u16(U[i] + V[i] + 0x00020002u, 2);
-        *reinterpret_cast<uint2*>(d + (size_t)dy * (2 * cols)) = make_uint2(v[0] | (v[1] << 8), v[2] | (v[3] << 8));
+        *reinterpret_cast<uint2*>(d + (size_t)dy * dpitch) = make_uint2(v[0] | (v[1] << 8), v[2] | (v[3] << 8));
     };
     uint32_t Xp[4], Yp[4], Xc[4], Yc[4];
     hrow(m0 - 1, Xp, Yp);
@@ -72,16 +72,17 @@ __global__ __launch_bounds__(256) void k_resize_linear2x_slide(const uint8_t* __
 }
 
 // ---- K-D4: cv::resize(src, Size(), 0.5, 0.5, INTER_NEAREST) (GaussPyramid.cpp:126) ----------
-// One thread = 4 destination pixels.  Requires cols % 8 == 0 (then dcols = cols/2, % 4 == 0).
-__global__ __launch_bounds__(256) void k_resize_nearest_half_v4(const uint8_t* __restrict__ src, size_t sframe,
-                                                                 uint8_t* __restrict__ dst, size_t dframe, int rows,
-                                                                 int cols, int drows, int dcols) {
+// One thread = 4 destination pixels from 8 source bytes; spitch / dpitch are multiples of 16, so
+// the 8-byte load and the 4-byte store may run into the row padding but never out of the row.
+__global__ __launch_bounds__(256) void k_resize_nearest_half_v4(const uint8_t* __restrict__ src, size_t sframe, int spitch,
+                                                                 uint8_t* __restrict__ dst, size_t dframe, int dpitch,
+                                                                 int rows, int drows, int dcols) {
     const int k = blockIdx.x * 256 + threadIdx.x;
     const int y = blockIdx.y;
     if (4 * k >= dcols) return;
     const int sy = min(2 * y, rows - 1);
-    const uint2 w = *reinterpret_cast<const uint2*>(src + blockIdx.z * sframe + (size_t)sy * cols + 8 * k);
-    *reinterpret_cast<uint32_t*>(dst + blockIdx.z * dframe + (size_t)y * dcols + 4 * k) =
+    const uint2 w = *reinterpret_cast<const uint2*>(src + blockIdx.z * sframe + (size_t)sy * spitch + 8 * k);
+    *reinterpret_cast<uint32_t*>(dst + blockIdx.z * dframe + (size_t)y * dpitch + 4 * k) =
         __builtin_amdgcn_perm(w.y, w.x, 0x06040200);
 }
 
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(256) void k_resize_nearest_half_v4(const uint8_t* _
 // bytes, fetched per staged row by one ds_read2_b32 of the enclosing dword pair and one v_perm
 // with a per-site selector, landing as (a, b) in 16-bit lanes for packed min/max.  A wave's 64
 // candidate flags leave as one ballot word = the bitmask layout of include/vslam.h.
-// Requires cols % 16 == 0.  grid = (ceil(words_per_row/4), lat_rows, frames).
+// Row pitch a multiple of 16 (any width).  grid = (ceil(words_per_row/4), lat_rows, frames).
 typedef unsigned short us2e_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) {
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(us2e_t, a), __builtin_bit_cast(us2e_t, b)));
@@ -123,8 +124,8 @@ __global__ __launch_bounds__(256) void k_extrema_w3(const uint8_t* __restrict__ 
         qkeep[threadIdx.x] = 0, qkeep[256 + threadIdx.x] = 0, qkeep[512 + threadIdx.x] = 0;
     }
     const int li = blockIdx.y, f = blockIdx.z;
-    const int rows = g.rows[o], cols = g.cols[o];
-    const size_t P = (size_t)rows * cols;
+    const int rows = g.rows[o], cols = g.cols[o], pitch = g.pitch[o];
+    const size_t P = (size_t)rows * pitch;
     const uint8_t* dog = pyr + f * pframe + g.oct_off[o] + (size_t)VSLAM_NUM_LEVELS * P;
     const int ya = max(3 * li - 1, 0), yb = 3 * li;  // padded rows i-1, i with i = 1 + 3li -> unpadded 3li-1, 3li
     const int yc = min(3 * li + 1, rows - 1);        // padded row i+1
@@ -139,11 +140,11 @@ __global__ __launch_bounds__(256) void k_extrema_w3(const uint8_t* __restrict__ 
             const int lev = rl < 10 ? (rl >> 1) : rl - 9, y = rl < 10 ? ((rl & 1) ? yb : ya) : yc;
             if (c >= 0 && c < cols)
                 *reinterpret_cast<uint4*>(srow + rl * EXT_PITCH + 16 * x16) =
-                    *reinterpret_cast<const uint4*>(dog + (size_t)lev * P + (size_t)y * cols + c);
+                    *reinterpret_cast<const uint4*>(dog + (size_t)lev * P + (size_t)y * pitch + c);  // may end in the row padding
         }
     }
     if (blockIdx.x == 0 && threadIdx.x < 10)  // column -1 replicates column 0 (padOctave)
-        srow[threadIdx.x * EXT_PITCH + 15] = dog[(size_t)(threadIdx.x >> 1) * P + (size_t)((threadIdx.x & 1) ? yb : ya) * cols];
+        srow[threadIdx.x * EXT_PITCH + 15] = dog[(size_t)(threadIdx.x >> 1) * P + (size_t)((threadIdx.x & 1) ? yb : ya) * pitch];
     __syncthreads();
     const int lc = g.lat_cols[o], wpr = g.wpr[o], lr = g.lat_rows[o];
     const int lj = blockIdx.x * 256 + threadIdx.x;
@@ -245,15 +246,15 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
     return a;
 }
 
-__global__ __launch_bounds__(256) void k_level_gradients(const uint8_t* __restrict__ g, int rows, int cols,
+__global__ __launch_bounds__(256) void k_level_gradients(const uint8_t* __restrict__ g, int gpitch, int rows, int cols,
                                                           float* __restrict__ gx, float* __restrict__ gy,
                                                           float* __restrict__ mag, float* __restrict__ orient) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     const int r = blockIdx.y;
     if (c >= cols) return;
-    const uint8_t* row = g + (size_t)r * cols;
+    const uint8_t* row = g + (size_t)r * gpitch;
     const float x = (float)((int)row[reflect101(c + 1, cols)] - (int)row[reflect101(c - 1, cols)]);
-    const float y = (float)((int)g[(size_t)reflect101(r + 1, rows) * cols + c] - (int)g[(size_t)reflect101(r - 1, rows) * cols + c]);
+    const float y = (float)((int)g[(size_t)reflect101(r + 1, rows) * gpitch + c] - (int)g[(size_t)reflect101(r - 1, rows) * gpitch + c]);
     const size_t o = (size_t)r * cols + c;
     if (gx) gx[o] = x;
     if (gy) gy[o] = y;

@@ -108,7 +108,7 @@ struct DogEntries {  // entry = one 64-site word of the (octave, level, lattice 
         const int wpr = g.wpr[o], lr = g.lat_rows[o];
         const int level = (int)(wl / ((size_t)lr * wpr)) + 1;
         const int li = (int)((wl / wpr) % lr), lj0 = (int)(wl % wpr) * 64;
-        const size_t P = (size_t)g.rows[o] * g.cols[o];
+        const size_t P = (size_t)g.rows[o] * g.pitch[o];
         const uint8_t* dog = pyr + f * pframe + g.oct_off[o] + (size_t)VSLAM_NUM_LEVELS * P;
         unsigned long long m = w[0];
         while (m) {
@@ -119,7 +119,7 @@ struct DogEntries {  // entry = one 64-site word of the (octave, level, lattice 
                 vslam_point pt;
                 pt.row = i;
                 pt.col = j;
-                pt.value = dog[(size_t)level * P + (size_t)(i - g.pad) * g.cols[o] + (j - g.pad)];
+                pt.value = dog[(size_t)level * P + (size_t)(i - g.pad) * g.pitch[o] + (j - g.pad)];
                 pt.padding = g.pad;
                 pt.octave = o;
                 pt.level = level;
@@ -173,10 +173,10 @@ __global__ __launch_bounds__(256) void k_points_localize_value(vslam_point* __re
     vslam_point& pt = pts[(size_t)f * cap + i];
     const int o = pt.octave;
     if (o < o_begin || o >= o_end) return;
-    const size_t P = (size_t)g.rows[o] * g.cols[o];
+    const size_t P = (size_t)g.rows[o] * g.pitch[o];
     const uint8_t* dog = pyr + f * pframe + g.oct_off[o] + (size_t)VSLAM_NUM_LEVELS * P;
     int d_x, d_y, d_s, nv;
-    dog_differences(dog, P, g.rows[o], g.cols[o], g.pad, pt.level, pt.row, pt.col, d_x, d_y, d_s);
+    dog_differences(dog, P, g.rows[o], g.cols[o], g.pitch[o], g.pad, pt.level, pt.row, pt.col, d_x, d_y, d_s);
     feature_point_localization(d_x, d_y, d_s, pt.value, nv);
     pt.value = nv;
 }

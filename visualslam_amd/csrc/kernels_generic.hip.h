@@ -275,10 +275,18 @@ __global__ __launch_bounds__(256) void k_harris_post(const float* __restrict__ r
 
 // ---- scale-space extrema (initialKeypointDetection, Diff_of_Gauss.cpp:254-297) ------------
 
+// Pitched plane -> dense rows (pyramid getters of widths that are not a multiple of 16).
+__global__ __launch_bounds__(256) void k_pack_rows(const uint8_t* __restrict__ src, int spitch, uint8_t* __restrict__ dst,
+                                                    int rows, int cols) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int r = blockIdx.y;
+    if (c < cols) dst[(size_t)r * cols + c] = src[(size_t)r * spitch + c];
+}
+
 struct ExtGeom {
     int n_oct, window, pad, min_contrast;
     int localize;  // list = FeaturePointLocalization survivors (min_contrast unused)
-    int rows[VSLAM_MAX_OCTAVES], cols[VSLAM_MAX_OCTAVES];
+    int rows[VSLAM_MAX_OCTAVES], cols[VSLAM_MAX_OCTAVES], pitch[VSLAM_MAX_OCTAVES];  // pitch: bytes per plane row
     int lat_rows[VSLAM_MAX_OCTAVES], lat_cols[VSLAM_MAX_OCTAVES], wpr[VSLAM_MAX_OCTAVES];
     unsigned long long oct_off[VSLAM_MAX_OCTAVES];   // byte offset of the octave in a pyramid frame block
     unsigned long long bits_off[VSLAM_MAX_OCTAVES];  // word offset of the octave in a bits frame block
@@ -286,13 +294,13 @@ struct ExtGeom {
 
 // The three finite differences of FeaturePointLocalization (Diff_of_Gauss.cpp:226-228) at padded
 // (i, j) of DoG `level`; padOctave's replicate border = clamped addressing.
-__device__ __forceinline__ void dog_differences(const uint8_t* __restrict__ dog, size_t P, int rows, int cols, int pad,
+__device__ __forceinline__ void dog_differences(const uint8_t* __restrict__ dog, size_t P, int rows, int cols, int pitch, int pad,
                                                 int level, int i, int j, int& d_x, int& d_y, int& d_s) {
     const int r = clampi(i - pad, 0, rows - 1), c = clampi(j - pad, 0, cols - 1);
     const uint8_t* D = dog + (size_t)level * P;
-    d_x = (int)D[(size_t)r * cols + clampi(j - 1 - pad, 0, cols - 1)] - (int)D[(size_t)r * cols + clampi(j + 1 - pad, 0, cols - 1)];
-    d_y = (int)D[(size_t)clampi(i - 1 - pad, 0, rows - 1) * cols + c] - (int)D[(size_t)clampi(i + 1 - pad, 0, rows - 1) * cols + c];
-    d_s = (int)D[(size_t)r * cols + c - P] - (int)D[(size_t)r * cols + c + P];
+    d_x = (int)D[(size_t)r * pitch + clampi(j - 1 - pad, 0, cols - 1)] - (int)D[(size_t)r * pitch + clampi(j + 1 - pad, 0, cols - 1)];
+    d_y = (int)D[(size_t)clampi(i - 1 - pad, 0, rows - 1) * pitch + c] - (int)D[(size_t)clampi(i + 1 - pad, 0, rows - 1) * pitch + c];
+    d_s = (int)D[(size_t)r * pitch + c - P] - (int)D[(size_t)r * pitch + c + P];
 }
 
 // One thread per lattice site; a wave's 64 candidate flags leave as one ballot word, which
@@ -303,15 +311,15 @@ __global__ __launch_bounds__(256) void k_extrema(const uint8_t* __restrict__ pyr
     const int lj = blockIdx.x * 256 + threadIdx.x;
     const int li = blockIdx.y;
     const int f = blockIdx.z / 3, level = blockIdx.z % 3 + 1;
-    const int rows = g.rows[o], cols = g.cols[o], pad = g.pad;
-    const size_t P = (size_t)rows * cols;
+    const int rows = g.rows[o], cols = g.cols[o], pitch = g.pitch[o], pad = g.pad;
+    const size_t P = (size_t)rows * pitch;
     const uint8_t* dog = pyr + f * pframe + g.oct_off[o] + (size_t)VSLAM_NUM_LEVELS * P;
     bool cand = false, listed = false;
     if (lj < g.lat_cols[o]) {
         const int i = pad + li * g.window, j = pad + lj * g.window;  // padded coordinates
         int mn = 256, mx = -1;
         for (int u = i - pad; u < i + pad; ++u) {
-            const size_t ro = (size_t)clampi(u - pad, 0, rows - 1) * cols;
+            const size_t ro = (size_t)clampi(u - pad, 0, rows - 1) * pitch;
             for (int v = j - pad; v < j + pad; ++v) {
                 const size_t idx = ro + clampi(v - pad, 0, cols - 1);
 #pragma unroll
@@ -322,13 +330,13 @@ __global__ __launch_bounds__(256) void k_extrema(const uint8_t* __restrict__ pyr
                 }
             }
         }
-        const int self = dog[(size_t)level * P + (size_t)(i - pad) * cols + (j - pad)];
+        const int self = dog[(size_t)level * P + (size_t)(i - pad) * pitch + (j - pad)];
         cand = self == mn || self == mx;
         if (!g.localize) {
             listed = cand && self >= g.min_contrast;
         } else if (cand) {
             int d_x, d_y, d_s, nv;
-            dog_differences(dog, P, rows, cols, pad, level, i, j, d_x, d_y, d_s);
+            dog_differences(dog, P, rows, cols, pitch, pad, level, i, j, d_x, d_y, d_s);
             listed = feature_point_localization(d_x, d_y, d_s, self, nv);
         }
     }

@@ -34,14 +34,14 @@ struct OrientLevels {  // per Gaussian level of the octave (null / 0 when no key
 // formed on the fly (they are integers, exact in f32).  Window [y-p, y+p) x [x-p, x+p) of the
 // unpadded image at the keypoint's padded coordinates; out-of-image reads (only possible for
 // windowSize > 3, where the reference itself reads out of bounds) are clamped like the oracle.
-__device__ __forceinline__ float edge_response_u8(const uint8_t* __restrict__ G, int rows, int cols, int y, int x, int pad) {
+__device__ __forceinline__ float edge_response_u8(const uint8_t* __restrict__ G, int gpitch, int rows, int cols, int y, int x, int pad) {
     float Ix2 = 0.f, Iy2 = 0.f, IxIy = 0.f;
     for (int u = y - pad; u < y + pad; ++u) {
         const int r = clampi(u, 0, rows - 1);
         for (int v = x - pad; v < x + pad; ++v) {
             const int c = clampi(v, 0, cols - 1);
-            const float gx = (float)((int)G[(size_t)r * cols + reflect101(c + 1, cols)] - (int)G[(size_t)r * cols + reflect101(c - 1, cols)]);
-            const float gy = (float)((int)G[(size_t)reflect101(r + 1, rows) * cols + c] - (int)G[(size_t)reflect101(r - 1, rows) * cols + c]);
+            const float gx = (float)((int)G[(size_t)r * gpitch + reflect101(c + 1, cols)] - (int)G[(size_t)r * gpitch + reflect101(c - 1, cols)]);
+            const float gy = (float)((int)G[(size_t)reflect101(r + 1, rows) * gpitch + c] - (int)G[(size_t)reflect101(r - 1, rows) * gpitch + c]);
             Ix2 += gx * gx;
             Iy2 += gy * gy;
             IxIy += gx * gy;
@@ -53,7 +53,7 @@ __device__ __forceinline__ float edge_response_u8(const uint8_t* __restrict__ G,
 }
 
 // grid = (keypoints), 256 threads, dynamic LDS = orient_lds_bytes(max R).
-__global__ __launch_bounds__(256) void k_orient_keypoints(const vslam_point* __restrict__ kps, int n, OrientLevels lv, int rows, int cols,
+__global__ __launch_bounds__(256) void k_orient_keypoints(const vslam_point* __restrict__ kps, int n, OrientLevels lv, int gpitch, int rows, int cols,
                                                            unsigned long long* __restrict__ masks) {
     extern __shared__ __attribute__((aligned(16))) float orient_smem[];
     __shared__ float mw[OR_WIN * OR_WIN];
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void k_orient_keypoints(const vslam_point* __r
     const int x = kp.col, y = kp.row, level = kp.level;
     if (threadIdx.x == 0) {
         const float r = 10.0f, threshold = ((r + 1.0f) * (r + 1.0f)) / r;  // :331-332
-        const float response = edge_response_u8(lv.gauss[level], rows, cols, y, x, kp.padding);
+        const float response = edge_response_u8(lv.gauss[level], gpitch, rows, cols, y, x, kp.padding);
         keep_s = response < threshold;  // :335
     }
     __syncthreads();

@@ -83,9 +83,9 @@ struct PyrTaps {
 template <class CFG, int L>
 __device__ __forceinline__ void pyr_level(const PyrTaps<CFG>* __restrict__ taps, const uint32_t* __restrict__ rp,
                                           uint32_t* __restrict__ hp, uint8_t* __restrict__ out, size_t P, int cols,
-                                          int rows, int tile_x0, int tile_y0, uint32_t (&prev_e)[4][2],
+                                          int pitch, int rows, int tile_x0, int tile_y0, uint32_t (&prev_e)[4][2],
                                           uint32_t (&prev_o)[4][2], uint8_t* __restrict__ next_base, int nrows,
-                                          int ncols) {
+                                          int ncols, int npitch) {
     constexpr int n = CFG::n(L), dl = CFG::delta(L), A = CFG::A(L);
     constexpr int NCG = CFG::ncg(L), M = CFG::m1(L), NB = CFG::nb(L);
     constexpr int RWP = CFG::RWP, HPP = CFG::HPP, TH = CFG::TH;
@@ -180,25 +180,27 @@ __device__ __forceinline__ void pyr_level(const PyrTaps<CFG>* __restrict__ taps,
             prev_o[jr][hw] = o;
         }
         if (y < rows && x < cols) {
-            const size_t off = (size_t)y * cols + x;
+            const size_t off = (size_t)y * pitch + x;  // the last 8-column group may end in the row padding
             *reinterpret_cast<uint2*>(out + (size_t)L * P + off) = make_uint2(g[0], g[1]);
             if (L > 0) *reinterpret_cast<uint2*>(out + (size_t)(VSLAM_NUM_LEVELS + L - 1) * P + off) = make_uint2(d[0], d[1]);
             // next octave's base = Gaussian[3] decimated 2:1, INTER_NEAREST (GaussPyramid.cpp:123-126):
             // pixel (2y', 2x'); tile origins and (jr, x) are even, so it is the even bytes of even rows
             if (L == 3 && next_base && (jr & 1) == 0 && (y >> 1) < nrows && (x >> 1) < ncols)
-                *reinterpret_cast<uint32_t*>(next_base + (size_t)(y >> 1) * ncols + (x >> 1)) =
+                *reinterpret_cast<uint32_t*>(next_base + (size_t)(y >> 1) * npitch + (x >> 1)) =
                     __builtin_amdgcn_perm(g[1], g[0], 0x06040200);
         }
     }
 }
 
 // grid = (ceil(cols/TW), ceil(rows/TH), frames); block = 256; dynamic LDS = CFG::LDS_BYTES.
-// Requires cols % 8 == 0 (8-byte row stores); rows arbitrary.
+// rows / cols arbitrary; `pitch` (row pitch of the base and of every output plane) and `npitch`
+// (next base) are multiples of 16 and >= the width rounded up to 8 (8-byte row stores).
 template <class CFG>
 __global__ __launch_bounds__(256) void k_pyr_octave(const uint8_t* __restrict__ base, size_t bframe,
                                                      uint8_t* __restrict__ oct_out, size_t pframe, int rows, int cols,
-                                                     const PyrTaps<CFG>* __restrict__ taps, uint8_t* __restrict__ next_base,
-                                                     size_t nframe, int nrows, int ncols) {
+                                                     int pitch, const PyrTaps<CFG>* __restrict__ taps,
+                                                     uint8_t* __restrict__ next_base, size_t nframe, int nrows, int ncols,
+                                                     int npitch) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t* rp = smem;
     uint32_t* hp = smem + CFG::RQ * CFG::RWP;
@@ -207,20 +209,20 @@ __global__ __launch_bounds__(256) void k_pyr_octave(const uint8_t* __restrict__ 
     const int tile_x0 = blockIdx.x * CFG::TW, tile_y0 = blockIdx.y * CFG::TH;
     const uint8_t* src = base + blockIdx.z * bframe;
     uint8_t* out = oct_out + blockIdx.z * pframe;
-    const size_t P = (size_t)rows * cols;
+    const size_t P = (size_t)rows * pitch;
 
     // ---- stage the base tile, byte-transposed ------------------------------------------------
     const bool interior = tile_x0 - R >= 0 && tile_x0 + CFG::TW + R <= cols && tile_y0 - R >= 0 &&
                           tile_y0 + CFG::TH + R <= rows;
-    if (interior && (cols & 15) == 0) {
+    if (interior) {
         // 16 pixels x 4 rows per item: 16-byte coalesced loads, four 4x4 byte transposes, four
         // 16-byte LDS stores (RW is a multiple of 16, tile origin - R is 16-byte aligned)
         for (int it = tid; it < RQ * (RW / 16); it += 256) {
             const int yq = it / (RW / 16), xs = it - yq * (RW / 16);
-            const uint8_t* p = src + (size_t)(tile_y0 - R + 4 * yq) * cols + (tile_x0 - R + 16 * xs);
+            const uint8_t* p = src + (size_t)(tile_y0 - R + 4 * yq) * pitch + (tile_x0 - R + 16 * xs);
             uint4 a[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) a[k] = *reinterpret_cast<const uint4*>(p + (size_t)k * cols);
+            for (int k = 0; k < 4; ++k) a[k] = *reinterpret_cast<const uint4*>(p + (size_t)k * pitch);
             const uint32_t* aw[4] = {&a[0].x, &a[1].x, &a[2].x, &a[3].x};
 #pragma unroll
             for (int q = 0; q < 4; ++q) {  // dword q of each row = pixels 4q..4q+3
@@ -236,22 +238,16 @@ __global__ __launch_bounds__(256) void k_pyr_octave(const uint8_t* __restrict__ 
             }
         }
     } else {
-        // border tiles (and widths that are not a multiple of 16): one dword x 4 rows per item,
-        // BORDER_REFLECT_101 resolved per byte
+        // border tiles: one dword x 4 rows per item, BORDER_REFLECT_101 resolved per byte
         for (int it = tid; it < RQ * (RW / 4); it += 256) {
             const int yq = it / (RW / 4), xq = it - yq * (RW / 4);
             const int gy = tile_y0 - R + 4 * yq, gx = tile_x0 - R + 4 * xq;
             uint32_t a[4];
-            if (interior) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) a[k] = *reinterpret_cast<const uint32_t*>(src + (size_t)(gy + k) * cols + gx);
-            } else {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const uint8_t* row = src + (size_t)reflect101(gy + k, rows) * cols;
-                    a[k] = (uint32_t)row[reflect101(gx, cols)] | ((uint32_t)row[reflect101(gx + 1, cols)] << 8) |
-                           ((uint32_t)row[reflect101(gx + 2, cols)] << 16) | ((uint32_t)row[reflect101(gx + 3, cols)] << 24);
-                }
+            for (int k = 0; k < 4; ++k) {
+                const uint8_t* row = src + (size_t)reflect101(gy + k, rows) * pitch;
+                a[k] = (uint32_t)row[reflect101(gx, cols)] | ((uint32_t)row[reflect101(gx + 1, cols)] << 8) |
+                       ((uint32_t)row[reflect101(gx + 2, cols)] << 16) | ((uint32_t)row[reflect101(gx + 3, cols)] << 24);
             }
             const uint32_t p01l = __builtin_amdgcn_perm(a[1], a[0], 0x05010400), p01h = __builtin_amdgcn_perm(a[1], a[0], 0x07030602);
             const uint32_t p23l = __builtin_amdgcn_perm(a[3], a[2], 0x05010400), p23h = __builtin_amdgcn_perm(a[3], a[2], 0x07030602);
@@ -269,12 +265,12 @@ __global__ __launch_bounds__(256) void k_pyr_octave(const uint8_t* __restrict__ 
 
     uint8_t* nb = next_base ? next_base + blockIdx.z * nframe : nullptr;
     uint32_t prev_e[4][2], prev_o[4][2];
-    pyr_level<CFG, 0>(taps, rp, hp, out, P, cols, rows, tile_x0, tile_y0, prev_e, prev_o, nb, nrows, ncols);
-    pyr_level<CFG, 1>(taps, rp, hp, out, P, cols, rows, tile_x0, tile_y0, prev_e, prev_o, nb, nrows, ncols);
-    pyr_level<CFG, 2>(taps, rp, hp, out, P, cols, rows, tile_x0, tile_y0, prev_e, prev_o, nb, nrows, ncols);
-    pyr_level<CFG, 3>(taps, rp, hp, out, P, cols, rows, tile_x0, tile_y0, prev_e, prev_o, nb, nrows, ncols);
-    pyr_level<CFG, 4>(taps, rp, hp, out, P, cols, rows, tile_x0, tile_y0, prev_e, prev_o, nb, nrows, ncols);
-    pyr_level<CFG, 5>(taps, rp, hp, out, P, cols, rows, tile_x0, tile_y0, prev_e, prev_o, nb, nrows, ncols);
+    pyr_level<CFG, 0>(taps, rp, hp, out, P, cols, pitch, rows, tile_x0, tile_y0, prev_e, prev_o, nb, nrows, ncols, npitch);
+    pyr_level<CFG, 1>(taps, rp, hp, out, P, cols, pitch, rows, tile_x0, tile_y0, prev_e, prev_o, nb, nrows, ncols, npitch);
+    pyr_level<CFG, 2>(taps, rp, hp, out, P, cols, pitch, rows, tile_x0, tile_y0, prev_e, prev_o, nb, nrows, ncols, npitch);
+    pyr_level<CFG, 3>(taps, rp, hp, out, P, cols, pitch, rows, tile_x0, tile_y0, prev_e, prev_o, nb, nrows, ncols, npitch);
+    pyr_level<CFG, 4>(taps, rp, hp, out, P, cols, pitch, rows, tile_x0, tile_y0, prev_e, prev_o, nb, nrows, ncols, npitch);
+    pyr_level<CFG, 5>(taps, rp, hp, out, P, cols, pitch, rows, tile_x0, tile_y0, prev_e, prev_o, nb, nrows, ncols, npitch);
 }
 
 // Host side: pack quantised taps into the operand shapes described at the top.

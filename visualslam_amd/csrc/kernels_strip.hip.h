@@ -33,16 +33,18 @@ struct StripTaps {
 
 // ------------------------------------------------------------------------------ vertical pass
 // grid = (ceil(cols/64), level split 1|2|3|6, frames); dynamic LDS = rhq * 64 * 4 bytes, rhq = (rows4 + 2*RM + 16)/4.
-// Requires cols % 4 == 0.  h: [frame][level][rows][cols] u16.
+// Any width; `pitch` (a multiple of 16) is the row pitch of the base in bytes and of the scratch in
+// elements, so the last 4-column group may run into the row padding.
+// h: [frame][level][rows][pitch] u16.
 __global__ __launch_bounds__(256) void k_gauss_v_strip(const uint8_t* __restrict__ base, size_t bframe,
                                                         uint16_t* __restrict__ h, size_t hframe, int rows, int cols,
-                                                        int RM, int rhq, const StripTaps* __restrict__ taps) {
+                                                        int pitch, int RM, int rhq, const StripTaps* __restrict__ taps) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t* rp = smem;  // [rhq][64]: dword (yq, c) = raw rows 4yq..4yq+3 (ry = y + RM) of column c
     const int tid = threadIdx.x;
     const int x0 = blockIdx.x * STRIP_W;
     const uint8_t* src = base + blockIdx.z * bframe;
-    const size_t P = (size_t)rows * cols;
+    const size_t P = (size_t)rows * pitch;
 
     for (int it = tid; it < rhq * (STRIP_W / 4); it += 256) {
         const int yq = it >> 4, xq = it & 15;
@@ -51,7 +53,7 @@ __global__ __launch_bounds__(256) void k_gauss_v_strip(const uint8_t* __restrict
         if (gx < cols) {
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                a[k] = *reinterpret_cast<const uint32_t*>(src + (size_t)reflect101(4 * yq + k - RM, rows) * cols + gx);
+                a[k] = *reinterpret_cast<const uint32_t*>(src + (size_t)reflect101(4 * yq + k - RM, rows) * pitch + gx);
         }
         const uint32_t p01l = __builtin_amdgcn_perm(a[1], a[0], 0x05010400), p01h = __builtin_amdgcn_perm(a[1], a[0], 0x07030602);
         const uint32_t p23l = __builtin_amdgcn_perm(a[3], a[2], 0x05010400), p23h = __builtin_amdgcn_perm(a[3], a[2], 0x07030602);
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(256) void k_gauss_v_strip(const uint8_t* __restrict
                 for (int j = 0; j < 4; ++j) {
                     const int y = ty0 + j;
                     if (y >= 0 && y < rows)
-                        *reinterpret_cast<uint2*>(hl + (size_t)y * cols + gx) =
+                        *reinterpret_cast<uint2*>(hl + (size_t)y * pitch + gx) =
                             make_uint2(acc[j][0] | (acc[j][1] << 16), acc[j][2] | (acc[j][3] << 16));
                 }
             }
@@ -142,22 +144,23 @@ __device__ __forceinline__ void h_item_level(const uint32_t* __restrict__ hrow, 
 }
 
 // grid = (1, ceil(rows/SH), frames); dynamic LDS = SH * pw * 4 bytes, pw = (cols + 2*(rmax+1) + 8)/2
-// rounded up to a multiple of 4.  Requires cols % 8 == 0 and (cols/8)*(SH/RI) <= 512.
+// rounded up to a multiple of 4.  Any width with ceil(cols/8)*(SH/RI) <= 512; `pitch` / `npitch` (multiples
+// of 16) are the row pitches of the scratch (elements), of the output planes and of the next base.
 // RI = rows per item: 4 amortises the tap loads (batches); 1 spreads a small launch over all
 // 256 threads (a single frame is bound by the latency of one workgroup, not by throughput).
 template <int SH, int RI>
 __global__ __launch_bounds__(256) void k_gauss_h_strip(const uint16_t* __restrict__ h, size_t hframe,
                                                         uint8_t* __restrict__ oct_out, size_t pframe, int rows,
-                                                        int cols, int pw, const StripTaps* __restrict__ taps,
+                                                        int cols, int pitch, int pw, const StripTaps* __restrict__ taps,
                                                         uint8_t* __restrict__ next_base, size_t nframe, int nrows,
-                                                        int ncols) {
+                                                        int ncols, int npitch) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t* hp = smem;  // [SH][pw] u16 pairs; LDS column cx = x + PL
     const int tid = threadIdx.x;
     const int y0 = blockIdx.y * SH;
-    const size_t P = (size_t)rows * cols;
+    const size_t P = (size_t)rows * pitch;
     uint8_t* out = oct_out + blockIdx.z * pframe;
-    const int ncg = cols >> 3, items = ncg * (SH / RI);
+    const int ncg = (cols + 7) >> 3, items = ncg * (SH / RI);
     uint32_t prev_e[2][RI][2], prev_o[2][RI][2];
 
     for (int l = 0; l < VSLAM_NUM_LEVELS; ++l) {
@@ -166,10 +169,13 @@ __global__ __launch_bounds__(256) void k_gauss_h_strip(const uint16_t* __restric
         // ---- stage SH rows, reflect-101 extended, as u16 pairs -------------------------------
         __syncthreads();  // previous level's reads are done
         for (int jr = tid >> 6; jr < SH; jr += 4) {  // one wave per row
-            const uint16_t* row = hl + (size_t)min(y0 + jr, rows - 1) * cols;
+            const uint16_t* row = hl + (size_t)min(y0 + jr, rows - 1) * pitch;
             uint32_t* dstp = hp + jr * pw + (PL >> 1);  // pair index of image column 0
-            // interior: 16-byte coalesced loads (8 columns), LDS side is only 4-byte aligned
-            for (int x8 = tid & 63; x8 < (cols >> 3); x8 += 64) {
+            // interior: 16-byte coalesced loads (8 columns), LDS side is only 4-byte aligned.  The
+            // last group of a width that is not a multiple of 8 brings scratch padding along; the
+            // halo loop below (same wave, later in program order) overwrites every pair with a
+            // column >= cols that a valid output can reach.
+            for (int x8 = tid & 63; x8 < ncg; x8 += 64) {
                 const uint4 v = *reinterpret_cast<const uint4*>(row + 8 * x8);
                 uint32_t* q = dstp + 4 * x8;
                 q[0] = v.x, q[1] = v.y, q[2] = v.z, q[3] = v.w;
@@ -212,12 +218,12 @@ __global__ __launch_bounds__(256) void k_gauss_h_strip(const uint16_t* __restric
                         prev_o[ii][jr][hw] = o;
                     }
                     if (y < rows) {
-                        const size_t off = (size_t)y * cols + x;
+                        const size_t off = (size_t)y * pitch + x;
                         *reinterpret_cast<uint2*>(out + (size_t)l * P + off) = make_uint2(g[0], g[1]);
                         if (l > 0) *reinterpret_cast<uint2*>(out + (size_t)(VSLAM_NUM_LEVELS + l - 1) * P + off) = make_uint2(d[0], d[1]);
                         // next octave's base = Gaussian[3] decimated 2:1 (GaussPyramid.cpp:123-126)
                         if (l == 3 && next_base && (y & 1) == 0 && (y >> 1) < nrows && (x >> 1) < ncols)
-                            *reinterpret_cast<uint32_t*>(next_base + blockIdx.z * nframe + (size_t)(y >> 1) * ncols + (x >> 1)) =
+                            *reinterpret_cast<uint32_t*>(next_base + blockIdx.z * nframe + (size_t)(y >> 1) * npitch + (x >> 1)) =
                                 __builtin_amdgcn_perm(g[1], g[0], 0x06040200);
                     }
                 }

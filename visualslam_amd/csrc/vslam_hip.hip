@@ -85,7 +85,7 @@ static int fail(vslam_ctx* c, int code, const std::string& msg) {
 static const char* const kKernelNames =
     "k_harris_fused\nk_harris_post\nk_resize_linear2x\nk_blur_h_generic\nk_blur_v_generic\n"
     "k_dog5\nk_resize_nearest_half\nk_extrema\nk_pyr_octave\n"
-    "k_gauss_v_strip\nk_gauss_h_strip\nk_resize_linear2x_slide\nk_resize_nearest_half_v4\nk_extrema_w3\nk_localize_points\nk_points_localize_value\nk_orient_keypoints\nk_edge_response_windows\nk_level_gradients\n"
+    "k_gauss_v_strip\nk_gauss_h_strip\nk_resize_linear2x_slide\nk_resize_nearest_half_v4\nk_extrema_w3\nk_localize_points\nk_points_localize_value\nk_orient_keypoints\nk_edge_response_windows\nk_level_gradients\nk_pack_rows\n"
     "k_harris_strip\nk_flag_count\nk_chunk_scan\nk_flag_scatter\nk_level_gradients";
 
 static std::pair<hipEvent_t, hipEvent_t>* timing_slot(vslam_ctx* c);
@@ -248,6 +248,10 @@ static bool matches_cfg(const int ks[6]) {
     return true;
 }
 
+// u16-pair columns of one staged row of the horizontal strip pass (left halo + ceil(cols/8) groups
+// + right halo of the widest kernel), a multiple of 4
+static int strip_pw(int cols, int nmax) { return ((cols + 7) / 2 + nmax / 2 + 12 + 3) & ~3; }
+
 static OctPlan plan_octave(double sigma0, int o, int rows, int cols) {
     OctPlan pl;
     int nmax = 0;
@@ -258,7 +262,7 @@ static OctPlan plan_octave(double sigma0, int o, int rows, int cols) {
         pl.ke[l] = (int)pl.taps[l].size();
         nmax = std::max(nmax, pl.ke[l]);
     }
-    if (cols % 8 != 0 || !taps_fit_u8(pl)) return pl;
+    if (!taps_fit_u8(pl)) return pl;
     if (matches_cfg<PyrCfgOct0>(pl.ke)) {
         pl.path = OctPath::Tile0;
     } else if (matches_cfg<PyrCfgOct1>(pl.ke)) {
@@ -267,7 +271,7 @@ static OctPlan plan_octave(double sigma0, int o, int rows, int cols) {
         const int RM = (nmax / 2 + 3) & ~3;
         const size_t v_lds = (size_t)((((rows + 3) & ~3) + 2 * RM + 16) / 4) * STRIP_W * 4;
         pl.sh = cols <= 1024 ? 16 : cols <= 2048 ? 8 : cols <= 4096 ? 4 : 0;
-        const size_t pw = (size_t)((cols / 2 + nmax / 2 + 8 + 3) & ~3);
+        const size_t pw = (size_t)strip_pw(cols, nmax);
         if (pl.sh && v_lds <= 150 * 1024 && pl.sh * pw * 4 <= 150 * 1024) pl.path = OctPath::Strip;
     }
     return pl;
@@ -294,14 +298,15 @@ static int get_strip_taps(vslam_ctx* c, double sigma0, int o, const OctPlan& pl,
 
 template <int SH, int RI>
 static int launch_h_strip(vslam_ctx* c, const uint16_t* h, size_t hframe, uint8_t* oct, size_t pframe, int rows, int cols,
-                          int pw, int nf, const StripTaps* taps, uint8_t* next_base, size_t nframe, int nrows, int ncols) {
+                          int pitch, int pw, int nf, const StripTaps* taps, uint8_t* next_base, size_t nframe, int nrows, int ncols,
+                          int npitch) {
     const size_t lds = (size_t)SH * pw * 4;
     HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gauss_h_strip<SH, RI>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     {
         TimedScope ts(c, "k_gauss_h_strip");
         hipLaunchKernelGGL((k_gauss_h_strip<SH, RI>), dim3(1, (rows + SH - 1) / SH, nf), dim3(256), lds, c->stream, h, hframe, oct,
-                           pframe, rows, cols, pw, taps, next_base, nframe, nrows, ncols);
+                           pframe, rows, cols, pitch, pw, taps, next_base, nframe, nrows, ncols, npitch);
     }
     HIPCHK(c, hipGetLastError());
     return VSLAM_OK;
@@ -309,8 +314,8 @@ static int launch_h_strip(vslam_ctx* c, const uint16_t* h, size_t hframe, uint8_
 
 // Coarse octave: vertical strips (dot4) into the u16 scratch, then horizontal strips (dot2).
 static int enqueue_strip_octave(vslam_ctx* c, double sigma0, int o, const OctPlan& pl, const uint8_t* base, size_t bframe,
-                                uint8_t* oct, size_t pframe, uint16_t* h, int rows, int cols, int nf, uint8_t* next_base,
-                                size_t nframe, int nrows, int ncols) {
+                                uint8_t* oct, size_t pframe, uint16_t* h, int rows, int cols, int pitch, int nf,
+                                uint8_t* next_base, size_t nframe, int nrows, int ncols, int npitch) {
     const StripTaps* taps;
     TRY(get_strip_taps(c, sigma0, o, pl, &taps));
     int nmax = 0;
@@ -318,7 +323,7 @@ static int enqueue_strip_octave(vslam_ctx* c, double sigma0, int o, const OctPla
     const int RM = (nmax / 2 + 3) & ~3;
     const int rhq = (((rows + 3) & ~3) + 2 * RM + 16) / 4;
     const size_t v_lds = (size_t)rhq * STRIP_W * 4;
-    const size_t P = (size_t)rows * cols;
+    const size_t P = (size_t)rows * pitch;
     HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gauss_v_strip),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)v_lds));
     {
@@ -328,20 +333,20 @@ static int enqueue_strip_octave(vslam_ctx* c, double sigma0, int o, const OctPla
         const int want = (256 + strips * nf - 1) / (strips * nf);
         const int lsplit = want >= 6 ? 6 : want >= 3 ? 3 : want >= 2 ? 2 : 1;
         hipLaunchKernelGGL(k_gauss_v_strip, dim3(strips, lsplit, nf), dim3(256), v_lds, c->stream, base, bframe, h, 6 * P, rows, cols,
-                           RM, rhq, taps);
+                           pitch, RM, rhq, taps);
     }
     HIPCHK(c, hipGetLastError());
-    const int pw = (cols / 2 + nmax / 2 + 8 + 3) & ~3;
+    const int pw = strip_pw(cols, nmax);
     // small batches: shorter row strips, more workgroups
     int sh = pl.sh;
     while (sh > 4 && (long)((rows + sh - 1) / sh) * nf < 256) sh >>= 1;
     // ... and, when even that leaves most threads without an item, one row per item
-    const bool fine = sh == 4 && (long)((rows + 3) / 4) * nf < 256 && (cols / 8) * 4 <= 512;
-    if (fine) return launch_h_strip<4, 1>(c, h, 6 * P, oct, pframe, rows, cols, pw, nf, taps, next_base, nframe, nrows, ncols);
+    const bool fine = sh == 4 && (long)((rows + 3) / 4) * nf < 256 && ((cols + 7) / 8) * 4 <= 512;
+    if (fine) return launch_h_strip<4, 1>(c, h, 6 * P, oct, pframe, rows, cols, pitch, pw, nf, taps, next_base, nframe, nrows, ncols, npitch);
     switch (sh) {
-        case 16: return launch_h_strip<16, 4>(c, h, 6 * P, oct, pframe, rows, cols, pw, nf, taps, next_base, nframe, nrows, ncols);
-        case 8: return launch_h_strip<8, 4>(c, h, 6 * P, oct, pframe, rows, cols, pw, nf, taps, next_base, nframe, nrows, ncols);
-        default: return launch_h_strip<4, 4>(c, h, 6 * P, oct, pframe, rows, cols, pw, nf, taps, next_base, nframe, nrows, ncols);
+        case 16: return launch_h_strip<16, 4>(c, h, 6 * P, oct, pframe, rows, cols, pitch, pw, nf, taps, next_base, nframe, nrows, ncols, npitch);
+        case 8: return launch_h_strip<8, 4>(c, h, 6 * P, oct, pframe, rows, cols, pitch, pw, nf, taps, next_base, nframe, nrows, ncols, npitch);
+        default: return launch_h_strip<4, 4>(c, h, 6 * P, oct, pframe, rows, cols, pitch, pw, nf, taps, next_base, nframe, nrows, ncols, npitch);
     }
 }
 
@@ -387,6 +392,7 @@ static void fill_geom(const vslam_params& p, const vslam_batch_layout& L, ExtGeo
     for (int o = 0; o < L.n_octaves; ++o) {
         g.rows[o] = L.rows[o];
         g.cols[o] = L.cols[o];
+        g.pitch[o] = L.pitch[o];
         g.lat_rows[o] = L.lat_rows[o];
         g.lat_cols[o] = L.lat_cols[o];
         g.wpr[o] = L.lat_words[o];
@@ -409,7 +415,7 @@ struct DogScratch {
 static size_t dog_h_elems(const vslam_batch_layout& L, double sigma0) {
     size_t m = 0;
     for (int o = 0; o < L.n_octaves; ++o) {
-        const size_t P = (size_t)L.rows[o] * L.cols[o];
+        const size_t P = (size_t)L.rows[o] * L.pitch[o];
         const OctPath path = plan_octave(sigma0, o, L.rows[o], L.cols[o]).path;
         if (path == OctPath::Strip) m = std::max(m, 6 * P);
         if (path == OctPath::Generic) m = std::max(m, P);
@@ -419,7 +425,7 @@ static size_t dog_h_elems(const vslam_batch_layout& L, double sigma0) {
 
 static size_t dog_scratch_bytes(const vslam_batch_layout& L, double sigma0, int nf) {
     size_t sum_p = 0;
-    for (int o = 0; o < L.n_octaves; ++o) sum_p += (size_t)L.rows[o] * L.cols[o];
+    for (int o = 0; o < L.n_octaves; ++o) sum_p += (size_t)L.rows[o] * L.pitch[o];
     return ws_need((size_t)nf * sum_p) + ws_need((size_t)nf * dog_h_elems(L, sigma0) * 2 + 256) +
            ws_need((size_t)nf * L.bits_frame_words * 8) + ws_need(4 * compaction_ws_elems(L.bits_frame_words, nf));
 }
@@ -427,8 +433,8 @@ static size_t dog_scratch_bytes(const vslam_batch_layout& L, double sigma0, int 
 static int dog_scratch_take(vslam_ctx* c, const vslam_batch_layout& L, double sigma0, int nf, DogScratch& s) {
     size_t sum_p = 0;
     for (int o = 0; o < L.n_octaves; ++o) {
-        s.base_off[o] = sum_p;
-        sum_p += (size_t)L.rows[o] * L.cols[o];
+        s.base_off[o] = sum_p;  // octave bases keep the pitched rows of the pyramid planes
+        sum_p += (size_t)L.rows[o] * L.pitch[o];
     }
     s.bases_frame = sum_p;
     s.bases = ws_take<uint8_t>(c, (size_t)nf * sum_p);
@@ -443,8 +449,8 @@ static int dog_scratch_take(vslam_ctx* c, const vslam_batch_layout& L, double si
 // Fused LDS-tiled octave (kernels_pyramid.hip.h); the plan has already matched CFG's widths.
 template <class CFG>
 static int enqueue_pyr_octave(vslam_ctx* c, double sigma0, int o, const OctPlan& pl, const uint8_t* base, size_t bframe,
-                              uint8_t* oct_out, size_t pframe, int rows, int cols, int nf, uint8_t* next_base, size_t nframe,
-                              int nrows, int ncols) {
+                              uint8_t* oct_out, size_t pframe, int rows, int cols, int pitch, int nf, uint8_t* next_base,
+                              size_t nframe, int nrows, int ncols, int npitch) {
     uint64_t sb;
     std::memcpy(&sb, &sigma0, 8);
     auto key = std::make_pair(sb, o);
@@ -466,7 +472,7 @@ static int enqueue_pyr_octave(vslam_ctx* c, double sigma0, int o, const OctPlan&
     {
         TimedScope ts(c, "k_pyr_octave");
         hipLaunchKernelGGL(k_pyr_octave<CFG>, grid, dim3(256), CFG::LDS_BYTES, c->stream, base, bframe, oct_out, pframe, rows,
-                           cols, taps, next_base, nframe, nrows, ncols);
+                           cols, pitch, taps, next_base, nframe, nrows, ncols, npitch);
     }
     HIPCHK(c, hipGetLastError());
     return VSLAM_OK;
@@ -484,45 +490,38 @@ static int enqueue_dog(vslam_ctx* c, const vslam_params& p, const vslam_batch_la
     fill_geom(p, L, g);
     if (p.cols % 4 == 0 && fstep == (size_t)p.cols && fframe % 4 == 0)
         LAUNCH(c, "k_resize_linear2x_slide", k_resize_linear2x_slide, dim3((p.cols / 4 + 255) / 256, (p.rows + 15) / 16, nf),
-               dim3(256), frames, fframe, s.bases + s.base_off[0], s.bases_frame, p.rows, p.cols, 16);
+               dim3(256), frames, fframe, s.bases + s.base_off[0], s.bases_frame, L.pitch[0], p.rows, p.cols, 16);
     else
         LAUNCH(c, "k_resize_linear2x", k_resize_linear2x, grid_rows(2 * p.cols, 2 * p.rows, nf), dim3(256), frames, fstep,
-               fframe, s.bases + s.base_off[0], (size_t)L.cols[0], s.bases_frame, p.rows, p.cols);
+               fframe, s.bases + s.base_off[0], (size_t)L.pitch[0], s.bases_frame, p.rows, p.cols);
     for (int o = 0; o < L.n_octaves; ++o) {
-        const int rows = L.rows[o], cols = L.cols[o];
-        const size_t P = (size_t)rows * cols;
+        const int rows = L.rows[o], cols = L.cols[o], pitch = L.pitch[o];
+        const size_t P = (size_t)rows * pitch;
         const uint8_t* base = s.bases + s.base_off[o];
         uint8_t* oct = pyr + L.octave_offset[o];
         const OctPlan pl = plan_octave(p.sigma0, o, rows, cols);
         // the fast octave kernels also emit the next octave's base (Gaussian[3] decimated 2:1)
         const bool has_next = o + 1 < L.n_octaves;
-        const bool fuse_next = has_next && pl.path != OctPath::Generic && L.cols[o + 1] % 4 == 0 && s.base_off[o + 1] % 4 == 0 &&
-                               s.bases_frame % 4 == 0;
+        const bool fuse_next = has_next && pl.path != OctPath::Generic;
         uint8_t* nb = fuse_next ? s.bases + s.base_off[o + 1] : nullptr;
-        const int nr = has_next ? L.rows[o + 1] : 0, nc = has_next ? L.cols[o + 1] : 0;
+        const int nr = has_next ? L.rows[o + 1] : 0, nc = has_next ? L.cols[o + 1] : 0, np = has_next ? L.pitch[o + 1] : 0;
         if (pl.path == OctPath::Tile0)
-            TRY(enqueue_pyr_octave<PyrCfgOct0>(c, p.sigma0, o, pl, base, s.bases_frame, oct, pframe, rows, cols, nf, nb, s.bases_frame, nr, nc));
+            TRY(enqueue_pyr_octave<PyrCfgOct0>(c, p.sigma0, o, pl, base, s.bases_frame, oct, pframe, rows, cols, pitch, nf, nb, s.bases_frame, nr, nc, np));
         else if (pl.path == OctPath::Tile1)
-            TRY(enqueue_pyr_octave<PyrCfgOct1>(c, p.sigma0, o, pl, base, s.bases_frame, oct, pframe, rows, cols, nf, nb, s.bases_frame, nr, nc));
+            TRY(enqueue_pyr_octave<PyrCfgOct1>(c, p.sigma0, o, pl, base, s.bases_frame, oct, pframe, rows, cols, pitch, nf, nb, s.bases_frame, nr, nc, np));
         else if (pl.path == OctPath::Strip)
-            TRY(enqueue_strip_octave(c, p.sigma0, o, pl, base, s.bases_frame, oct, pframe, s.h, rows, cols, nf, nb, s.bases_frame, nr, nc));
+            TRY(enqueue_strip_octave(c, p.sigma0, o, pl, base, s.bases_frame, oct, pframe, s.h, rows, cols, pitch, nf, nb, s.bases_frame, nr, nc, np));
         else {
             for (int l = 0; l < VSLAM_NUM_LEVELS; ++l)
-                TRY(enqueue_blur(c, base, (size_t)cols, s.bases_frame, oct + (size_t)l * P, (size_t)cols, pframe, s.h, rows,
+                TRY(enqueue_blur(c, base, (size_t)pitch, s.bases_frame, oct + (size_t)l * P, (size_t)pitch, pframe, s.h, rows,
                                  cols, nf, pl.ks[l], pl.sg[l]));
             LAUNCH(c, "k_dog5", k_dog5, dim3((unsigned)((P + 255) / 256), 1, nf), dim3(256), oct,
                    oct + (size_t)VSLAM_NUM_LEVELS * P, P, pframe);
         }
-        if (has_next && !fuse_next) {
-            if (cols % 8 == 0 && (L.octave_offset[o] + 3 * P) % 8 == 0 && s.base_off[o + 1] % 4 == 0 && s.bases_frame % 4 == 0)
-                LAUNCH(c, "k_resize_nearest_half_v4", k_resize_nearest_half_v4,
-                       dim3((L.cols[o + 1] / 4 + 255) / 256, L.rows[o + 1], nf), dim3(256), oct + (size_t)3 * P, pframe,
-                       s.bases + s.base_off[o + 1], s.bases_frame, rows, cols, L.rows[o + 1], L.cols[o + 1]);
-            else
-                LAUNCH(c, "k_resize_nearest_half", k_resize_nearest_half, grid_rows(L.cols[o + 1], L.rows[o + 1], nf),
-                       dim3(256), oct + (size_t)3 * P, (size_t)cols, pframe, s.bases + s.base_off[o + 1],
-                       (size_t)L.cols[o + 1], s.bases_frame, rows, cols, L.rows[o + 1], L.cols[o + 1]);
-        }
+        if (has_next && !fuse_next)
+            LAUNCH(c, "k_resize_nearest_half_v4", k_resize_nearest_half_v4, dim3((L.cols[o + 1] / 4 + 256) / 256, L.rows[o + 1], nf),
+                   dim3(256), oct + (size_t)3 * P, pframe, pitch, s.bases + s.base_off[o + 1], s.bases_frame, L.pitch[o + 1], rows,
+                   L.rows[o + 1], L.cols[o + 1]);
         if (do_extrema && L.lat_rows[o] > 0 && L.lat_cols[o] > 0) {
             hipStream_t es = c->stream;
             if (side) {
@@ -530,7 +529,7 @@ static int enqueue_dog(vslam_ctx* c, const vslam_params& p, const vslam_batch_la
                 HIPCHK(c, hipStreamWaitEvent(side, c->ev_oct[o], 0));
                 es = side;
             }
-            if (p.extrema_window == 3 && cols % 16 == 0) {
+            if (p.extrema_window == 3) {
                 const dim3 eg((L.lat_words[o] + 3) / 4, L.lat_rows[o], nf);
                 if (p.localize)
                     hipLaunchKernelGGL(k_extrema_w3<true>, eg, dim3(256), 0, es, pyr, pframe, g, o, bits, s.lflags, L.bits_frame_words);
@@ -763,7 +762,7 @@ int vslam_resize_linear2x_u8(vslam_ctx* c, const uint8_t* src, int rows, int col
     TRY(h2d(c, d_src, cols, src, step, cols, rows));
     if (cols % 4 == 0)
         LAUNCH(c, "k_resize_linear2x_slide", k_resize_linear2x_slide, dim3((cols / 4 + 255) / 256, (rows + 15) / 16, 1), dim3(256),
-               d_src, P, d_dst, 4 * P, rows, cols, 16);
+               d_src, P, d_dst, 4 * P, 2 * cols, rows, cols, 16);
     else
         LAUNCH(c, "k_resize_linear2x", k_resize_linear2x, grid_rows(2 * cols, 2 * rows), dim3(256), d_src, (size_t)cols, P,
                d_dst, (size_t)2 * cols, 4 * P, rows, cols);
@@ -947,7 +946,7 @@ int vslam_pyramid_build_u8(vslam_ctx* c, const uint8_t* img, int rows, int cols,
         py->info.rows[o] = L.rows[o];
         py->info.cols[o] = L.cols[o];
         py->base_off[o] = sum_p;
-        sum_p += (size_t)L.rows[o] * L.cols[o];
+        sum_p += (size_t)L.rows[o] * L.pitch[o];
         for (int l = 0; l < VSLAM_NUM_LEVELS; ++l) {
             py->info.sigma[o][l] = sigma_at(sigma0, o, l);
             py->info.ksize[o][l] = gauss_ksize_u8(py->info.sigma[o][l]);
@@ -995,8 +994,15 @@ int vslam_pyramid_get_info(const vslam_pyramid* py, vslam_pyramid_info* out) {
 static int pyramid_fetch(const vslam_pyramid* py, int octave, const uint8_t* d_src, uint8_t* dst, size_t dst_step) {
     vslam_ctx* c = py->ctx;
     TRY(bind_device(c));
-    const int rows = py->layout.rows[octave], cols = py->layout.cols[octave];
+    const int rows = py->layout.rows[octave], cols = py->layout.cols[octave], pitch = py->layout.pitch[octave];
     ARGCHK(c, dst && dst_step >= (size_t)cols, "pyramid getter: bad destination");
+    if (pitch != cols) {  // pitched plane: pack the rows on the device, then one linear copy
+        const size_t P = (size_t)rows * cols;
+        TRY(ws_reserve(c, ws_need(P)));
+        uint8_t* d_dense = ws_take<uint8_t>(c, P);
+        LAUNCH(c, "k_pack_rows", k_pack_rows, grid_rows(cols, rows), dim3(256), d_src, pitch, d_dense, rows, cols);
+        d_src = d_dense;
+    }
     TRY(d2h(c, dst, dst_step, d_src, cols, cols, rows));
     return vslam_ctx_sync(c);
 }
@@ -1011,7 +1017,7 @@ int vslam_pyramid_get_gauss(const vslam_pyramid* py, int octave, int level, uint
     if (!py) return VSLAM_ERR_INVALID;
     if (octave < 0 || octave >= py->layout.n_octaves || level < 0 || level >= VSLAM_NUM_LEVELS)
         return fail(py->ctx, VSLAM_ERR_RANGE, "octave/level out of range");
-    const size_t P = (size_t)py->layout.rows[octave] * py->layout.cols[octave];
+    const size_t P = (size_t)py->layout.rows[octave] * py->layout.pitch[octave];
     return pyramid_fetch(py, octave, py->d_block + py->layout.octave_offset[octave] + (size_t)level * P, dst, dst_step);
 }
 
@@ -1019,7 +1025,7 @@ int vslam_pyramid_get_dog(const vslam_pyramid* py, int octave, int level, uint8_
     if (!py) return VSLAM_ERR_INVALID;
     if (octave < 0 || octave >= py->layout.n_octaves || level < 0 || level >= VSLAM_NUM_DOGS)
         return fail(py->ctx, VSLAM_ERR_RANGE, "octave/level out of range");
-    const size_t P = (size_t)py->layout.rows[octave] * py->layout.cols[octave];
+    const size_t P = (size_t)py->layout.rows[octave] * py->layout.pitch[octave];
     return pyramid_fetch(py, octave,
                          py->d_block + py->layout.octave_offset[octave] + (size_t)(VSLAM_NUM_LEVELS + level) * P, dst,
                          dst_step);
@@ -1042,8 +1048,9 @@ int vslam_pyramid_get_gradients(const vslam_pyramid* py, int octave, int level, 
         float* d = ws_take<float>(c, P);
         dev[i] = host[i] ? d : nullptr;
     }
-    const uint8_t* g = py->d_block + py->layout.octave_offset[octave] + (size_t)level * P;
-    LAUNCH(c, "k_level_gradients", k_level_gradients, grid_rows(cols, rows), dim3(256), g, rows, cols, dev[0], dev[1], dev[2],
+    const int pitch = py->layout.pitch[octave];
+    const uint8_t* g = py->d_block + py->layout.octave_offset[octave] + (size_t)level * rows * pitch;
+    LAUNCH(c, "k_level_gradients", k_level_gradients, grid_rows(cols, rows), dim3(256), g, pitch, rows, cols, dev[0], dev[1], dev[2],
            dev[3]);
     for (int i = 0; i < 4; ++i)
         if (host[i]) TRY(d2h(c, host[i], dst_step, dev[i], 4 * (size_t)cols, 4 * (size_t)cols, rows));
@@ -1075,7 +1082,7 @@ static int dog_points_host(vslam_ctx* c, const vslam_pyramid* py, int octave, in
     HIPCHK(c, hipMemsetAsync(d_n, 0, 4, c->stream));
     const size_t ow = (size_t)3 * L.lat_rows[octave] * L.lat_words[octave];
     if (ow) {
-        if (window == 3 && L.cols[octave] % 16 == 0) {
+        if (window == 3) {
             const dim3 eg((L.lat_words[octave] + 3) / 4, L.lat_rows[octave], 1);
             if (localize)
                 LAUNCH(c, "k_extrema_w3", k_extrema_w3<true>, eg, dim3(256), py->d_block, L.pyramid_frame_bytes, g, octave, d_bits, d_lf, words);
@@ -1137,8 +1144,8 @@ int vslam_filter_keypoints(vslam_ctx* c, const vslam_pyramid* py, int octave, co
     ARGCHK(c, n <= 0x7fffffff, "filterKeypoints: too many keypoints");
     *count = 0;
     if (n == 0) return VSLAM_OK;
-    const int rows = py->layout.rows[octave], cols = py->layout.cols[octave];
-    const size_t P = (size_t)rows * cols;
+    const int rows = py->layout.rows[octave], cols = py->layout.cols[octave], pitch = py->layout.pitch[octave];
+    const size_t P = (size_t)rows * cols;  // dense f32 scratch images
     // what the reference would throw on (vector::at, Rect outside the padded Mat) is an error here
     bool used[VSLAM_NUM_LEVELS] = {};
     for (size_t i = 0; i < n; ++i) {
@@ -1176,10 +1183,10 @@ int vslam_filter_keypoints(vslam_ctx* c, const vslam_pyramid* py, int octave, co
         if (!used[l]) continue;
         float* d_mag = ws_take<float>(c, P);
         float* d_ori = ws_take<float>(c, P);
-        const uint8_t* g = py->d_block + py->layout.octave_offset[octave] + (size_t)l * P;
+        const uint8_t* g = py->d_block + py->layout.octave_offset[octave] + (size_t)l * rows * pitch;
         // processGradients for the level (GaussPyramid.cpp:65-104): magnitude and orientation only
-        LAUNCH(c, "k_level_gradients", k_level_gradients, grid_rows(cols, rows), dim3(256), g, rows, cols, (float*)nullptr, (float*)nullptr,
-               d_mag, d_ori);
+        LAUNCH(c, "k_level_gradients", k_level_gradients, grid_rows(cols, rows), dim3(256), g, pitch, rows, cols, (float*)nullptr,
+               (float*)nullptr, d_mag, d_ori);
         HIPCHK(c, hipMemcpyAsync(d_taps + toff, taps[l].data(), 4 * taps[l].size(), hipMemcpyHostToDevice, c->stream));
         lv.gauss[l] = g;
         lv.mag[l] = d_mag;
@@ -1192,7 +1199,7 @@ int vslam_filter_keypoints(vslam_ctx* c, const vslam_pyramid* py, int octave, co
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_orient_keypoints), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     {
         TimedScope ts(c, "k_orient_keypoints");
-        hipLaunchKernelGGL(k_orient_keypoints, dim3((unsigned)n), dim3(256), lds, c->stream, d_kps, (int)n, lv, rows, cols, d_masks);
+        hipLaunchKernelGGL(k_orient_keypoints, dim3((unsigned)n), dim3(256), lds, c->stream, d_kps, (int)n, lv, pitch, rows, cols, d_masks);
     }
     HIPCHK(c, hipGetLastError());
     OrientEntries ent{d_masks, d_kps, n, d_out};

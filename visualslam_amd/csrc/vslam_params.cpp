@@ -129,9 +129,10 @@ int make_layout(const vslam_params* p, vslam_batch_layout* L) {
         L->lat_words[o] = (L->lat_cols[o] + 63) / 64;
         L->octave_offset[o] = off;
         L->bits_offset[o] = woff;
+        L->pitch[o] = (c + 15) & ~15;
         const size_t P = (size_t)r * c;
         sum_p += P;
-        off += (VSLAM_NUM_LEVELS + VSLAM_NUM_DOGS) * P;
+        off += (VSLAM_NUM_LEVELS + VSLAM_NUM_DOGS) * ((size_t)r * L->pitch[o]);
         woff += (size_t)3 * L->lat_rows[o] * L->lat_words[o];
         half_size(r, c, &r, &c);
     }
