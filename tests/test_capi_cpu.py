@@ -33,7 +33,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
         assert hasattr(lib, n), f"{n} declared in include/vslam.h but not exported"
     assert set(names) == set(capi.SIGNATURES), "capi.SIGNATURES out of sync with include/vslam.h"
     assert lib.vslam_version() == 100
-    assert b"k_harris_fused" in lib.vslam_kernel_names()
+    assert b"k_harris_strip" in lib.vslam_kernel_names()
 
 
 def test_struct_sizes_match_reference_types():

@@ -19,25 +19,31 @@ namespace vslam {
 //   dst(2m)   = ((A(m-1) >> 2) + ((3 A(m)) >> 2) + 2) >> 2
 //   dst(2m+1) = (((3 A(m)) >> 2) + (A(m+1) >> 2) + 2) >> 2
 // which is bit-identical to the literal formula (k_resize_linear2x in kernels_generic.hip.h;
-// clamped reads at the borders reproduce OpenCV's border rule because the weights sum to 2048).  Requires cols % 4 == 0.  grid = (ceil(cols/4/256), ceil(rows/seg), frames).
+// clamped reads at the borders reproduce OpenCV's border rule because the weights sum to 2048).  Any width and source step; dpitch >= 2*cols rounded up to 8.  grid = (ceil(ceil(cols/4)/256), ceil(rows/seg), frames).
 typedef unsigned short us2r_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pk_lshr_u16(uint32_t a, int sh) {
     return __builtin_bit_cast(uint32_t, (us2r_t)(__builtin_bit_cast(us2r_t, a) >> (unsigned short)sh));
 }
 
-__global__ __launch_bounds__(256) void k_resize_linear2x_slide(const uint8_t* __restrict__ src, size_t sframe,
+__global__ __launch_bounds__(256) void k_resize_linear2x_slide(const uint8_t* __restrict__ src, size_t sstep, size_t sframe,
                                                                 uint8_t* __restrict__ dst, size_t dframe, int dpitch,
                                                                 int rows, int cols, int seg) {
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (4 * k >= cols) return;
+    const bool whole = 4 * k + 3 < cols;  // last group of a width that is not a multiple of 4: clamp per byte
     const int m0 = blockIdx.y * seg, m1 = min(m0 + seg, rows);
     const uint8_t* s = src + blockIdx.z * sframe;
     uint8_t* d = dst + blockIdx.z * dframe + 8 * k;
     const int xl = max(4 * k - 1, 0), xr = min(4 * k + 4, cols - 1);
     // X = A >> 2 and Y = 3A >> 2 of one source row, as (j0,j2) (j1,j3) (j4,j6) (j5,j7) 16-bit pairs
     auto hrow = [&](int m, uint32_t (&X)[4], uint32_t (&Y)[4]) {
-        const uint8_t* r = s + (size_t)min(max(m, 0), rows - 1) * cols;
-        const uint32_t w = *reinterpret_cast<const uint32_t*>(r + 4 * k);  // s1 s2 s3 s4
+        const uint8_t* r = s + (size_t)min(max(m, 0), rows - 1) * sstep;
+        uint32_t w;  // s1 s2 s3 s4; rows of an arbitrary width / step are not dword aligned: 4-byte copy
+        if (whole)
+            __builtin_memcpy(&w, r + 4 * k, 4);
+        else
+            w = (uint32_t)r[4 * k] | ((uint32_t)r[min(4 * k + 1, cols - 1)] << 8) | ((uint32_t)r[min(4 * k + 2, cols - 1)] << 16) |
+                ((uint32_t)r[cols - 1] << 24);
         const uint32_t s0 = r[xl], s5 = r[xr];
         const uint32_t P = __builtin_amdgcn_perm(w, w, 0x0c010c00);   // (s1, s2)
         const uint32_t Q = __builtin_amdgcn_perm(w, w, 0x0c030c02);   // (s3, s4)

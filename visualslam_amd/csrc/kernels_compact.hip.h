@@ -54,36 +54,6 @@ struct HarrisStripEntries {  // entry = (row, strip): 4 ballot words (pixel slot
     }
 };
 
-struct HarrisWordEntries {  // entry = 64 consecutive pixels of a row (fallback Harris path)
-    const unsigned long long* flags;
-    size_t fframe;
-    int rows, cols, wpr;
-    const float* resp;
-    size_t rframe;
-    vslam_kp* out;
-    __device__ size_t count() const { return (size_t)rows * wpr; }
-    __device__ unsigned int load(int f, size_t e, unsigned long long (&w)[4]) const {
-        w[0] = flags[f * fframe + e];
-        return __popcll(w[0]);
-    }
-    __device__ void emit(int f, size_t e, const unsigned long long (&w)[4], unsigned int pos, unsigned int cap) const {
-        const int r = (int)(e / wpr), c0 = (int)(e % wpr) * 64;
-        unsigned long long m = w[0];
-        while (m) {
-            const int b = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            if (pos < cap) {
-                vslam_kp kp;
-                kp.row = r;
-                kp.col = c0 + b;
-                kp.response = resp[f * rframe + (size_t)r * cols + c0 + b];
-                out[(size_t)f * cap + pos] = kp;
-            }
-            ++pos;
-        }
-    }
-};
-
 struct DogEntries {  // entry = one 64-site word of the (octave, level, lattice row) bitmask layout
     const unsigned long long* lflags;
     size_t bframe;

@@ -1,7 +1,7 @@
 // Generic (any size / any window / any kernel width) HIP kernels for gfx950.
 // They back the host-buffer primitives of include/vslam.h for arbitrary parameters and
 // are the fallback of the batched path for parameter sets the specialised kernels
-// (kernels_harris.hip.h, kernels_pyramid.hip.h) do not cover.  One thread per output
+// (kernels_harris_strip.hip.h, kernels_pyramid.hip.h) do not cover.  One thread per output
 // element, coalesced row accesses, caches do the rest.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -234,43 +234,6 @@ __global__ __launch_bounds__(256) void k_nms2_generic(const float* __restrict__ 
         for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
         if ((threadIdx.x & 63) == 0 && m > 0.0f) atomicMax(true_max_bits, __float_as_uint(m));
     }
-}
-
-// ---- Harris post-processing for the default windows (3 and 5) ----------------------------
-// One pass over the response map: NonMaximumSuppression on the 8-bit view (window 3,
-// Harris_corners.cpp:176-178), NMS2 window 5 (:179) and the keypoint criterion (:139,181).
-// A wave covers 64 consecutive pixels of one row; its keypoint flags leave as one ballot word.
-__global__ __launch_bounds__(256) void k_harris_post(const float* __restrict__ resp, size_t rstep_elems,
-                                                      size_t rframe, int rows, int cols,
-                                                      uint8_t* __restrict__ mask, size_t mstep, size_t mframe,
-                                                      float* __restrict__ nms2, size_t nstep_elems, size_t nframe,
-                                                      unsigned long long* __restrict__ flags, int wpr,
-                                                      size_t fframe) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    const int i = blockIdx.y;
-    const float* R = resp + blockIdx.z * rframe;
-    bool kp = false;
-    if (j < cols) {
-        const float c = R[(size_t)i * rstep_elems + j];
-        if (mask) {
-            int m = 0;
-            for (int u = max(i - 1, 0); u <= min(i + 1, rows - 1); ++u)
-                for (int v = max(j - 1, 0); v <= min(j + 1, cols - 1); ++v)
-                    if (u != i || v != j) m = max(m, cvt_abs_u8(R[(size_t)u * rstep_elems + v]));
-            mask[blockIdx.z * mframe + (size_t)i * mstep + j] = cvt_abs_u8(c) > m ? 255 : 0;
-        }
-        float o = 0.0f;
-        if (i >= 2 && i < rows - 2 && j >= 2 && j < cols - 2) {
-            float wmax = 0.0f;
-            for (int u = i - 2; u < i + 2; ++u)
-                for (int v = j - 2; v < j + 2; ++v) wmax = fmaxf(wmax, R[(size_t)u * rstep_elems + v]);
-            if (c >= wmax) o = wmax;
-        }
-        if (nms2) nms2[blockIdx.z * nframe + (size_t)i * nstep_elems + j] = o;
-        kp = cvt_abs_u8(o) > 253;
-    }
-    const unsigned long long w = __ballot(kp);
-    if (flags && (threadIdx.x & 63) == 0 && (j >> 6) < wpr) flags[blockIdx.z * fframe + (size_t)i * wpr + (j >> 6)] = w;
 }
 
 // ---- scale-space extrema (initialKeypointDetection, Diff_of_Gauss.cpp:254-297) ------------

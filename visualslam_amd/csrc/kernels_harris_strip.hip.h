@@ -15,7 +15,10 @@
 //
 // Lanes 0,1 and 62,63 of a wave only feed their neighbours (each stage invalidates one more
 // edge pixel), so a strip produces 60 lanes x 4 = 240 output columns; strips start every 240.
-// Requires cols % 4 == 0.
+// ANYW = false requires cols % 4 == 0 (every row dword-aligned, the image ends on a lane
+// boundary); ANYW = true takes any width: unaligned 4/16-byte accesses for the lanes that lie
+// fully inside, per-pixel loads, replicate-edge selection and stores for the one lane that
+// straddles the right edge.
 //
 // Exactness: all pre-response quantities are integers (16-bit lanes for
 // the blur and the gradients, int32 for products and 3x3 sums < 2^24); det is formed exactly
@@ -61,6 +64,7 @@ struct HarrisStripArgs {
 };
 
 // grid = (ceil(nstrips*nseg / 4), 1, frames), block = 256 (4 independent waves).
+template <bool ANYW>
 __global__ __launch_bounds__(256) void k_harris_strip(const HarrisStripArgs a) {
     const int lane = threadIdx.x & 63;
     const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -72,16 +76,22 @@ __global__ __launch_bounds__(256) void k_harris_strip(const HarrisStripArgs a) {
     const uint8_t* src = a.img + blockIdx.z * a.frame;
     const int x0 = strip * HS_STRIP_W + 4 * (lane - 2);
     const int y_begin = sgi * a.seg, y_end = min(y_begin + a.seg, rows);
-    const bool lane_in = x0 >= 0 && x0 < cols;
+    const bool lane_in = x0 >= 0 && x0 < cols;                 // owns at least one image pixel
+    const bool lane_full = x0 >= 0 && x0 + 4 <= cols;          // owns four (always, when !ANYW)
     const bool lane_out = lane >= 2 && lane < 62 && lane_in;
     const bool left_edge = x0 == 0, right_edge = x0 + 4 == cols;
+    const int jedge = ANYW && lane_in && !lane_full ? cols - x0 : 0;  // 1..3: first pixel slot outside the image
     bool inter[4];  // NMS2 is evaluated for columns [2, cols-2)
 #pragma unroll
     for (int k = 0; k < 4; ++k) inter[k] = lane_out && x0 + k >= 2 && x0 + k < cols - 2;
 
     auto load_row = [&](int t) -> uint32_t {
         const uint8_t* row = src + (size_t)reflect101(t, rows) * cols;
-        if (lane_in) return *reinterpret_cast<const uint32_t*>(row + x0);
+        if (ANYW ? lane_full : lane_in) {
+            uint32_t w;
+            __builtin_memcpy(&w, row + x0, 4);  // dword aligned when !ANYW
+            return w;
+        }
         return (uint32_t)row[reflect101(x0, cols)] | ((uint32_t)row[reflect101(x0 + 1, cols)] << 8) |
                ((uint32_t)row[reflect101(x0 + 2, cols)] << 16) | ((uint32_t)row[reflect101(x0 + 3, cols)] << 24);
     };
@@ -133,6 +143,11 @@ __global__ __launch_bounds__(256) void k_harris_strip(const HarrisStripArgs a) {
             const int l = (int)from_left((uint32_t)P[c][4]), r = (int)from_right((uint32_t)P[c][1]);
             P[c][0] = left_edge ? P[c][1] : l;
             P[c][5] = right_edge ? P[c][4] : r;
+            if (ANYW) {  // the image ends inside this lane: column `cols` repeats column cols-1
+#pragma unroll
+                for (int j = 1; j <= 3; ++j)
+                    if (jedge == j) P[c][j + 1] = P[c][j];
+            }
 #pragma unroll
             for (int k = 0; k < 4; ++k) hsC[c][k] = P[c][k] + P[c][k + 1] + P[c][k + 2];
         }
@@ -154,7 +169,8 @@ __global__ __launch_bounds__(256) void k_harris_strip(const HarrisStripArgs a) {
                 const float trtr = tr * tr;
                 const float ktr = a.k * trtr;
                 const float resp = det - ktr;
-                Rb[k] = (b >= 0 && b < rows && lane_in && resp > 0.0f) ? resp : 0.0f;
+                const bool px_in = ANYW ? (lane_in && (lane_full || k < jedge)) : lane_in;
+                Rb[k] = (b >= 0 && b < rows && px_in && resp > 0.0f) ? resp : 0.0f;
             }
         }
 #pragma unroll
@@ -193,9 +209,24 @@ __global__ __launch_bounds__(256) void k_harris_strip(const HarrisStripArgs a) {
             }
             if (lane_out) {
                 const size_t off = blockIdx.z * N + (size_t)y * cols + x0;
-                if (a.resp) *reinterpret_cast<float4*>(a.resp + off) = make_float4(Ry[0], Ry[1], Ry[2], Ry[3]);
-                if (a.mask) *reinterpret_cast<uint32_t*>(a.mask + off) = mword;
-                if (a.nms2) *reinterpret_cast<float4*>(a.nms2 + off) = make_float4(n2[0], n2[1], n2[2], n2[3]);
+                if (!ANYW) {
+                    if (a.resp) *reinterpret_cast<float4*>(a.resp + off) = make_float4(Ry[0], Ry[1], Ry[2], Ry[3]);
+                    if (a.mask) *reinterpret_cast<uint32_t*>(a.mask + off) = mword;
+                    if (a.nms2) *reinterpret_cast<float4*>(a.nms2 + off) = make_float4(n2[0], n2[1], n2[2], n2[3]);
+                } else if (lane_full) {  // same stores, not 16 / 4-byte aligned
+                    const float4 rv = make_float4(Ry[0], Ry[1], Ry[2], Ry[3]), nv = make_float4(n2[0], n2[1], n2[2], n2[3]);
+                    if (a.resp) __builtin_memcpy(a.resp + off, &rv, 16);
+                    if (a.mask) __builtin_memcpy(a.mask + off, &mword, 4);
+                    if (a.nms2) __builtin_memcpy(a.nms2 + off, &nv, 16);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+                        if (k < jedge) {
+                            if (a.resp) a.resp[off + k] = Ry[k];
+                            if (a.mask) a.mask[off + k] = (uint8_t)(mword >> (8 * k));
+                            if (a.nms2) a.nms2[off + k] = n2[k];
+                        }
+                }
             }
             if (a.flags && lane == 0) {
                 unsigned long long* F = a.flags + blockIdx.z * a.fframe + ((size_t)y * a.nstrips + strip) * 4;

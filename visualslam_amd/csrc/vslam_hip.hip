@@ -13,7 +13,6 @@
 
 #include "../../include/vslam.h"
 #include "kernels_generic.hip.h"
-#include "kernels_harris.hip.h"
 #include "kernels_pyramid.hip.h"
 #include "kernels_strip.hip.h"
 #include "kernels_aux.hip.h"
@@ -83,7 +82,7 @@ static int fail(vslam_ctx* c, int code, const std::string& msg) {
     } while (0)
 
 static const char* const kKernelNames =
-    "k_harris_fused\nk_harris_post\nk_resize_linear2x\nk_blur_h_generic\nk_blur_v_generic\n"
+    "k_resize_linear2x\nk_blur_h_generic\nk_blur_v_generic\n"
     "k_dog5\nk_resize_nearest_half\nk_extrema\nk_pyr_octave\n"
     "k_gauss_v_strip\nk_gauss_h_strip\nk_resize_linear2x_slide\nk_resize_nearest_half_v4\nk_extrema_w3\nk_localize_points\nk_points_localize_value\nk_orient_keypoints\nk_edge_response_windows\nk_level_gradients\nk_pack_rows\n"
     "k_harris_strip\nk_flag_count\nk_chunk_scan\nk_flag_scatter\nk_level_gradients";
@@ -488,12 +487,8 @@ static int enqueue_dog(vslam_ctx* c, const vslam_params& p, const vslam_batch_la
     // octave kernels wrote); ordered after each octave by an event.  nullptr = same stream.
     ExtGeom g;
     fill_geom(p, L, g);
-    if (p.cols % 4 == 0 && fstep == (size_t)p.cols && fframe % 4 == 0)
-        LAUNCH(c, "k_resize_linear2x_slide", k_resize_linear2x_slide, dim3((p.cols / 4 + 255) / 256, (p.rows + 15) / 16, nf),
-               dim3(256), frames, fframe, s.bases + s.base_off[0], s.bases_frame, L.pitch[0], p.rows, p.cols, 16);
-    else
-        LAUNCH(c, "k_resize_linear2x", k_resize_linear2x, grid_rows(2 * p.cols, 2 * p.rows, nf), dim3(256), frames, fstep,
-               fframe, s.bases + s.base_off[0], (size_t)L.pitch[0], s.bases_frame, p.rows, p.cols);
+    LAUNCH(c, "k_resize_linear2x_slide", k_resize_linear2x_slide, dim3(((p.cols + 3) / 4 + 255) / 256, (p.rows + 15) / 16, nf), dim3(256),
+           frames, fstep, fframe, s.bases + s.base_off[0], s.bases_frame, L.pitch[0], p.rows, p.cols, 16);
     for (int o = 0; o < L.n_octaves; ++o) {
         const int rows = L.rows[o], cols = L.cols[o], pitch = L.pitch[o];
         const size_t P = (size_t)rows * pitch;
@@ -554,59 +549,44 @@ static int enqueue_dog(vslam_ctx* c, const vslam_params& p, const vslam_batch_la
     return VSLAM_OK;
 }
 
-// Words of keypoint-flag scratch per frame for the Harris chain.
-static size_t harris_flag_words(int rows, int cols) {
-    if (cols % 4 == 0) return (size_t)rows * ((cols + HS_STRIP_W - 1) / HS_STRIP_W) * 4;
-    return (size_t)rows * ((cols + 63) / 64);
-}
+// Words of keypoint-flag scratch per frame for the Harris chain: 4 ballot words per strip row.
+static size_t harris_flag_words(int rows, int cols) { return (size_t)rows * ((cols + HS_STRIP_W - 1) / HS_STRIP_W) * 4; }
 
-// Harris chain on nf device frames: response (required buffer), optional mask / nms2 /
-// keypoint list.  cols % 4 == 0: the single-pass wave-strip kernel; otherwise the LDS-tiled
-// response kernel + the post-processing kernel.
-static int enqueue_harris(vslam_ctx* c, const uint8_t* frames, size_t fstep, size_t fframe, int rows, int cols,
-                          int nf, float k, float* resp, uint8_t* mask, float* nms2, unsigned long long* hflags,
-                          vslam_kp* kps, unsigned int cap, unsigned int* counts, unsigned int* chunk_ws) {
+// Harris chain on nf device frames with dense rows: response (required buffer), optional mask /
+// nms2 / keypoint list, all from the single-pass wave-strip kernel - its aligned form when every
+// row and frame starts on a dword, the any-width form otherwise.
+static int enqueue_harris(vslam_ctx* c, const uint8_t* frames, size_t fframe, int rows, int cols, int nf, float k,
+                          float* resp, uint8_t* mask, float* nms2, unsigned long long* hflags, vslam_kp* kps,
+                          unsigned int cap, unsigned int* counts, unsigned int* chunk_ws) {
     const size_t N = (size_t)rows * cols;
-    if (cols % 4 == 0 && fstep == (size_t)cols && fframe % 4 == 0) {
-        HarrisStripArgs a;
-        a.img = frames;
-        a.frame = fframe;
-        a.rows = rows;
-        a.cols = cols;
-        a.k = k;
-        a.resp = resp;
-        a.mask = mask;
-        a.nms2 = nms2;
-        a.flags = hflags;
-        a.nstrips = (cols + HS_STRIP_W - 1) / HS_STRIP_W;
-        a.fframe = (size_t)rows * a.nstrips * 4;
-        // enough waves to fill the chip several times over, long enough strips to amortise the
-        // 9-row pipeline fill
-        const long want_seg = std::max<long>(1, 12288 / ((long)a.nstrips * nf));
-        a.seg = (int)std::min<long>(rows, std::max<long>(16, (rows + want_seg - 1) / want_seg));
-        const int nseg = (rows + a.seg - 1) / a.seg;
-        LAUNCH(c, "k_harris_strip", k_harris_strip, dim3((a.nstrips * nseg + 3) / 4, 1, nf), dim3(256), a);
-        if (hflags && kps && counts) {
-            HarrisStripEntries ent{hflags, a.fframe, rows, cols, a.nstrips, resp, N, kps};
-            TRY(enqueue_compaction(c, ent, (size_t)rows * a.nstrips, nf, chunk_ws, cap, counts, 0));
-        }
-        return VSLAM_OK;
-    }
-    LAUNCH(c, "k_harris_fused", k_harris_fused, dim3((cols + HT_W - 1) / HT_W, (rows + HT_H - 1) / HT_H, nf),
-           dim3(256), frames, fstep, fframe, rows, cols, k, resp, (size_t)cols, N);
-    if (mask || nms2 || hflags) {
-        const int wpr = (cols + 63) / 64;
-        LAUNCH(c, "k_harris_post", k_harris_post, grid_rows(cols, rows, nf), dim3(256), resp, (size_t)cols, N, rows, cols,
-               mask, (size_t)cols, N, nms2, (size_t)cols, N, hflags, wpr, (size_t)rows * wpr);
-        if (hflags && kps && counts) {
-            HarrisWordEntries ent{hflags, (size_t)rows * wpr, rows, cols, wpr, resp, N, kps};
-            TRY(enqueue_compaction(c, ent, (size_t)rows * wpr, nf, chunk_ws, cap, counts, 0));
-        }
+    const bool aligned = cols % 4 == 0 && fframe % 4 == 0;
+    HarrisStripArgs a;
+    a.img = frames;
+    a.frame = fframe;
+    a.rows = rows;
+    a.cols = cols;
+    a.k = k;
+    a.resp = resp;
+    a.mask = mask;
+    a.nms2 = nms2;
+    a.flags = hflags;
+    a.nstrips = (cols + HS_STRIP_W - 1) / HS_STRIP_W;
+    a.fframe = (size_t)rows * a.nstrips * 4;
+    // enough waves to fill the chip several times over, long enough strips to amortise the
+    // 9-row pipeline fill
+    const long want_seg = std::max<long>(1, 12288 / ((long)a.nstrips * nf));
+    a.seg = (int)std::min<long>(rows, std::max<long>(16, (rows + want_seg - 1) / want_seg));
+    const int nseg = (rows + a.seg - 1) / a.seg;
+    if (aligned)
+        LAUNCH(c, "k_harris_strip", k_harris_strip<false>, dim3((a.nstrips * nseg + 3) / 4, 1, nf), dim3(256), a);
+    else
+        LAUNCH(c, "k_harris_strip", k_harris_strip<true>, dim3((a.nstrips * nseg + 3) / 4, 1, nf), dim3(256), a);
+    if (hflags && kps && counts) {
+        HarrisStripEntries ent{hflags, a.fframe, rows, cols, a.nstrips, resp, N, kps};
+        TRY(enqueue_compaction(c, ent, (size_t)rows * a.nstrips, nf, chunk_ws, cap, counts, 0));
     }
     return VSLAM_OK;
 }
-
-// ------------------------------------------------------------------- host <-> device copies
 
 static int h2d(vslam_ctx* c, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width_bytes,
                size_t rows) {
@@ -762,7 +742,7 @@ int vslam_resize_linear2x_u8(vslam_ctx* c, const uint8_t* src, int rows, int col
     TRY(h2d(c, d_src, cols, src, step, cols, rows));
     if (cols % 4 == 0)
         LAUNCH(c, "k_resize_linear2x_slide", k_resize_linear2x_slide, dim3((cols / 4 + 255) / 256, (rows + 15) / 16, 1), dim3(256),
-               d_src, P, d_dst, 4 * P, 2 * cols, rows, cols, 16);
+               d_src, (size_t)cols, P, d_dst, 4 * P, 2 * cols, rows, cols, 16);
     else
         LAUNCH(c, "k_resize_linear2x", k_resize_linear2x, grid_rows(2 * cols, 2 * rows), dim3(256), d_src, (size_t)cols, P,
                d_dst, (size_t)2 * cols, 4 * P, rows, cols);
@@ -835,7 +815,7 @@ int vslam_harris_response_u8(vslam_ctx* c, const uint8_t* img, int rows, int col
     uint8_t* d_img = ws_take<uint8_t>(c, P);
     float* d_r = ws_take<float>(c, P);
     TRY(h2d(c, d_img, cols, img, step, cols, rows));
-    TRY(enqueue_harris(c, d_img, cols, P, rows, cols, 1, k, d_r, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr));
+    TRY(enqueue_harris(c, d_img, P, rows, cols, 1, k, d_r, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr));
     TRY(d2h(c, resp, resp_step, d_r, 4 * (size_t)cols, 4 * (size_t)cols, rows));
     return vslam_ctx_sync(c);
 }
@@ -907,7 +887,7 @@ int vslam_harris_keypoints_u8(vslam_ctx* c, const uint8_t* img, int rows, int co
     unsigned int* d_n = ws_take<unsigned int>(c, 1);
     unsigned int* d_cws = ws_take<unsigned int>(c, compaction_ws_elems(harris_flag_words(rows, cols), 1));
     TRY(h2d(c, d_img, cols, img, step, cols, rows));
-    TRY(enqueue_harris(c, d_img, cols, P, rows, cols, 1, k, d_r, nullptr, nullptr, d_f, d_k, dcap, d_n, d_cws));
+    TRY(enqueue_harris(c, d_img, P, rows, cols, 1, k, d_r, nullptr, nullptr, d_f, d_k, dcap, d_n, d_cws));
     unsigned int n = 0;
     HIPCHK(c, hipMemcpyAsync(&n, d_n, 4, hipMemcpyDeviceToHost, c->stream));
     TRY(vslam_ctx_sync(c));
@@ -1287,7 +1267,7 @@ int vslam_detect_batch_dev(vslam_ctx* c, const vslam_params* pp, const uint8_t* 
         if (harris) {
             StreamSwap sw(c, sh);
             float* resp = out->response ? out->response + (size_t)f0 * N : resp_ws;
-            TRY(enqueue_harris(c, fr, p.cols, frame_stride, p.rows, p.cols, nf, p.harris_k, resp,
+            TRY(enqueue_harris(c, fr, frame_stride, p.rows, p.cols, nf, p.harris_k, resp,
                                out->nms_mask ? out->nms_mask + (size_t)f0 * N : nullptr,
                                out->nms2 ? out->nms2 + (size_t)f0 * N : nullptr, want_kps ? hflags : nullptr,
                                want_kps ? out->harris_kps + (size_t)f0 * p.harris_cap : nullptr, p.harris_cap,
