@@ -206,9 +206,19 @@ __global__ __launch_bounds__(256) void k_pyr_octave(const uint8_t* __restrict__ 
     uint32_t* hp = smem + CFG::RQ * CFG::RWP;
     constexpr int R = CFG::R, RW = CFG::RW, RWP = CFG::RWP, RQ = CFG::RQ;
     const int tid = threadIdx.x;
-    const int tile_x0 = blockIdx.x * CFG::TW, tile_y0 = blockIdx.y * CFG::TH;
-    const uint8_t* src = base + blockIdx.z * bframe;
-    uint8_t* out = oct_out + blockIdx.z * pframe;
+    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an
+    // L2), so the linear id is remapped to give every XCD one contiguous run of tiles - row-major
+    // neighbours, which share their halo rows and columns, then meet in the same 4 MB L2 instead
+    // of each fetching the halo from HBM.  Placement is a speed matter only.
+    unsigned int bid = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const unsigned int per_xcd = (gridDim.x * gridDim.y * gridDim.z) >> 3;
+    if (bid < (per_xcd << 3)) bid = (bid & 7u) * per_xcd + (bid >> 3);
+    const unsigned int tiles_per_frame = gridDim.x * gridDim.y;
+    const unsigned int fz = bid / tiles_per_frame, rem = bid - fz * tiles_per_frame;
+    const unsigned int by = rem / gridDim.x, bx = rem - by * gridDim.x;
+    const int tile_x0 = bx * CFG::TW, tile_y0 = by * CFG::TH;
+    const uint8_t* src = base + fz * bframe;
+    uint8_t* out = oct_out + fz * pframe;
     const size_t P = (size_t)rows * pitch;
 
     // ---- stage the base tile, byte-transposed ------------------------------------------------
@@ -263,7 +273,7 @@ __global__ __launch_bounds__(256) void k_pyr_octave(const uint8_t* __restrict__ 
     // any value is harmless), so they are left uninitialised.
     __syncthreads();
 
-    uint8_t* nb = next_base ? next_base + blockIdx.z * nframe : nullptr;
+    uint8_t* nb = next_base ? next_base + fz * nframe : nullptr;
     uint32_t prev_e[4][2], prev_o[4][2];
     pyr_level<CFG, 0>(taps, rp, hp, out, P, cols, pitch, rows, tile_x0, tile_y0, prev_e, prev_o, nb, nrows, ncols, npitch);
     pyr_level<CFG, 1>(taps, rp, hp, out, P, cols, pitch, rows, tile_x0, tile_y0, prev_e, prev_o, nb, nrows, ncols, npitch);
