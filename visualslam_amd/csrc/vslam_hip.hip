@@ -9,6 +9,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <set>
 #include <vector>
 
 #include "../../include/vslam.h"
@@ -43,6 +44,8 @@ struct vslam_ctx {
     // recycled pyramid blocks: a GaussPyramid per image would otherwise pay hipMalloc + hipFree of
     // >100 MB each time (milliseconds, more than the kernels)
     std::vector<std::pair<size_t, void*>> block_cache;
+    // kernels whose dynamic-LDS ceiling has been raised on this device (once, not per launch)
+    std::set<const void*> lds_raised;
     // bench timing hook
     std::string timing_name;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timing_ev;
@@ -147,6 +150,15 @@ struct StreamSwap {
     StreamSwap(vslam_ctx* ctx, hipStream_t s) : c(ctx), saved(ctx->stream) { c->stream = s; }
     ~StreamSwap() { c->stream = saved; }
 };
+
+// Raises a kernel's dynamic shared memory ceiling to the most any launch of it may ask for.
+static constexpr int kMaxDynLds = 150 * 1024;
+static int raise_dyn_lds(vslam_ctx* c, const void* fn) {
+    if (c->lds_raised.count(fn)) return VSLAM_OK;
+    HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds));
+    c->lds_raised.insert(fn);
+    return VSLAM_OK;
+}
 
 static void* block_alloc(vslam_ctx* c, size_t bytes, size_t* cap) {
     int best = -1;
@@ -300,8 +312,7 @@ static int launch_h_strip(vslam_ctx* c, const uint16_t* h, size_t hframe, uint8_
                           int pitch, int pw, int nf, const StripTaps* taps, uint8_t* next_base, size_t nframe, int nrows, int ncols,
                           int npitch) {
     const size_t lds = (size_t)SH * pw * 4;
-    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gauss_h_strip<SH, RI>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    TRY(raise_dyn_lds(c, reinterpret_cast<const void*>(&k_gauss_h_strip<SH, RI>)));
     {
         TimedScope ts(c, "k_gauss_h_strip");
         hipLaunchKernelGGL((k_gauss_h_strip<SH, RI>), dim3(1, (rows + SH - 1) / SH, nf), dim3(256), lds, c->stream, h, hframe, oct,
@@ -323,8 +334,7 @@ static int enqueue_strip_octave(vslam_ctx* c, double sigma0, int o, const OctPla
     const int rhq = (((rows + 3) & ~3) + 2 * RM + 16) / 4;
     const size_t v_lds = (size_t)rhq * STRIP_W * 4;
     const size_t P = (size_t)rows * pitch;
-    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gauss_v_strip),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)v_lds));
+    TRY(raise_dyn_lds(c, reinterpret_cast<const void*>(&k_gauss_v_strip)));
     {
         TimedScope ts(c, "k_gauss_v_strip");
         // small batches: split the six levels over workgroups until the launch has >= 256 of them
@@ -462,8 +472,7 @@ static int enqueue_pyr_octave(vslam_ctx* c, double sigma0, int o, const OctPlan&
         void* d = nullptr;
         HIPCHK(c, hipMalloc(&d, sizeof(PyrTaps<CFG>)));
         HIPCHK(c, hipMemcpy(d, host.data(), sizeof(PyrTaps<CFG>), hipMemcpyHostToDevice));
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pyr_octave<CFG>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES));
+        TRY(raise_dyn_lds(c, reinterpret_cast<const void*>(&k_pyr_octave<CFG>)));
         it = c->tile_taps.emplace(key, d).first;
     }
     const PyrTaps<CFG>* taps = static_cast<const PyrTaps<CFG>*>(it->second);
@@ -1175,8 +1184,7 @@ int vslam_filter_keypoints(vslam_ctx* c, const vslam_pyramid* py, int octave, co
         lv.kn[l] = (int)taps[l].size();
         toff += align_up(taps[l].size(), 64);
     }
-    if (lds > 48 * 1024)
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_orient_keypoints), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    TRY(raise_dyn_lds(c, reinterpret_cast<const void*>(&k_orient_keypoints)));
     {
         TimedScope ts(c, "k_orient_keypoints");
         hipLaunchKernelGGL(k_orient_keypoints, dim3((unsigned)n), dim3(256), lds, c->stream, d_kps, (int)n, lv, pitch, rows, cols, d_masks);
