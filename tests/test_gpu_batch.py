@@ -86,12 +86,26 @@ def check_frame(p, L, out, f, img, n_oct):
 
 def test_batch_small_frames_all_outputs(env):
     ctx, torch = env
-    frames = synth.frames_np(11, 96, 160, stream_id=7)  # 11 > chunk of 8: exercises chunking
+    frames = synth.frames_np(11, 96, 160, stream_id=7)
     frames[3] = synth.frame_np(96, 160, kind="noise")
     frames[5] = synth.frame_np(96, 160, kind="constant")
     p, L, out = run_batch(ctx, torch, frames, n_octaves=3)
     for f in range(frames.shape[0]):
         check_frame(p, L, out, f, frames[f], 3)
+
+
+def test_batch_larger_than_one_chunk(env):
+    # more frames than one whole-batch launch takes (256): the second chunk reuses the scratch and
+    # the auxiliary streams of the first; frames on both sides of the seam against the oracle
+    ctx, torch = env
+    frames = synth.frames_np(300, 40, 56, stream_id=13)
+    frames[256] = synth.frame_np(40, 56, kind="noise")
+    p, L, out = run_batch(ctx, torch, frames, n_octaves=2, harris_cap=1024, dog_cap=2048)
+    for f in (0, 1, 254, 255, 256, 257, 299):
+        check_frame(p, L, out, f, frames[f], 2)
+    # every frame of the first chunk also appears, identically, nowhere else: spot-check that no
+    # frame of chunk 2 picked up results of chunk 1
+    assert out["dog_counts"][256] != out["dog_counts"][0] or out["harris_counts"][256] != out["harris_counts"][0]
 
 
 def test_batch_ragged_size_and_small_caps(env):
