@@ -122,8 +122,8 @@ __device__ __forceinline__ void pyr_level(const PyrTaps<CFG>* __restrict__ taps,
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             uint2 w;
-            w.x = acc[j][0] | (acc[j][1] << 16);
-            w.y = acc[j][2] | (acc[j][3] << 16);
+            w.x = __builtin_amdgcn_perm(acc[j][1], acc[j][0], 0x05040100);  // (acc0, acc1) as u16 pair: one v_perm, not shift + or
+            w.y = __builtin_amdgcn_perm(acc[j][3], acc[j][2], 0x05040100);
             *reinterpret_cast<uint2*>(hp + (8 * ro + j) * HPP + 2 * cg) = w;
         }
     }
@@ -173,9 +173,9 @@ __device__ __forceinline__ void pyr_level(const PyrTaps<CFG>* __restrict__ taps,
             // into 16-bit lanes (the shape the saturating subtract wants), then interleave.
             const uint32_t e = __builtin_amdgcn_perm(acc[jr][4 * hw + 2], acc[jr][4 * hw + 0], 0x0c060c02);  // (G0, G2)
             const uint32_t o = __builtin_amdgcn_perm(acc[jr][4 * hw + 3], acc[jr][4 * hw + 1], 0x0c060c02);  // (G1, G3)
-            g[hw] = e | (o << 8);
+            g[hw] = __builtin_amdgcn_perm(o, e, 0x06020400);  // bytes (e0, o0, e1, o1): interleave in one v_perm
             if (L > 0)  // D_{L-1} = saturate_u8(G_L - G_{L-1}), GaussPyramid.cpp:197
-                d[hw] = pk_sub_sat_u16(e, prev_e[jr][hw]) | (pk_sub_sat_u16(o, prev_o[jr][hw]) << 8);
+                d[hw] = __builtin_amdgcn_perm(pk_sub_sat_u16(o, prev_o[jr][hw]), pk_sub_sat_u16(e, prev_e[jr][hw]), 0x06020400);
             prev_e[jr][hw] = e;
             prev_o[jr][hw] = o;
         }

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void k_gauss_v_strip(const uint8_t* __restrict
                     const int y = ty0 + j;
                     if (y >= 0 && y < rows)
                         *reinterpret_cast<uint2*>(hl + (size_t)y * pitch + gx) =
-                            make_uint2(acc[j][0] | (acc[j][1] << 16), acc[j][2] | (acc[j][3] << 16));
+                            make_uint2(__builtin_amdgcn_perm(acc[j][1], acc[j][0], 0x05040100), __builtin_amdgcn_perm(acc[j][3], acc[j][2], 0x05040100));
                 }
             }
         }
@@ -212,8 +212,8 @@ __global__ __launch_bounds__(256) void k_gauss_h_strip(const uint16_t* __restric
                     for (int hw = 0; hw < 2; ++hw) {
                         const uint32_t e = __builtin_amdgcn_perm(acc[jr][4 * hw + 2], acc[jr][4 * hw + 0], 0x0c060c02);
                         const uint32_t o = __builtin_amdgcn_perm(acc[jr][4 * hw + 3], acc[jr][4 * hw + 1], 0x0c060c02);
-                        g[hw] = e | (o << 8);
-                        if (l > 0) d[hw] = pk_sub_sat_u16(e, prev_e[ii][jr][hw]) | (pk_sub_sat_u16(o, prev_o[ii][jr][hw]) << 8);
+                        g[hw] = __builtin_amdgcn_perm(o, e, 0x06020400);  // bytes (e0, o0, e1, o1): interleave in one v_perm
+                        if (l > 0) d[hw] = __builtin_amdgcn_perm(pk_sub_sat_u16(o, prev_o[ii][jr][hw]), pk_sub_sat_u16(e, prev_e[ii][jr][hw]), 0x06020400);
                         prev_e[ii][jr][hw] = e;
                         prev_o[ii][jr][hw] = o;
                     }
