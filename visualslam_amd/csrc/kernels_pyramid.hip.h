@@ -180,13 +180,20 @@ __device__ __forceinline__ void pyr_level(const PyrTaps<CFG>* __restrict__ taps,
             prev_o[jr][hw] = o;
         }
         if (y < rows && x < cols) {
-            const size_t off = (size_t)y * pitch + x;  // the last 8-column group may end in the row padding
-            *reinterpret_cast<uint2*>(out + (size_t)L * P + off) = make_uint2(g[0], g[1]);
-            if (L > 0) *reinterpret_cast<uint2*>(out + (size_t)(VSLAM_NUM_LEVELS + L - 1) * P + off) = make_uint2(d[0], d[1]);
+            // 32-bit offset inside a wave-uniform plane pointer (a frame's octave block is far below
+            // 4 GB): scalar base + VGPR offset addressing, no 64-bit address arithmetic per store.
+            // The last 8-column group may end in the row padding.
+            const uint32_t off = (uint32_t)y * (uint32_t)pitch + (uint32_t)x;
+            uint8_t* gp = out + (size_t)L * P;
+            *reinterpret_cast<uint2*>(gp + off) = make_uint2(g[0], g[1]);
+            if (L > 0) {
+                uint8_t* dp = out + (size_t)(VSLAM_NUM_LEVELS + L - 1) * P;
+                *reinterpret_cast<uint2*>(dp + off) = make_uint2(d[0], d[1]);
+            }
             // next octave's base = Gaussian[3] decimated 2:1, INTER_NEAREST (GaussPyramid.cpp:123-126):
             // pixel (2y', 2x'); tile origins and (jr, x) are even, so it is the even bytes of even rows
             if (L == 3 && next_base && (jr & 1) == 0 && (y >> 1) < nrows && (x >> 1) < ncols)
-                *reinterpret_cast<uint32_t*>(next_base + (size_t)(y >> 1) * npitch + (x >> 1)) =
+                *reinterpret_cast<uint32_t*>(next_base + ((uint32_t)(y >> 1) * (uint32_t)npitch + (uint32_t)(x >> 1))) =
                     __builtin_amdgcn_perm(g[1], g[0], 0x06040200);
         }
     }

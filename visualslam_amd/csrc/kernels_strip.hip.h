@@ -218,9 +218,13 @@ __global__ __launch_bounds__(256) void k_gauss_h_strip(const uint16_t* __restric
                         prev_o[ii][jr][hw] = o;
                     }
                     if (y < rows) {
-                        const size_t off = (size_t)y * pitch + x;
-                        *reinterpret_cast<uint2*>(out + (size_t)l * P + off) = make_uint2(g[0], g[1]);
-                        if (l > 0) *reinterpret_cast<uint2*>(out + (size_t)(VSLAM_NUM_LEVELS + l - 1) * P + off) = make_uint2(d[0], d[1]);
+                        const uint32_t off = (uint32_t)y * (uint32_t)pitch + (uint32_t)x;  // 32-bit offset in a uniform plane pointer
+                        uint8_t* gp = out + (size_t)l * P;
+                        *reinterpret_cast<uint2*>(gp + off) = make_uint2(g[0], g[1]);
+                        if (l > 0) {
+                            uint8_t* dp = out + (size_t)(VSLAM_NUM_LEVELS + l - 1) * P;
+                            *reinterpret_cast<uint2*>(dp + off) = make_uint2(d[0], d[1]);
+                        }
                         // next octave's base = Gaussian[3] decimated 2:1 (GaussPyramid.cpp:123-126)
                         if (l == 3 && next_base && (y & 1) == 0 && (y >> 1) < nrows && (x >> 1) < ncols)
                             *reinterpret_cast<uint32_t*>(next_base + blockIdx.z * nframe + (size_t)(y >> 1) * npitch + (x >> 1)) =
