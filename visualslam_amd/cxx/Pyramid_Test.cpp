@@ -54,6 +54,12 @@ int main() {
             EXPECT(gx.at<float>(10, 10) == (float)((int)b.at<uchar>(10, 11) - (int)b.at<uchar>(10, 9)));
             EXPECT(gx.at<float>(10, 0) == 0.0f);  // reflect-101
         }
+        {   // whole-pyramid gradient maps (GaussPyramid.hpp:41-44) on a small pyramid: every octave, 6 levels each
+            Mat small_img = imgio::synthetic(48, 64);
+            GaussPyramid sp{small_img, 2, 1.6};
+            EXPECT(sp.pyramidGradX().size() == 2 && sp.pyramidGradOrient().at(1).size() == 6);
+            EXPECT(sp.pyramidGradMag().at(0)[5].rows == 96 && sp.pyramidGradY().at(1)[0].cols == 64);
+        }
         GaussPyramid autop{img, 1.6};  // second constructor: floor(log2(600)) - 4 = 5 octaves
         EXPECT(autop.getNumOctaves() == 5);
         std::vector<Mat> padded = GaussPyramid::padOctave(1, d);

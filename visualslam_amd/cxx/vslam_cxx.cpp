@@ -230,6 +230,11 @@ const std::map<int, std::vector<Mat>>& GaussPyramid::pyramidGauss() {
     return gauss_;
 }
 
+const std::map<int, std::vector<Mat>>& GaussPyramid::allGrads(int kind) {
+    for (int o = 0; o < info_.n_octaves; ++o) grads(o, kind);
+    return grad_[kind];
+}
+
 const std::map<int, std::vector<Mat>>& GaussPyramid::pyramidDiff() {
     for (int o = 0; o < info_.n_octaves; ++o) octaveDiff(o);
     return diff_;

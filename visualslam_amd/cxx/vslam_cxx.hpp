@@ -90,6 +90,12 @@ public:
     const std::vector<cv::Mat>& imagePyramid();
     const std::map<int, std::vector<cv::Mat>>& pyramidGauss();
     const std::map<int, std::vector<cv::Mat>>& pyramidDiff();
+    // GaussPyramid.hpp:41-44.  These materialise every level of every octave (96 bytes per pyramid
+    // pixel, 1.06 GB for a 1080p frame) exactly as the reference's constructor does.
+    const std::map<int, std::vector<cv::Mat>>& pyramidGradX() { return allGrads(0); }
+    const std::map<int, std::vector<cv::Mat>>& pyramidGradY() { return allGrads(1); }
+    const std::map<int, std::vector<cv::Mat>>& pyramidGradMag() { return allGrads(2); }
+    const std::map<int, std::vector<cv::Mat>>& pyramidGradOrient() { return allGrads(3); }
     static std::vector<cv::Mat> padOctave(int padding, const std::vector<cv::Mat>& images);
     const vslam_pyramid* handle() const { return pyr_; }  // the HBM-resident pyramid
 
@@ -103,6 +109,7 @@ private:
     std::map<int, std::vector<double>> sigmas_;
     std::map<int, std::vector<cv::Mat>> gauss_, diff_, grad_[4];
     const std::vector<cv::Mat>& grads(int octave, int kind);
+    const std::map<int, std::vector<cv::Mat>>& allGrads(int kind);
 };
 
 // void initialKeypointDetection(...), Diff_of_Gauss.cpp:254-297, as the reference runs it: every
