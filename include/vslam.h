@@ -218,6 +218,12 @@ int vslam_filter_keypoints(vslam_ctx* ctx, const vslam_pyramid* pyr, int octave,
 int vslam_edge_response_windows(vslam_ctx* ctx, const float* gx_windows, const float* gy_windows, int window_elems,
                                 size_t n, float* response);
 
+/* void StructureMatrix(Mat& M, Mat& Ix, Mat& Iy, int padding, int i, int j), Harris_corners.cpp:10-29,
+ * for n pixels whose (2*padding+1)^2 gradient windows the caller has gathered in the
+ * reference's loop order (:16-17): sums = n x (Ix2, IxIy, Iy2) = M(0,0), M(0,1) = M(1,0), M(1,1). */
+int vslam_structure_matrix_windows(vslam_ctx* ctx, const float* gx_windows, const float* gy_windows, int window_elems,
+                                   size_t n, float* sums);
+
 /* ------------------------------------------- device-resident batched detection */
 
 typedef struct {

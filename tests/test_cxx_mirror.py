@@ -44,7 +44,7 @@ def test_executables_run(built, exe, arg):
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["exe"] == exe
     if exe == "Harris":
-        assert out["keypoints_stagewise"] == out["keypoints_fused"] > 0
+        assert out["keypoints_stagewise"] == out["keypoints_fused"] > 0 and out["structure_matrix_mismatch"] == 0
     if exe == "DoG":
         assert len(out["octaves"]) == 4 and out["keypoints"] > 0 and out["per_point_mismatch"] == 0
     if exe == "Pyramid_Test":

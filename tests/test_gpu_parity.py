@@ -322,6 +322,12 @@ def test_edge_response_windows(ctx):
     want = np.array([oracle.compute_edge_response(a.reshape(2, 2), b.reshape(2, 2), 1, 1, 1) for a, b in zip(gx, gy)], np.float32)
     assert got.tobytes() == want.tobytes()
     assert not np.isfinite(got[:100]).any()  # tr^2 / 0
+    # StructureMatrix (Harris_corners.cpp:10-29): the same sums over a 3x3 window, entries of M
+    wx = rng.integers(-255, 256, (300, 9)).astype(np.float32)
+    wy = rng.integers(-255, 256, (300, 9)).astype(np.float32)
+    m = ctx.structure_matrix_windows(wx, wy)
+    want_m = np.stack([(wx * wx).sum(1), (wx * wy).sum(1), (wy * wy).sum(1)], 1)  # integers < 2^24: exact in f32
+    assert m.tobytes() == want_m.astype(np.float32).tobytes()
 
 
 @pytest.mark.parametrize("shape,n_oct", [((40, 56), 2), ((33, 47), 2), ((1, 5), 1)])

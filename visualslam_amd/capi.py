@@ -106,6 +106,7 @@ SIGNATURES = {
     "vslam_localize_points": (_I, [_P, _P, _Z, _P, _P]),
     "vslam_filter_keypoints": (_I, [_P, _P, _I, _P, _Z, _P, _Z, C.POINTER(_Z)]),
     "vslam_edge_response_windows": (_I, [_P, _P, _P, _I, _Z, _P]),
+    "vslam_structure_matrix_windows": (_I, [_P, _P, _P, _I, _Z, _P]),
     "vslam_params_default": (None, [C.POINTER(Params), _I, _I]),
     "vslam_batch_layout_query": (_I, [C.POINTER(Params), C.POINTER(BatchLayout)]),
     "vslam_detect_batch_dev": (_I, [_P, C.POINTER(Params), _P, _Z, _I, C.POINTER(BatchOut)]),
@@ -347,6 +348,15 @@ class Context:
         assert gx.shape == gy.shape and gx.ndim == 2
         out = np.zeros(gx.shape[0], np.float32)
         self._chk(lib().vslam_edge_response_windows(self._h, gx.ctypes.data, gy.ctypes.data, gx.shape[1], gx.shape[0], out.ctypes.data), "vslam_edge_response_windows")
+        return out
+
+    def structure_matrix_windows(self, gx_windows, gy_windows):
+        """StructureMatrix for n gathered windows: f32 [n, elems] each -> f32 [n, 3] = (Ix2, IxIy, Iy2)."""
+        gx = np.ascontiguousarray(gx_windows, dtype=np.float32)
+        gy = np.ascontiguousarray(gy_windows, dtype=np.float32)
+        assert gx.shape == gy.shape and gx.ndim == 2
+        out = np.zeros((gx.shape[0], 3), np.float32)
+        self._chk(lib().vslam_structure_matrix_windows(self._h, gx.ctypes.data, gy.ctypes.data, gx.shape[1], gx.shape[0], out.ctypes.data), "vslam_structure_matrix_windows")
         return out
 
     def pyramid(self, img, n_octaves: int = 4, sigma0: float = 1.6):

@@ -121,10 +121,12 @@ __global__ __launch_bounds__(256) void k_orient_keypoints(const vslam_point* __r
 
 static inline size_t orient_lds_bytes(int R) { return (size_t)(OR_WIN + 2 * R) * OR_WIN * 4 + (size_t)(OR_WIN + 2 * R) * 4; }
 
-// computeEdgeResponse on caller-gathered windows (the per-point C++ entry point): gxw / gyw hold
-// n windows of `elems` gradient values in the reference's loop order.
+// StructureMatrix (Harris_corners.cpp:10-29) / computeEdgeResponse (Diff_of_Gauss.cpp:79-109) on
+// caller-gathered windows (the per-point C++ entry points): gxw / gyw hold n windows of `elems`
+// gradient values in the reference's loop order.  sums (may be null): n x (Ix2, IxIy, Iy2), the
+// entries of M; response (may be null): tr^2 / det.
 __global__ __launch_bounds__(256) void k_edge_response_windows(const float* __restrict__ gxw, const float* __restrict__ gyw, int elems,
-                                                                int n, float* __restrict__ out) {
+                                                                int n, float* __restrict__ sums, float* __restrict__ response) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     float Ix2 = 0.f, Iy2 = 0.f, IxIy = 0.f;
@@ -134,9 +136,12 @@ __global__ __launch_bounds__(256) void k_edge_response_windows(const float* __re
         Iy2 += gy * gy;
         IxIy += gx * gy;
     }
-    const float det = (float)((double)Ix2 * (double)Iy2 - (double)IxIy * (double)IxIy);
-    const float tr = (float)(0.0 + (double)Ix2 + (double)Iy2);
-    out[i] = (tr * tr) / det;
+    if (sums) sums[3 * (size_t)i] = Ix2, sums[3 * (size_t)i + 1] = IxIy, sums[3 * (size_t)i + 2] = Iy2;
+    if (response) {
+        const float det = (float)((double)Ix2 * (double)Iy2 - (double)IxIy * (double)IxIy);
+        const float tr = (float)(0.0 + (double)Ix2 + (double)Iy2);
+        response[i] = (tr * tr) / det;
+    }
 }
 
 }  // namespace vslam

@@ -1201,26 +1201,37 @@ int vslam_filter_keypoints(vslam_ctx* c, const vslam_pyramid* py, int octave, co
     return VSLAM_OK;
 }
 
-int vslam_edge_response_windows(vslam_ctx* c, const float* gx_windows, const float* gy_windows, int window_elems, size_t n,
-                                float* response) {
+static int gradient_windows(vslam_ctx* c, const float* gx_windows, const float* gy_windows, int window_elems, size_t n, float* sums,
+                            float* response, const char* what) {
     TRY(bind_device(c));
-    ARGCHK(c, window_elems >= 0 && ((gx_windows && gy_windows) || window_elems == 0 || n == 0) && (response || n == 0),
-           "computeEdgeResponse: bad arguments");
-    ARGCHK(c, n <= 0x7fffffff, "computeEdgeResponse: too many points");
+    ARGCHK(c, window_elems >= 0 && ((gx_windows && gy_windows) || window_elems == 0 || n == 0) && (sums || response || n == 0), what);
+    ARGCHK(c, n <= 0x7fffffff / 3, what);
     if (n == 0) return VSLAM_OK;
     const size_t we = (size_t)window_elems * n;
-    TRY(ws_reserve(c, 2 * ws_need(4 * we + 4) + ws_need(4 * n)));
+    TRY(ws_reserve(c, 2 * ws_need(4 * we + 4) + ws_need(12 * n) + ws_need(4 * n)));
     float* d_gx = ws_take<float>(c, we + 1);
     float* d_gy = ws_take<float>(c, we + 1);
+    float* d_s = ws_take<float>(c, 3 * n);
     float* d_r = ws_take<float>(c, n);
     if (we) {
         HIPCHK(c, hipMemcpyAsync(d_gx, gx_windows, 4 * we, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(d_gy, gy_windows, 4 * we, hipMemcpyHostToDevice, c->stream));
     }
     LAUNCH(c, "k_edge_response_windows", k_edge_response_windows, dim3((unsigned)((n + 255) / 256)), dim3(256), d_gx, d_gy, window_elems, (int)n,
-           d_r);
-    HIPCHK(c, hipMemcpyAsync(response, d_r, 4 * n, hipMemcpyDeviceToHost, c->stream));
+           sums ? d_s : (float*)nullptr, response ? d_r : (float*)nullptr);
+    if (sums) HIPCHK(c, hipMemcpyAsync(sums, d_s, 12 * n, hipMemcpyDeviceToHost, c->stream));
+    if (response) HIPCHK(c, hipMemcpyAsync(response, d_r, 4 * n, hipMemcpyDeviceToHost, c->stream));
     return vslam_ctx_sync(c);
+}
+
+int vslam_edge_response_windows(vslam_ctx* c, const float* gx_windows, const float* gy_windows, int window_elems, size_t n,
+                                float* response) {
+    return gradient_windows(c, gx_windows, gy_windows, window_elems, n, nullptr, response, "computeEdgeResponse: bad arguments");
+}
+
+int vslam_structure_matrix_windows(vslam_ctx* c, const float* gx_windows, const float* gy_windows, int window_elems, size_t n,
+                                   float* sums) {
+    return gradient_windows(c, gx_windows, gy_windows, window_elems, n, sums, nullptr, "StructureMatrix: bad arguments");
 }
 
 // ------------------------------------------------------------- device-resident batched path

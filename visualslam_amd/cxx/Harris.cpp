@@ -32,14 +32,25 @@ int main(int argc, char** argv) {
                 circles += abs_NMS.at<uchar>(r, c) > 253;                // draw_them_circles criterion, :139
                 strict += nms.at<uchar>(r, c) != 0;
             }
+        // the per-pixel helper of :10-29 reproduces the response at one interior pixel: det(M) - k tr(M)^2
+        int smMismatch = 0;
+        if (img.rows > 8 && img.cols > 8) {
+            const int i = img.rows / 2, j = img.cols / 2;
+            Mat M = Mat::zeros(2, 2, CV_32F);
+            StructureMatrix(M, grad_x, grad_y, 1, i, j);
+            const float det = (float)((double)M.at<float>(0, 0) * M.at<float>(1, 1) - (double)M.at<float>(0, 1) * M.at<float>(1, 0));
+            const float tr = (float)((double)M.at<float>(0, 0) + (double)M.at<float>(1, 1));
+            const float trtr = tr * tr, ktr = 0.04f * trtr, resp = det - ktr;
+            smMismatch = HResponse.at<float>(i, j) != (resp > 0 ? resp : 0.0f);
+        }
         // the same result from the single fused kernel
         const std::vector<vslam_kp> kps = HarrisKeypoints(img, 0.04f);
         const auto t2 = std::chrono::steady_clock::now();
         std::printf("{\"exe\": \"Harris\", \"rows\": %d, \"cols\": %d, \"keypoints_stagewise\": %ld, \"keypoints_fused\": %zu, "
-                    "\"nms3_maxima\": %ld, \"ms_stagewise\": %.3f, \"ms_fused\": %.3f}\n",
-                    img.rows, img.cols, circles, kps.size(), strict, std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                    "\"nms3_maxima\": %ld, \"structure_matrix_mismatch\": %d, \"ms_stagewise\": %.3f, \"ms_fused\": %.3f}\n",
+                    img.rows, img.cols, circles, kps.size(), strict, smMismatch, std::chrono::duration<double, std::milli>(t1 - t0).count(),
                     std::chrono::duration<double, std::milli>(t2 - t1).count());
-        return circles == (long)kps.size() ? 0 : 2;
+        return circles == (long)kps.size() && !smMismatch ? 0 : 2;
     } catch (const std::exception& e) {
         std::fprintf(stderr, "Harris: %s\n", e.what());
         return EXIT_FAILURE;

@@ -333,3 +333,22 @@ void filterKeypoints(GaussPyramid& pyramid, int octave, std::vector<SLAM::point>
     for (size_t i = 0; i < n; ++i)
         reducedKeypoints.emplace_back(buf[i].row, buf[i].col, buf[i].value, buf[i].padding, buf[i].octave, buf[i].level);
 }
+
+void StructureMatrix(cv::Mat& M, cv::Mat& Ix, cv::Mat& Iy, int padding, int i, int j) {
+    vslam_ctx* c = default_context();
+    if (padding < 0 || i - padding < 0 || j - padding < 0 || i + padding >= Ix.rows || j + padding >= Ix.cols || Iy.rows != Ix.rows ||
+        Iy.cols != Ix.cols || M.rows < 2 || M.cols < 2)
+        throw vslam::Error(VSLAM_ERR_RANGE, "StructureMatrix: window outside the gradient images");
+    std::vector<float> wx, wy;
+    for (int u = i - padding; u <= i + padding; ++u)      // :16
+        for (int v = j - padding; v <= j + padding; ++v) {  // :17
+            wx.push_back(Ix.at<float>(u, v));
+            wy.push_back(Iy.at<float>(u, v));
+        }
+    float m[3] = {0.f, 0.f, 0.f};
+    check(vslam_structure_matrix_windows(c, wx.data(), wy.data(), (int)wx.size(), 1, m), c, "StructureMatrix");
+    M.at<float>(0, 0) = m[0];  // :25-28
+    M.at<float>(0, 1) = m[1];
+    M.at<float>(1, 0) = m[1];
+    M.at<float>(1, 1) = m[2];
+}

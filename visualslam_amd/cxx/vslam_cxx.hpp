@@ -14,8 +14,8 @@
 //   void filterKeypoints(GaussPyramid&, int, std::vector<SLAM::point>&, std::vector<SLAM::point>&)
 //                                                              Diff_of_Gauss.cpp:254
 // plus the OpenCV calls on the path (vslamcv::GaussianBlur / Sobel / convertScaleAbs / resize).
-// StructureMatrix (:10) is a per-pixel helper used only inside HarrisCorner and is subsumed by
-// it.  Errors of the C ABI surface as vslam::Error (the reference relies on cv::Exception).
+// StructureMatrix (:10) is also provided as a per-pixel call; HarrisCorner itself runs the whole
+// image in one kernel.  Errors of the C ABI surface as vslam::Error (the reference relies on cv::Exception).
 // The per-level gradient getters (octaveGradX/Y/Mag/Orient, processGradients, SURVEY.md section 8f
 // row 1) are computed on the GPU on first access instead of in the constructor.
 #pragma once
@@ -60,6 +60,10 @@ void convertScaleAbs(const cv::Mat& src, cv::Mat& dst);
 void resize(const cv::Mat& src, cv::Mat& dst, cv::Size dsize, double fx, double fy, int interpolation);
 }  // namespace vslamcv
 
+// void StructureMatrix(Mat& M, Mat& Ix, Mat& Iy, int padding, int i, int j), Harris_corners.cpp:10-29:
+// gathers the (2*padding+1)^2 window on the host, sums on the GPU (vslam_structure_matrix_windows).
+// HarrisCorner does not call it per pixel - it runs the whole image in one kernel.
+void StructureMatrix(cv::Mat& M, cv::Mat& Ix, cv::Mat& Iy, int padding, int i, int j);
 cv::Mat HarrisCorner(cv::Mat& Ix, cv::Mat& Iy);
 cv::Mat NonMaximumSuppression(cv::Mat& response, int windowSize);
 cv::Mat NMS2(cv::Mat& response, int windowSize);
