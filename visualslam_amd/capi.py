@@ -14,7 +14,9 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvslam.so")
+# VSLAM_LIBRARY: development switch for A/B timing of two builds of the same library on one box
+# (tools/ab.sh); everything else uses the in-tree build.
+LIB_PATH = os.environ.get("VSLAM_LIBRARY") or os.path.join(_HERE, "lib", "libvslam.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 MAX_OCTAVES = 16
@@ -120,7 +122,7 @@ def build(force: bool = False) -> str:
     """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(_HERE, "..", "include", "vslam.h")]
     stale = force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(s) for s in srcs)
-    if stale:
+    if stale and not os.environ.get("VSLAM_LIBRARY"):
         r = subprocess.run(["make", "-C", CSRC] + (["-B"] if force else []), capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("building libvslam.so failed:\n" + r.stdout + r.stderr)
