@@ -65,7 +65,7 @@ struct HarrisStripArgs {
 
 // grid = (ceil(nstrips*nseg / 4), 1, frames), block = 256 (4 independent waves).
 template <bool ANYW>
-__global__ __launch_bounds__(256) void k_harris_strip(const HarrisStripArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_harris_strip(const HarrisStripArgs a) {
     const int lane = threadIdx.x & 63;
     const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int nseg = (a.rows + a.seg - 1) / a.seg;
