@@ -141,6 +141,13 @@ __device__ __forceinline__ void pyr_level(const PyrTaps<CFG>* __restrict__ taps,
         for (int j = 0; j < 8; ++j) acc[jr][j] = 32768u;  // the one round-half-up of A2-iv
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
+        // Wide kernels (octave 1: up to 58 tap pairs per level) do not fit the SGPR file next to the
+        // rest of the pass and were reloaded through v_readlane (410 of them).  There the pairs
+        // are pinned per 8-column block instead: block b reads tp[8b-7 .. 8b+7], loaded behind an
+        // opaque zero defined one block earlier, so at most two blocks' pairs are live.
+        uint32_t zb = 0;
+        if (CFG::TPM > 40 && (b & 1) == 0) asm volatile("s_mov_b32 %0, 0" : "=s"(zb));
+        const uint32_t* __restrict__ tpb = CFG::TPM > 40 ? tp + zb : tp;
 #pragma unroll
         for (int jr = 0; jr < 4; ++jr) {
             const uint4 v = *reinterpret_cast<const uint4*>(hp + (4 * rg + jr) * HPP + 4 * xg + 4 * b);
@@ -154,7 +161,7 @@ __device__ __forceinline__ void pyr_level(const PyrTaps<CFG>* __restrict__ taps,
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int e = 2 * (4 * b + pp) - j - dl + 1;  // tap pair (e-1, e)
-                    if (e >= 0 && e <= n) acc[jr][j] = udot2(vv[pp], tp[e], acc[jr][j]);
+                    if (e >= 0 && e <= n) acc[jr][j] = udot2(vv[pp], tpb[e], acc[jr][j]);
                 }
             }
         }
