@@ -193,8 +193,8 @@ __global__ __launch_bounds__(256) void k_extrema_w3(const uint8_t* __restrict__ 
                         int nv;  // exactly singular: the test is value/255 > 0.03f
                         listed[L - 1] = feature_point_localization(d_x, d_y, d_s, (int)self[L], nv);
                     } else {
-                        // the f64 closed-form inverse is ~10x the rest of this kernel per call: queue
-                        // the site so that the workgroup evaluates its queue densely afterwards
+                        // three non-zero differences: queue the site so that the workgroup evaluates
+                        // its queue on dense lanes afterwards
                         const unsigned int q = atomicAdd(&qn, 1u);
                         queue[q] = make_uint2((uint32_t)(d_x + 256) | ((uint32_t)(d_y + 256) << 10) | ((uint32_t)(d_s + 256) << 20),
                                               self[L] | ((uint32_t)((L - 1) * 256 + threadIdx.x) << 8));
@@ -209,8 +209,10 @@ __global__ __launch_bounds__(256) void k_extrema_w3(const uint8_t* __restrict__ 
         for (unsigned int q = threadIdx.x; q < n; q += 256) {
             const uint2 e = queue[q];
             int nv;
+            // table lookup for small differences (all of them on ordinary frames), closed form otherwise;
+            // dense lanes with independent loads, so the table's latency overlaps across the queue
             qkeep[e.y >> 8] = feature_point_localization((int)(e.x & 1023u) - 256, (int)((e.x >> 10) & 1023u) - 256,
-                                                         (int)(e.x >> 20) - 256, (int)(e.y & 255u), nv);
+                                                         (int)(e.x >> 20) - 256, (int)(e.y & 255u), nv, g.loc_lut);
         }
         __syncthreads();
 #pragma unroll

@@ -131,23 +131,23 @@ struct OrientEntries {  // entry = one keypoint of filterKeypoints: 36-bit mask 
     }
 };
 
-// localize mode: rewrite the value of every listed point the way FeaturePointLocalization does
-// at Diff_of_Gauss.cpp:246.  One thread per list record (dense, unlike the per-word emit loop).
-// grid = (ceil(cap/256), frames); octaves [o_begin, o_end) only - the list is appended per octave.
-__global__ __launch_bounds__(256) void k_points_localize_value(vslam_point* __restrict__ pts, const unsigned int* __restrict__ counts,
-                                                               unsigned int cap, const uint8_t* __restrict__ pyr, size_t pframe,
-                                                               ExtGeom g, int o_begin, int o_end) {
+// localize mode: rewrite the value of the points one octave has just appended the way
+// FeaturePointLocalization does at Diff_of_Gauss.cpp:246.  One thread per list record (dense,
+// unlike the per-word emit loop); records [begins[f], min(counts[f], cap)) of frame f, begins ==
+// nullptr meaning 0.  grid = (ceil(most records an octave can add / 256), frames).
+__global__ __launch_bounds__(256) void k_points_localize_value(vslam_point* __restrict__ pts, const unsigned int* __restrict__ begins,
+                                                               const unsigned int* __restrict__ counts, unsigned int cap,
+                                                               const uint8_t* __restrict__ pyr, size_t pframe, ExtGeom g) {
     const int f = blockIdx.y;
-    const unsigned int i = blockIdx.x * 256 + threadIdx.x;
+    const unsigned int i = (begins ? begins[f] : 0u) + blockIdx.x * 256 + threadIdx.x;
     if (i >= min(counts[f], cap)) return;
     vslam_point& pt = pts[(size_t)f * cap + i];
     const int o = pt.octave;
-    if (o < o_begin || o >= o_end) return;
     const size_t P = (size_t)g.rows[o] * g.pitch[o];
     const uint8_t* dog = pyr + f * pframe + g.oct_off[o] + (size_t)VSLAM_NUM_LEVELS * P;
     int d_x, d_y, d_s, nv;
     dog_differences(dog, P, g.rows[o], g.cols[o], g.pitch[o], g.pad, pt.level, pt.row, pt.col, d_x, d_y, d_s);
-    feature_point_localization(d_x, d_y, d_s, pt.value, nv);
+    feature_point_localization(d_x, d_y, d_s, pt.value, nv, g.loc_lut);
     pt.value = nv;
 }
 

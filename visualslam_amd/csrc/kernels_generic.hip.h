@@ -253,6 +253,7 @@ struct ExtGeom {
     int lat_rows[VSLAM_MAX_OCTAVES], lat_cols[VSLAM_MAX_OCTAVES], wpr[VSLAM_MAX_OCTAVES];
     unsigned long long oct_off[VSLAM_MAX_OCTAVES];   // byte offset of the octave in a pyramid frame block
     unsigned long long bits_off[VSLAM_MAX_OCTAVES];  // word offset of the octave in a bits frame block
+    const float* loc_lut;  // table of the localization's quadratic term for small differences, may be null
 };
 
 // The three finite differences of FeaturePointLocalization (Diff_of_Gauss.cpp:226-228) at padded
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(256) void k_extrema(const uint8_t* __restrict__ pyr
         } else if (cand) {
             int d_x, d_y, d_s, nv;
             dog_differences(dog, P, rows, cols, pitch, pad, level, i, j, d_x, d_y, d_s);
-            listed = feature_point_localization(d_x, d_y, d_s, self, nv);
+            listed = feature_point_localization(d_x, d_y, d_s, self, nv, g.loc_lut);
         }
     }
     const unsigned long long wc = __ballot(cand), wl = __ballot(listed);

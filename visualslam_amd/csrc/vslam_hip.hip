@@ -46,6 +46,7 @@ struct vslam_ctx {
     std::vector<std::pair<size_t, void*>> block_cache;
     // kernels whose dynamic-LDS ceiling has been raised on this device (once, not per launch)
     std::set<const void*> lds_raised;
+    float* loc_lut = nullptr;  // FeaturePointLocalization table (kernels_localize.hip.h), built on first use
     // bench timing hook
     std::string timing_name;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timing_ev;
@@ -391,8 +392,19 @@ static int enqueue_compaction(vslam_ctx* c, const E& ent, size_t entries, int nf
 }
 static inline size_t compaction_ws_elems(size_t entries, int nf) { return (size_t)nf * ((entries + CMP_CHUNK - 1) / CMP_CHUNK) + 64; }
 
-static void fill_geom(const vslam_params& p, const vslam_batch_layout& L, ExtGeom& g) {
+// The table of the localization's quadratic term, filled by the same device function that the
+// kernels fall back to (so a lookup cannot differ from the computation).
+static int ensure_loc_lut(vslam_ctx* c) {
+    if (c->loc_lut) return VSLAM_OK;
+    constexpr int n = LOC_LUT_N * LOC_LUT_N * LOC_LUT_N;
+    HIPCHK(c, hipMalloc((void**)&c->loc_lut, sizeof(float) * n));
+    LAUNCH(c, "k_build_localization_lut", k_build_localization_lut, dim3((n + 255) / 256), dim3(256), c->loc_lut);
+    return VSLAM_OK;
+}
+
+static void fill_geom(const vslam_ctx* c, const vslam_params& p, const vslam_batch_layout& L, ExtGeom& g) {
     std::memset(&g, 0, sizeof(g));
+    g.loc_lut = c->loc_lut;
     g.n_oct = L.n_octaves;
     g.window = p.extrema_window;
     g.pad = (p.extrema_window - 1) / 2;
@@ -417,6 +429,7 @@ struct DogScratch {
     uint16_t* h = nullptr;  // nf * P0 u16
     unsigned long long* lflags = nullptr;
     unsigned int* cws = nullptr;  // compaction chunk totals / offsets
+    unsigned int* pbegin = nullptr;  // localize mode: per-frame list length before the current octave
 };
 
 // u16 scratch elements per frame: 6 row-sum images for a strip octave, 1 for a generic octave,
@@ -436,7 +449,7 @@ static size_t dog_scratch_bytes(const vslam_batch_layout& L, double sigma0, int 
     size_t sum_p = 0;
     for (int o = 0; o < L.n_octaves; ++o) sum_p += (size_t)L.rows[o] * L.pitch[o];
     return ws_need((size_t)nf * sum_p) + ws_need((size_t)nf * dog_h_elems(L, sigma0) * 2 + 256) +
-           ws_need((size_t)nf * L.bits_frame_words * 8) + ws_need(4 * compaction_ws_elems(L.bits_frame_words, nf));
+           ws_need((size_t)nf * L.bits_frame_words * 8) + ws_need(4 * compaction_ws_elems(L.bits_frame_words, nf)) + ws_need(4 * (size_t)nf);
 }
 
 static int dog_scratch_take(vslam_ctx* c, const vslam_batch_layout& L, double sigma0, int nf, DogScratch& s) {
@@ -450,7 +463,8 @@ static int dog_scratch_take(vslam_ctx* c, const vslam_batch_layout& L, double si
     s.h = ws_take<uint16_t>(c, (size_t)nf * dog_h_elems(L, sigma0) + 128);
     s.lflags = ws_take<unsigned long long>(c, (size_t)nf * L.bits_frame_words);
     s.cws = ws_take<unsigned int>(c, compaction_ws_elems(L.bits_frame_words, nf));
-    if (!s.bases || !s.h || !s.lflags || !s.cws) return fail(c, VSLAM_ERR_NOMEM, "workspace sizing error (dog)");
+    s.pbegin = ws_take<unsigned int>(c, nf);
+    if (!s.bases || !s.h || !s.lflags || !s.cws || !s.pbegin) return fail(c, VSLAM_ERR_NOMEM, "workspace sizing error (dog)");
     return VSLAM_OK;
 }
 
@@ -495,7 +509,8 @@ static int enqueue_dog(vslam_ctx* c, const vslam_params& p, const vslam_batch_la
     // `side`: stream for the extrema scans and the list compaction (they only read what the
     // octave kernels wrote); ordered after each octave by an event.  nullptr = same stream.
     ExtGeom g;
-    fill_geom(p, L, g);
+    if (p.localize) TRY(ensure_loc_lut(c));
+    fill_geom(c, p, L, g);
     LAUNCH(c, "k_resize_linear2x_slide", k_resize_linear2x_slide, dim3(((p.cols + 3) / 4 + 255) / 256, (p.rows + 15) / 16, nf), dim3(256),
            frames, fstep, fframe, s.bases + s.base_off[0], s.bases_frame, L.pitch[0], p.rows, p.cols, 16);
     for (int o = 0; o < L.n_octaves; ++o) {
@@ -549,10 +564,20 @@ static int enqueue_dog(vslam_ctx* c, const vslam_params& p, const vslam_batch_la
         if (do_extrema && points && counts) {
             StreamSwap sw(c, side ? side : c->stream);
             DogEntries ent{s.lflags, L.bits_frame_words, pyr, pframe, g, o, o + 1, points};
+            // localize mode: the records this octave appends get their values rewritten right away
+            // (a dense pass over [count before, count after)), beside the next octave's kernels
+            const size_t oct_max = std::min<size_t>((size_t)3 * L.lat_rows[o] * L.lat_cols[o], p.dog_cap);
+            const bool rewrite = p.localize && p.dog_cap && oct_max;
+            if (rewrite) {
+                if (o > 0)
+                    HIPCHK(c, hipMemcpyAsync(s.pbegin, counts, sizeof(unsigned int) * (size_t)nf, hipMemcpyDeviceToDevice, c->stream));
+                else
+                    HIPCHK(c, hipMemsetAsync(s.pbegin, 0, sizeof(unsigned int) * (size_t)nf, c->stream));
+            }
             TRY(enqueue_compaction(c, ent, (size_t)3 * L.lat_rows[o] * L.lat_words[o], nf, s.cws, p.dog_cap, counts, o > 0 ? 1 : 0));
-            if (p.localize && o == L.n_octaves - 1 && p.dog_cap)
-                LAUNCH(c, "k_points_localize_value", k_points_localize_value, dim3((p.dog_cap + 255) / 256, nf), dim3(256), points, counts,
-                       p.dog_cap, pyr, pframe, g, 0, L.n_octaves);
+            if (rewrite)
+                LAUNCH(c, "k_points_localize_value", k_points_localize_value, dim3((unsigned)((oct_max + 255) / 256), nf), dim3(256), points,
+                       s.pbegin, counts, p.dog_cap, pyr, pframe, g);
         }
     }
     return VSLAM_OK;
@@ -662,6 +687,7 @@ int vslam_ctx_destroy(vslam_ctx* c) {
     }
     if (c->ws) (void)hipFree(c->ws);
     for (auto& b : c->block_cache) (void)hipFree(b.second);
+    if (c->loc_lut) (void)hipFree(c->loc_lut);
     for (int i = 0; i < 2; ++i) {
         if (c->aux[i]) (void)hipStreamDestroy(c->aux[i]);
         if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
@@ -1060,7 +1086,8 @@ static int dog_points_host(vslam_ctx* c, const vslam_pyramid* py, int octave, in
     vslam_batch_layout L;
     if (make_layout(&p, &L) != VSLAM_OK) return fail(c, VSLAM_ERR_INVALID, "bad extrema parameters");
     ExtGeom g;
-    fill_geom(p, L, g);
+    if (p.localize) TRY(ensure_loc_lut(c));
+    fill_geom(c, p, L, g);
     const size_t words = L.bits_frame_words;
     TRY(ws_reserve(c, 2 * ws_need(words * 8) + ws_need(sizeof(vslam_point) * (size_t)p.dog_cap) + 256 + ws_need(4 * compaction_ws_elems(words, 1))));
     unsigned long long* d_bits = ws_take<unsigned long long>(c, words);
@@ -1084,8 +1111,8 @@ static int dog_points_host(vslam_ctx* c, const vslam_pyramid* py, int octave, in
         DogEntries ent{d_lf, words, py->d_block, L.pyramid_frame_bytes, g, octave, octave + 1, d_pts};
         TRY(enqueue_compaction(c, ent, ow, 1, d_cws, p.dog_cap, d_n, 0));
         if (localize && p.dog_cap)
-            LAUNCH(c, "k_points_localize_value", k_points_localize_value, dim3((p.dog_cap + 255) / 256, 1), dim3(256), d_pts, d_n, p.dog_cap,
-                   py->d_block, L.pyramid_frame_bytes, g, octave, octave + 1);
+            LAUNCH(c, "k_points_localize_value", k_points_localize_value, dim3((p.dog_cap + 255) / 256, 1), dim3(256), d_pts,
+                   (const unsigned int*)nullptr, d_n, p.dog_cap, py->d_block, L.pyramid_frame_bytes, g);
     }
     unsigned int n = 0;
     HIPCHK(c, hipMemcpyAsync(&n, d_n, 4, hipMemcpyDeviceToHost, c->stream));
@@ -1117,7 +1144,8 @@ int vslam_localize_points(vslam_ctx* c, const int* diffs, size_t n, int* keep, i
     int4* d_in = ws_take<int4>(c, n);
     int2* d_out = ws_take<int2>(c, n);
     HIPCHK(c, hipMemcpyAsync(d_in, diffs, 16 * n, hipMemcpyHostToDevice, c->stream));
-    LAUNCH(c, "k_localize_points", k_localize_points, dim3((unsigned)((n + 255) / 256)), dim3(256), d_in, (int)n, d_out);
+    TRY(ensure_loc_lut(c));  // same path as the fused kernels: table for small differences, closed form otherwise
+    LAUNCH(c, "k_localize_points", k_localize_points, dim3((unsigned)((n + 255) / 256)), dim3(256), d_in, (int)n, d_out, c->loc_lut);
     std::vector<int2> h(n);
     HIPCHK(c, hipMemcpyAsync(h.data(), d_out, 8 * n, hipMemcpyDeviceToHost, c->stream));
     TRY(vslam_ctx_sync(c));
