@@ -257,9 +257,12 @@ def test_feature_point_localization_bit_exact(ctx):
     # every combination, including the ones whose outcome is rounding noise
     r = np.arange(-12, 13)
     grid = np.stack(np.meshgrid(r, r, r, [0, 5, 7, 8, 9, 40, 255], indexing="ij"), -1).reshape(-1, 4)
+    # both sides of the edge of the 16^3 table of the quadratic term (kernels_localize.hip.h)
+    e = np.array([-17, -16, -15, -14, -1, 1, 14, 15, 16, 17])
+    edge = np.stack(np.meshgrid(e, e, e, [0, 8, 200], indexing="ij"), -1).reshape(-1, 4)
     rng = np.random.default_rng(7)
     rnd = np.concatenate([rng.integers(-255, 256, (200000, 3)), rng.integers(0, 256, (200000, 1))], 1)
-    d = np.concatenate([grid, rnd]).astype(np.int32)
+    d = np.concatenate([grid, edge, rnd]).astype(np.int32)
     keep, val = ctx.localize_points(d)
     wk = np.zeros(len(d), bool)
     wv = d[:, 3].copy()
