@@ -127,6 +127,8 @@ def main():
     ap.add_argument("--kernel", default=None, help="kernel to time with HIP events for the roofline object")
     ap.add_argument("--localize", type=int, default=0,
                     help="1: DoG list = FeaturePointLocalization survivors (SURVEY 8f row 2) instead of the contrast-8 candidate list")
+    ap.add_argument("--orient", type=int, default=0,
+                    help="1: also run filterKeypoints on every frame's keypoint list (SURVEY 8f row 3); implies --localize 1")
     ap.add_argument("--cpu-sample", type=int, default=6, help="frames in the CPU baseline sample (0 = skip)")
     args = ap.parse_args()
 
@@ -161,7 +163,7 @@ def main():
     capi.build()
     rows, cols, n = args.rows, args.cols, args.frames
     ctx = capi.Context(local_rank, torch.cuda.current_stream().cuda_stream)
-    p = capi.default_params(rows, cols, n_octaves=args.octaves, localize=args.localize)
+    p = capi.default_params(rows, cols, n_octaves=args.octaves, localize=1 if args.orient else args.localize, orient=args.orient)
     L = capi.batch_layout(p)
 
     # one camera stream per GPU: stream_id = rank
@@ -176,6 +178,9 @@ def main():
         dog_points=torch.empty((n, p.dog_cap, 6), dtype=torch.int32, device=dev),
         dog_counts=torch.zeros(n, dtype=torch.int32, device=dev),
     )
+    if args.orient:
+        out["oriented_points"] = torch.empty((n, p.oriented_cap, 6), dtype=torch.int32, device=dev)
+        out["oriented_counts"] = torch.zeros(n, dtype=torch.int32, device=dev)
     counts_local = torch.zeros(2, dtype=torch.int64, device=dev)
     counts_all = torch.zeros((world, 2), dtype=torch.int64, device=dev)
 
@@ -263,11 +268,12 @@ def main():
             "config": {
                 "workload": f"batch of {n} synthetic {cols}x{rows} frames per GPU, Harris(k=0.04)+NMS and DoG pyramid "
                             f"{args.octaves} octaves x (6 Gaussian, 5 DoG) + extrema, fused (BASELINE config 4)",
-                "frames_per_gpu": n, "rows": rows, "cols": cols, "octaves": args.octaves, "localize": args.localize,
+                "frames_per_gpu": n, "rows": rows, "cols": cols, "octaves": args.octaves, "localize": p.localize, "orient": args.orient,
                 "parallelism": f"frames sharded 1 stream/GPU x{world}; RCCL all-gather of counts only",
             },
             "keypoints_per_sec": kp_per_step * args.steps / dt,
-            "keypoints_per_step": {"harris": totals[0], "dog": totals[1], "list_overflow": overflow},
+            "keypoints_per_step": {"harris": totals[0], "dog": totals[1], "list_overflow": overflow,
+                                   **({"oriented_rank0": int(out["oriented_counts"].sum())} if args.orient else {})},
             "pipeline_hbm": {
                 "algorithmic_bytes_per_frame": bytes_frame,
                 "achieved_GBps": bytes_frame * fps / world / 1e9,

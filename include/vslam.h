@@ -236,8 +236,12 @@ typedef struct {
     int min_contrast;    /* list threshold on the 8-bit DoG value; 8 */
     int localize;        /* 1: dog_points = FeaturePointLocalization survivors (vslam_dog_keypoints),
                           * min_contrast unused; 0 (default): candidates with value >= min_contrast */
+    int orient;          /* 1: also run filterKeypoints (Diff_of_Gauss.cpp:301-372) on every frame's
+                          * keypoint list -> oriented_points / oriented_counts; needs localize = 1 */
     uint32_t harris_cap; /* per-frame capacity of the Harris keypoint list */
     uint32_t dog_cap;    /* per-frame capacity of the DoG point list */
+    uint32_t oriented_cap; /* per-frame capacity of the oriented keypoint list (and of the
+                            * edge-test survivors it is made from) */
 } vslam_params;
 
 /* Byte layout of the per-frame output blocks, so that a caller can allocate them. */
@@ -272,6 +276,9 @@ typedef struct {
     uint64_t* extrema_bits;  /* [n][bits_frame_words] */
     vslam_point* dog_points; /* [n][dog_cap], order (octave, level, i, j) */
     uint32_t* dog_counts;    /* [n] totals (may exceed cap) */
+    vslam_point* oriented_points; /* [n][oriented_cap] filterKeypoints output: {row, col, angle, 0, octave, level},
+                                   * order (octave, keypoint, histogram bin); params.orient = 1 */
+    uint32_t* oriented_counts;    /* [n] totals (may exceed cap) */
 } vslam_batch_out;
 
 void vslam_params_default(vslam_params* p, int rows, int cols);

@@ -37,6 +37,9 @@ def run_batch(ctx, torch, frames_np, with_nms2=True, **pkw):
         dog_points=torch.zeros((n, p.dog_cap, 6), dtype=torch.int32, device=dev),
         dog_counts=torch.zeros(n, dtype=torch.int32, device=dev),
     )
+    if p.orient:
+        o["oriented_points"] = torch.zeros((n, p.oriented_cap, 6), dtype=torch.int32, device=dev)
+        o["oriented_counts"] = torch.zeros(n, dtype=torch.int32, device=dev)
     ctx.detect_batch(p, frames, **o)
     torch.cuda.synchronize()
     return p, L, {k: (v.cpu().numpy() if v is not None else None) for k, v in o.items()}
@@ -81,6 +84,12 @@ def check_frame(p, L, out, f, img, n_oct):
     m = min(len(allp), p.dog_cap)
     got = out["dog_points"][f][:m].copy().view(capi.POINT_DTYPE).reshape(-1)
     assert got.tobytes() == allp[:m].tobytes()
+    if p.orient:  # filterKeypoints per octave, concatenated in octave order
+        wo = np.concatenate([want.filter_keypoints(o, all_pts[o]) for o in range(n_oct)])
+        assert out["oriented_counts"][f] == len(wo), (f, int(out["oriented_counts"][f]), len(wo))
+        mo = min(len(wo), p.oriented_cap)
+        goo = out["oriented_points"][f][:mo].copy().view(capi.POINT_DTYPE).reshape(-1)
+        assert goo.tobytes() == wo[:mo].tobytes()
     want.close()
 
 
@@ -127,6 +136,23 @@ def test_batch_localized_keypoints(env, shape, n_oct, window):
         check_frame(p, L, out, f, frames[f], n_oct)
 
 
+@pytest.mark.parametrize("shape,n_oct", [((96, 160), 3), ((75, 131), 2), ((270, 480), 4), ((40, 56), 3)])
+def test_batch_oriented_keypoints(env, shape, n_oct):
+    # orient = 1: filterKeypoints inside the batched path (edge test -> survivors -> magnitude region in
+    # LDS -> histogram peaks), bit-exact against the oracle; noise frames have thousands of survivors
+    ctx, torch = env
+    frames = synth.frames_np(4, *shape, stream_id=17)
+    frames[1] = synth.frame_np(*shape, kind="noise")
+    frames[3] = synth.frame_np(*shape, frame=5, stream_id=3, kind="noise")
+    p, L, out = run_batch(ctx, torch, frames, n_octaves=n_oct, localize=1, orient=1)
+    assert out["oriented_counts"].sum() > 0
+    for f in range(4):
+        check_frame(p, L, out, f, frames[f], n_oct)
+    # a tight survivor / output capacity truncates the lists but keeps the totals of what was processed
+    p2, L2, out2 = run_batch(ctx, torch, frames[1:2], n_octaves=n_oct, localize=1, orient=1, oriented_cap=8)
+    assert (out2["oriented_points"][0][:8] == out["oriented_points"][1][:8]).all()
+
+
 def test_config1_640x480_plumbing(env):
     # BASELINE config 1: 640x480 grayscale frame, Harris k=0.04 (synthetic, seed 0x5EED0001)
     ctx, torch = env
@@ -149,8 +175,8 @@ def test_full_1080p_frame_localized_and_oriented(env):
     # and the per-image filterKeypoints call against the oracle (noise frame: every stage populated)
     ctx, torch = env
     frames = synth.frame_np(1080, 1920, kind="noise")[None].copy()  # [None] alone leaves stride 0 on the new axis
-    p, L, out = run_batch(ctx, torch, frames, with_nms2=False, localize=1)
-    check_frame(p, L, out, 0, frames[0], 4)
+    p, L, out = run_batch(ctx, torch, frames, with_nms2=False, localize=1, orient=1, oriented_cap=1 << 17)
+    check_frame(p, L, out, 0, frames[0], 4)  # includes the batched filterKeypoints list
     want, got = oracle.Pyramid(frames[0], 4, 1.6), ctx.pyramid(frames[0], 4, 1.6)
     n_oriented = 0
     for o in range(4):

@@ -37,7 +37,8 @@ class Params(C.Structure):
     _fields_ = [
         ("rows", C.c_int), ("cols", C.c_int), ("n_octaves", C.c_int), ("sigma0", C.c_double),
         ("harris_k", C.c_float), ("do_harris", C.c_int), ("extrema_window", C.c_int),
-        ("min_contrast", C.c_int), ("localize", C.c_int), ("harris_cap", C.c_uint32), ("dog_cap", C.c_uint32),
+        ("min_contrast", C.c_int), ("localize", C.c_int), ("orient", C.c_int), ("harris_cap", C.c_uint32), ("dog_cap", C.c_uint32),
+        ("oriented_cap", C.c_uint32),
     ]
 
 
@@ -59,6 +60,7 @@ class BatchOut(C.Structure):
         ("harris_kps", C.c_void_p), ("harris_counts", C.c_void_p),
         ("pyramid", C.c_void_p), ("extrema_bits", C.c_void_p),
         ("dog_points", C.c_void_p), ("dog_counts", C.c_void_p),
+        ("oriented_points", C.c_void_p), ("oriented_counts", C.c_void_p),
     ]
 
 

@@ -131,6 +131,60 @@ struct OrientEntries {  // entry = one keypoint of filterKeypoints: 36-bit mask 
     }
 };
 
+struct SurvivorEntries {  // entry = 64 consecutive list records of a frame: bits = records that pass the edge test
+    const unsigned long long* flags;
+    size_t fwords;
+    unsigned int* surv;  // [frame][scap] record indices, ascending
+    __device__ size_t count() const { return fwords; }
+    __device__ unsigned int load(int f, size_t e, unsigned long long (&w)[4]) const {
+        w[0] = flags[f * fwords + e];
+        return __popcll(w[0]);
+    }
+    __device__ void emit(int f, size_t e, const unsigned long long (&w)[4], unsigned int pos, unsigned int cap) const {
+        unsigned long long m = w[0];
+        while (m) {
+            const int b = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            if (pos < cap) surv[(size_t)f * cap + pos] = (unsigned int)(e * 64 + b);
+            ++pos;
+        }
+    }
+};
+
+struct OrientBatchEntries {  // entry = one survivor of a frame: 36-bit mask of its histogram peaks
+    const unsigned long long* masks;
+    const unsigned int* surv;
+    const unsigned int* scounts;
+    unsigned int scap;
+    const vslam_point* pts;
+    unsigned int pcap;
+    vslam_point* out;
+    __device__ size_t count() const { return scap; }
+    __device__ unsigned int load(int f, size_t e, unsigned long long (&w)[4]) const {
+        w[0] = e < min(scounts[f], scap) ? masks[(size_t)f * scap + e] : 0ull;
+        return __popcll(w[0]);
+    }
+    __device__ void emit(int f, size_t e, const unsigned long long (&w)[4], unsigned int pos, unsigned int cap) const {
+        const vslam_point kp = pts[(size_t)f * pcap + surv[(size_t)f * scap + e]];
+        unsigned long long m = w[0];
+        while (m) {
+            const int b = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            if (pos < cap) {  // SLAM::point{y, x, angle, 0, octave, level}, Diff_of_Gauss.cpp:365
+                vslam_point pt;
+                pt.row = kp.row;
+                pt.col = kp.col;
+                pt.value = b * 10;
+                pt.padding = 0;
+                pt.octave = kp.octave;
+                pt.level = kp.level;
+                out[(size_t)f * cap + pos] = pt;
+            }
+            ++pos;
+        }
+    }
+};
+
 // localize mode: rewrite the value of the points one octave has just appended the way
 // FeaturePointLocalization does at Diff_of_Gauss.cpp:246.  One thread per list record (dense,
 // unlike the per-word emit loop); records [begins[f], min(counts[f], cap)) of frame f, begins ==

@@ -1,0 +1,153 @@
+// filterKeypoints (Diff_of_Gauss.cpp:301-372) inside the batched, device-resident path
+// (params.orient): every frame's keypoint list (vslam_detect_batch_dev with localize = 1) goes
+// through the edge test and the orientation histogram without leaving HBM.
+//
+//   k_edge_flags          one thread per list record: computeEdgeResponse (:79-109) on Sobel
+//                         differences formed from the u8 Gaussian level, tr^2/det < 12.1 (:335);
+//                         ballot words of the survivors -> ordered survivor index list
+//   k_orient_survivors    one workgroup per survivor (grid-stride over the list): unlike the
+//                         per-image kernel (kernels_orient.hip.h) there are no dense magnitude /
+//                         orientation images - materialising them for a batch costs more than the
+//                         whole detection - so the (16+2R)^2 magnitude region the window's blur
+//                         reaches is formed in LDS from the Gaussian level (same f32 arithmetic:
+//                         exact integer gradients, correctly rounded sqrt), then row pass, symmetric
+//                         column pass, histogram and peak mask exactly as in the per-image kernel.
+//                         Regions that do not fit the LDS (the 300-tap kernels of octave 3, where
+//                         survivors are rare) take the magnitudes tap by tap instead.
+// The masks are compacted into SLAM::point{row, col, angle, 0, octave, level} records in list
+// order, which is the reference's order (octave, keypoint, bin).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "kernels_aux.hip.h"
+#include "kernels_orient.hip.h"
+
+namespace vslam {
+
+struct OrientBatchGeom {
+    int n_oct;
+    int rows[VSLAM_MAX_OCTAVES], cols[VSLAM_MAX_OCTAVES], pitch[VSLAM_MAX_OCTAVES];
+    unsigned long long oct_off[VSLAM_MAX_OCTAVES];  // byte offset of the octave in a pyramid frame block
+    const float* kern[VSLAM_MAX_OCTAVES][VSLAM_NUM_LEVELS];  // f32 Gaussian taps of sigma = 1.5 * sigma(o, l)
+    int kn[VSLAM_MAX_OCTAVES][VSLAM_NUM_LEVELS];
+};
+
+// grid = (ceil(cap/256), frames): flags[f][i/64] bit i%64 = record i of frame f passes the edge test
+__global__ __launch_bounds__(256) void k_edge_flags(const vslam_point* __restrict__ pts, const unsigned int* __restrict__ counts,
+                                                     unsigned int cap, const uint8_t* __restrict__ pyr, size_t pframe,
+                                                     OrientBatchGeom g, unsigned long long* __restrict__ flags, size_t fwords) {
+    const int f = blockIdx.y;
+    const unsigned int i = blockIdx.x * 256 + threadIdx.x;
+    bool keep = false;
+    if (i < min(counts[f], cap)) {
+        const vslam_point kp = pts[(size_t)f * cap + i];
+        const int o = kp.octave;
+        const uint8_t* G = pyr + f * pframe + g.oct_off[o] + (size_t)kp.level * g.rows[o] * g.pitch[o];
+        const float r = 10.0f, threshold = ((r + 1.0f) * (r + 1.0f)) / r;  // :331-332
+        keep = edge_response_u8(G, g.pitch[o], g.rows[o], g.cols[o], kp.row, kp.col, kp.padding) < threshold;  // :335
+    }
+    const unsigned long long w = __ballot(keep);
+    if ((threadIdx.x & 63) == 0 && (i >> 6) < fwords) flags[(size_t)f * fwords + (i >> 6)] = w;
+}
+
+// cv::magnitude / cv::phase of the level's Sobel gradients at one pixel (processGradients,
+// GaussPyramid.cpp:65-104), formed from the u8 Gaussian level like k_level_gradients does.
+__device__ __forceinline__ void gradient_at(const uint8_t* __restrict__ G, int gpitch, int rows, int cols, int r, int c, float& x, float& y) {
+    x = (float)((int)G[(size_t)r * gpitch + reflect101(c + 1, cols)] - (int)G[(size_t)r * gpitch + reflect101(c - 1, cols)]);
+    y = (float)((int)G[(size_t)reflect101(r + 1, rows) * gpitch + c] - (int)G[(size_t)reflect101(r - 1, rows) * gpitch + c]);
+}
+__device__ __forceinline__ float magnitude_at(const uint8_t* __restrict__ G, int gpitch, int rows, int cols, int r, int c) {
+    float x, y;
+    gradient_at(G, gpitch, rows, cols, r, c, x, y);
+    const float xx = x * x, yy = y * y;
+    return (float)sqrt((double)(xx + yy));  // correctly rounded f32 square root
+}
+
+// grid = (G, frames), 256 threads, dynamic LDS = lds_floats * 4 bytes (row / column maps + strip + region);
+// survivors of octaves outside [oct_lo, oct_hi) are left to the launch with the other LDS budget.
+__global__ __launch_bounds__(256) void k_orient_survivors(const vslam_point* __restrict__ pts, unsigned int cap,
+                                                           const unsigned int* __restrict__ surv, const unsigned int* __restrict__ scounts,
+                                                           unsigned int scap, const uint8_t* __restrict__ pyr, size_t pframe,
+                                                           OrientBatchGeom g, int lds_floats, int oct_lo, int oct_hi,
+                                                           unsigned long long* __restrict__ masks) {
+    extern __shared__ __attribute__((aligned(16))) float orient_smem[];
+    __shared__ float mw[OR_WIN * OR_WIN];
+    __shared__ uint8_t bin[OR_WIN * OR_WIN];
+    __shared__ float histo[OR_BINS];
+    const int f = blockIdx.y;
+    const unsigned int ns = min(scounts[f], scap);
+    for (unsigned int k = blockIdx.x; k < ns; k += gridDim.x) {
+        const vslam_point kp = pts[(size_t)f * cap + surv[(size_t)f * scap + k]];
+        const int o = kp.octave, level = kp.level, x = kp.col, y = kp.row;
+        if (o < oct_lo || o >= oct_hi) continue;  // this launch's LDS budget is for octaves [oct_lo, oct_hi): workgroup-uniform
+        const int rows = g.rows[o], cols = g.cols[o], gpitch = g.pitch[o];
+        const uint8_t* __restrict__ G = pyr + f * pframe + g.oct_off[o] + (size_t)level * rows * gpitch;
+        const int kn = g.kn[o][level], R = kn >> 1;
+        const float* __restrict__ kt = g.kern[o][level];
+        const int prows = rows + 2 * OR_PAD, pcols = cols + 2 * OR_PAD;
+        const int span = OR_WIN + 2 * R;
+        // LDS: [span] row map, [span] column map, [span][16] strip, then the magnitude region if it fits
+        int* ry = reinterpret_cast<int*>(orient_smem);
+        int* cx = ry + span;
+        float* rb = orient_smem + 2 * span;
+        float* M = rb + span * OR_WIN;
+        const bool region = 2 * span + span * OR_WIN + span * span <= lds_floats;
+        __syncthreads();  // the previous survivor's reads of the LDS are done
+        for (int i = threadIdx.x; i < span; i += 256) {
+            ry[i] = clampi(reflect101(y + i - R, prows) - OR_PAD, 0, rows - 1);  // parent reflect-101, then padOctave's replicate
+            cx[i] = clampi(reflect101(x + i - R, pcols) - OR_PAD, 0, cols - 1);
+        }
+        __syncthreads();
+        if (region) {
+            for (int it = threadIdx.x; it < span * span; it += 256) {
+                const int rr = it / span, cc = it - rr * span;
+                M[it] = magnitude_at(G, gpitch, rows, cols, ry[rr], cx[cc]);
+            }
+            __syncthreads();
+            for (int it = threadIdx.x; it < span * OR_WIN; it += 256) {
+                const int rr = it >> 4, c = it & 15;
+                const float* __restrict__ S = M + rr * span + c;
+                float s0 = kt[0] * S[0];
+                for (int i = 1; i < kn; ++i) s0 += kt[i] * S[i];
+                rb[it] = s0;
+            }
+        } else {
+            for (int it = threadIdx.x; it < span * OR_WIN; it += 256) {
+                const int rr = it >> 4, c = it & 15;
+                float s0 = kt[0] * magnitude_at(G, gpitch, rows, cols, ry[rr], cx[c]);
+                for (int i = 1; i < kn; ++i) s0 += kt[i] * magnitude_at(G, gpitch, rows, cols, ry[rr], cx[c + i]);
+                rb[it] = s0;
+            }
+        }
+        __syncthreads();
+        {
+            const int i = threadIdx.x >> 4, j = threadIdx.x & 15;
+            float s0 = kt[R] * rb[(i + R) * OR_WIN + j];
+            for (int t = 1; t <= R; ++t) s0 += kt[R + t] * (rb[(i + R + t) * OR_WIN + j] + rb[(i + R - t) * OR_WIN + j]);
+            mw[threadIdx.x] = s0;
+            float gx, gy;
+            gradient_at(G, gpitch, rows, cols, clampi(y + i - OR_PAD, 0, rows - 1), clampi(x + j - OR_PAD, 0, cols - 1), gx, gy);
+            const float reductionCoeff = (float)OR_BINS / 360.0f;            // :114
+            const int index = (int)(fast_atan2_deg(gy, gx) * reductionCoeff);  // :126
+            bin[threadIdx.x] = (uint8_t)min(max(index, 0), OR_BINS - 1);
+        }
+        __syncthreads();
+        if (threadIdx.x < OR_BINS) {  // one lane per bin, pixels in row-major order: the reference's += order
+            float h = 0.0f;
+            for (int p = 0; p < OR_WIN * OR_WIN; ++p)
+                if (bin[p] == threadIdx.x) h += mw[p];
+            histo[threadIdx.x] = h;
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            float mx = histo[0];
+            for (int b = 1; b < OR_BINS; ++b) mx = fmaxf(mx, histo[b]);
+            const float peakThreshold = mx * 0.8f;                                           // :358
+            const bool peak = threadIdx.x < OR_BINS && histo[threadIdx.x] > peakThreshold;  // :362
+            const unsigned long long m = __ballot(peak);
+            if (threadIdx.x == 0) masks[(size_t)f * scap + k] = m;
+        }
+    }
+}
+
+}  // namespace vslam

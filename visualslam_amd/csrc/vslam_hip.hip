@@ -19,6 +19,7 @@
 #include "kernels_aux.hip.h"
 #include "kernels_harris_strip.hip.h"
 #include "kernels_orient.hip.h"
+#include "kernels_orient_batch.hip.h"
 #include "kernels_compact.hip.h"
 #include "vslam_internal.h"
 
@@ -47,6 +48,7 @@ struct vslam_ctx {
     // kernels whose dynamic-LDS ceiling has been raised on this device (once, not per launch)
     std::set<const void*> lds_raised;
     float* loc_lut = nullptr;  // FeaturePointLocalization table (kernels_localize.hip.h), built on first use
+    std::map<std::pair<uint64_t, int>, float*> orient_taps;  // (sigma bits, kernel width) -> f32 Gaussian taps on the device
     // bench timing hook
     std::string timing_name;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timing_ev;
@@ -88,7 +90,7 @@ static int fail(vslam_ctx* c, int code, const std::string& msg) {
 static const char* const kKernelNames =
     "k_resize_linear2x\nk_blur_h_generic\nk_blur_v_generic\n"
     "k_dog5\nk_resize_nearest_half\nk_extrema\nk_pyr_octave\n"
-    "k_gauss_v_strip\nk_gauss_h_strip\nk_resize_linear2x_slide\nk_resize_nearest_half_v4\nk_extrema_w3\nk_localize_points\nk_points_localize_value\nk_orient_keypoints\nk_edge_response_windows\nk_level_gradients\nk_pack_rows\n"
+    "k_gauss_v_strip\nk_gauss_h_strip\nk_resize_linear2x_slide\nk_resize_nearest_half_v4\nk_extrema_w3\nk_localize_points\nk_points_localize_value\nk_orient_keypoints\nk_edge_response_windows\nk_level_gradients\nk_pack_rows\nk_edge_flags\nk_orient_survivors\n"
     "k_harris_strip\nk_flag_count\nk_chunk_scan\nk_flag_scatter\nk_level_gradients";
 
 static std::pair<hipEvent_t, hipEvent_t>* timing_slot(vslam_ctx* c);
@@ -688,6 +690,7 @@ int vslam_ctx_destroy(vslam_ctx* c) {
     if (c->ws) (void)hipFree(c->ws);
     for (auto& b : c->block_cache) (void)hipFree(b.second);
     if (c->loc_lut) (void)hipFree(c->loc_lut);
+    for (auto& kv : c->orient_taps) (void)hipFree(kv.second);
     for (int i = 0; i < 2; ++i) {
         if (c->aux[i]) (void)hipStreamDestroy(c->aux[i]);
         if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
@@ -1264,6 +1267,108 @@ int vslam_structure_matrix_windows(vslam_ctx* c, const float* gx_windows, const 
 
 // ------------------------------------------------------------- device-resident batched path
 
+// Device copy of getGaussianKernel(n, sigma, CV_32F) for the orientation blur, cached per context.
+static int get_orient_taps(vslam_ctx* c, double sigma, const float** out, int* n_out) {
+    const int n = gauss_ksize_f32(sigma);
+    uint64_t sb;
+    std::memcpy(&sb, &sigma, 8);
+    auto key = std::make_pair(sb, n);
+    auto it = c->orient_taps.find(key);
+    if (it == c->orient_taps.end()) {
+        std::vector<float> t;
+        if (!gauss_kernel_f32(n, sigma, t)) return fail(c, VSLAM_ERR_INVALID, "filterKeypoints: bad blur kernel");
+        float* d = nullptr;
+        HIPCHK(c, hipMalloc((void**)&d, 4 * t.size()));
+        HIPCHK(c, hipMemcpy(d, t.data(), 4 * t.size(), hipMemcpyHostToDevice));
+        it = c->orient_taps.emplace(key, d).first;
+    }
+    *out = it->second;
+    *n_out = n;
+    return VSLAM_OK;
+}
+
+struct OrientScratch {
+    unsigned long long* flags = nullptr;  // [nf][fwords] edge-test ballots
+    unsigned int* surv = nullptr;         // [nf][scap] surviving record indices
+    unsigned int* scounts = nullptr;      // [nf]
+    unsigned long long* masks = nullptr;  // [nf][scap] histogram-peak masks
+    unsigned int* cws = nullptr;          // compaction scratch
+    size_t fwords = 0;
+};
+static size_t orient_scratch_bytes(const vslam_params& p, int nf) {
+    const size_t fwords = ((size_t)p.dog_cap + 63) / 64, scap = p.oriented_cap;
+    return ws_need((size_t)nf * fwords * 8) + ws_need((size_t)nf * scap * 4) + ws_need((size_t)nf * 4) + ws_need((size_t)nf * scap * 8) +
+           ws_need(4 * compaction_ws_elems(std::max(fwords, scap), nf));
+}
+static int orient_scratch_take(vslam_ctx* c, const vslam_params& p, int nf, OrientScratch& s) {
+    s.fwords = ((size_t)p.dog_cap + 63) / 64;
+    const size_t scap = p.oriented_cap;
+    s.flags = ws_take<unsigned long long>(c, (size_t)nf * s.fwords);
+    s.surv = ws_take<unsigned int>(c, (size_t)nf * scap);
+    s.scounts = ws_take<unsigned int>(c, nf);
+    s.masks = ws_take<unsigned long long>(c, (size_t)nf * scap);
+    s.cws = ws_take<unsigned int>(c, compaction_ws_elems(std::max(s.fwords, scap), nf));
+    if (!s.flags || !s.surv || !s.scounts || !s.masks || !s.cws) return fail(c, VSLAM_ERR_NOMEM, "workspace sizing error (orient)");
+    return VSLAM_OK;
+}
+
+// filterKeypoints for the keypoint lists of nf frames (kernels_orient_batch.hip.h), on the
+// context's current stream; the lists must be complete on that stream.
+static int enqueue_orient_batch(vslam_ctx* c, const vslam_params& p, const vslam_batch_layout& L, int nf, const uint8_t* pyr,
+                                size_t pframe, const vslam_point* points, const unsigned int* counts, OrientScratch& s,
+                                vslam_point* oriented, unsigned int* oriented_counts) {
+    OrientBatchGeom g;
+    std::memset(&g, 0, sizeof(g));
+    g.n_oct = L.n_octaves;
+    int need_lo = 0, need_hi = 0;  // LDS floats for the octaves whose magnitude region fits beside 3-4 other workgroups / at all
+    constexpr int kSmallLds = 10 * 1024 + 512, kBigLds = 36 * 1024;  // floats: 42 KB, 144 KB
+    int split = L.n_octaves;       // first octave handled by the big-LDS launch
+    for (int o = 0; o < L.n_octaves; ++o) {
+        g.rows[o] = L.rows[o];
+        g.cols[o] = L.cols[o];
+        g.pitch[o] = L.pitch[o];
+        g.oct_off[o] = L.octave_offset[o];
+        int worst = 0;
+        for (int l = 1; l <= 3; ++l) {  // the levels initialKeypointDetection produces (Diff_of_Gauss.cpp:264)
+            TRY(get_orient_taps(c, 1.5 * sigma_at(p.sigma0, o, l), &g.kern[o][l], &g.kn[o][l]));  // :346
+            const int span = OR_WIN + 2 * (g.kn[o][l] / 2);
+            worst = std::max(worst, 2 * span + span * OR_WIN + span * span);
+        }
+        if (worst <= kSmallLds && split == L.n_octaves)
+            need_lo = std::max(need_lo, worst);
+        else {
+            split = std::min(split, o);
+            // regions that exceed even the big budget are read tap by tap; the strip and the maps still need room
+            int strip = 0;
+            for (int l = 1; l <= 3; ++l) strip = std::max(strip, (OR_WIN + 2 * (g.kn[o][l] / 2)) * (OR_WIN + 2));
+            need_hi = std::max(need_hi, std::min(std::max(worst, strip), std::max(kBigLds, strip)));
+        }
+    }
+    const size_t scap = p.oriented_cap;
+    const size_t fw = s.fwords;
+    LAUNCH(c, "k_edge_flags", k_edge_flags, dim3((unsigned)((fw * 64 + 255) / 256), nf), dim3(256), points, counts, p.dog_cap, pyr, pframe, g,
+           s.flags, fw);
+    SurvivorEntries se{s.flags, fw, s.surv};
+    TRY(enqueue_compaction(c, se, fw, nf, s.cws, (unsigned int)scap, s.scounts, 0));
+    TRY(raise_dyn_lds(c, reinterpret_cast<const void*>(&k_orient_survivors)));
+    const int gwg = (int)std::min<long>(1024, std::max<long>(16, 8192 / nf));
+    if (split > 0) {
+        TimedScope ts(c, "k_orient_survivors");
+        hipLaunchKernelGGL(k_orient_survivors, dim3(gwg, nf), dim3(256), (size_t)need_lo * 4, c->stream, points, p.dog_cap, s.surv, s.scounts,
+                           (unsigned int)scap, pyr, pframe, g, need_lo, 0, split, s.masks);
+    }
+    HIPCHK(c, hipGetLastError());
+    if (split < L.n_octaves) {
+        TimedScope ts(c, "k_orient_survivors");
+        hipLaunchKernelGGL(k_orient_survivors, dim3(gwg, nf), dim3(256), (size_t)need_hi * 4, c->stream, points, p.dog_cap, s.surv, s.scounts,
+                           (unsigned int)scap, pyr, pframe, g, need_hi, split, L.n_octaves, s.masks);
+    }
+    HIPCHK(c, hipGetLastError());
+    OrientBatchEntries oe{s.masks, s.surv, s.scounts, (unsigned int)scap, points, p.dog_cap, oriented};
+    TRY(enqueue_compaction(c, oe, scap, nf, s.cws, (unsigned int)scap, oriented_counts, 0));
+    return VSLAM_OK;
+}
+
 int vslam_detect_batch_dev(vslam_ctx* c, const vslam_params* pp, const uint8_t* d_frames, size_t frame_stride,
                            int n_frames, const vslam_batch_out* out) {
     TRY(bind_device(c));
@@ -1276,6 +1381,10 @@ int vslam_detect_batch_dev(vslam_ctx* c, const vslam_params* pp, const uint8_t* 
     const bool want_kps = out->harris_kps && out->harris_counts;
     const bool harris = p.do_harris && (out->response || out->nms_mask || out->nms2 || want_kps);
     ARGCHK(c, !dog || out->pyramid, "detect_batch: the DoG path needs out->pyramid");
+    const bool orient = dog && p.orient;
+    ARGCHK(c, !orient || (p.localize && out->dog_points && out->dog_counts && out->oriented_points && out->oriented_counts &&
+                          p.oriented_cap > 0 && p.dog_cap > 0 && p.extrema_window == 3),
+           "detect_batch: orient needs localize = 1, windowSize 3, the DoG point list and the oriented outputs");
     const size_t N = (size_t)p.rows * p.cols;
     // Whole-batch launches: every kernel sees all frames (grid.z = frames), so even the coarse
     // octaves fill the chip.  Scratch: octave bases (+ u16 row sums of the non-tiled octaves).
@@ -1285,9 +1394,12 @@ int vslam_detect_batch_dev(vslam_ctx* c, const vslam_params* pp, const uint8_t* 
     if (harris)
         need += (out->response ? 0 : ws_need((size_t)chunk * N * 4)) + ws_need((size_t)chunk * harris_flag_words(p.rows, p.cols) * 8) +
                 ws_need(4 * compaction_ws_elems(harris_flag_words(p.rows, p.cols), chunk));
+    if (orient) need += orient_scratch_bytes(p, chunk);
     TRY(ws_reserve(c, need));
     DogScratch s;
     if (dog) TRY(dog_scratch_take(c, L, p.sigma0, chunk, s));
+    OrientScratch os;
+    if (orient) TRY(orient_scratch_take(c, p, chunk, os));
     float* resp_ws = (harris && !out->response) ? ws_take<float>(c, (size_t)chunk * N) : nullptr;
     unsigned long long* hflags = harris ? ws_take<unsigned long long>(c, (size_t)chunk * harris_flag_words(p.rows, p.cols)) : nullptr;
     unsigned int* hcws = harris ? ws_take<unsigned int>(c, compaction_ws_elems(harris_flag_words(p.rows, p.cols), chunk)) : nullptr;
@@ -1327,6 +1439,12 @@ int vslam_detect_batch_dev(vslam_ctx* c, const vslam_params* pp, const uint8_t* 
                             out->extrema_bits ? (unsigned long long*)out->extrema_bits + (size_t)f0 * L.bits_frame_words : nullptr,
                             ext, out->dog_points ? out->dog_points + (size_t)f0 * p.dog_cap : nullptr,
                             out->dog_counts ? out->dog_counts + f0 : nullptr, sx));
+            if (orient) {  // filterKeypoints behind the list, on the stream that produced it
+                StreamSwap sw(c, sx ? sx : c->stream);
+                TRY(enqueue_orient_batch(c, p, L, nf, out->pyramid + (size_t)f0 * L.pyramid_frame_bytes, L.pyramid_frame_bytes,
+                                         out->dog_points + (size_t)f0 * p.dog_cap, out->dog_counts + f0, os,
+                                         out->oriented_points + (size_t)f0 * p.oriented_cap, out->oriented_counts + f0));
+            }
         }
     }
     if (use_aux)  // join

@@ -191,6 +191,8 @@ void vslam_params_default(vslam_params* p, int rows, int cols) {
     p->extrema_window = 3;   // Diff_of_Gauss.cpp:772
     p->min_contrast = 8;
     p->localize = 0;
+    p->orient = 0;
+    p->oriented_cap = 1u << 16;
     p->harris_cap = 1u << 18;
     p->dog_cap = 1u << 18;
 }
