@@ -300,7 +300,7 @@ def test_batch_random_shapes(env):
     ctx, torch = env
     rng = np.random.default_rng(20261003)
     shapes = set()
-    while len(shapes) < 14:
+    while len(shapes) < 18:
         r = int(rng.integers(2, 150))
         c = int(rng.integers(2, 300))
         if rng.random() < 0.6:
@@ -312,6 +312,7 @@ def test_batch_random_shapes(env):
             n_oct -= 1
         frames = synth.frames_np(2, rows, cols, stream_id=rows * 1000 + cols)
         frames[1] = synth.frame_np(rows, cols, kind="noise")
-        p, L, out = run_batch(ctx, torch, frames, n_octaves=n_oct)
+        mode = int(rng.integers(0, 3))  # plain candidate list / localized / localized + oriented
+        p, L, out = run_batch(ctx, torch, frames, n_octaves=n_oct, localize=int(mode >= 1), orient=int(mode == 2))
         for f in range(2):
             check_frame(p, L, out, f, frames[f], n_oct)
