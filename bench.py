@@ -145,13 +145,24 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # Rehearsal switches (not used by the driver): VSLAM_BENCH_BACKEND=gloo runs the collectives of
+    # the N > 1 path over gloo on host copies, VSLAM_BENCH_SHARE_GPU=1 puts every rank on cuda:0 -
+    # together they exercise the multi-rank code on a one-GPU box (RCCL refuses two ranks per GPU).
+    backend = os.environ.get("VSLAM_BENCH_BACKEND", "nccl")
+    if os.environ.get("VSLAM_BENCH_SHARE_GPU") == "1":
+        local_rank_dev = 0
+    else:
+        local_rank_dev = local_rank
+    torch.cuda.set_device(local_rank_dev)
+    dev = torch.device("cuda", local_rank_dev)
     use_dist = world > 1 or "RANK" in os.environ  # under torchrun even a single rank goes through RCCL
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     if args.gpus != world and rank == 0:
         print(f"note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
 
@@ -162,7 +173,7 @@ def main():
         dist.barrier()
     capi.build()
     rows, cols, n = args.rows, args.cols, args.frames
-    ctx = capi.Context(local_rank, torch.cuda.current_stream().cuda_stream)
+    ctx = capi.Context(local_rank_dev, torch.cuda.current_stream().cuda_stream)
     p = capi.default_params(rows, cols, n_octaves=args.octaves, localize=1 if args.orient else args.localize, orient=args.orient)
     L = capi.batch_layout(p)
 
@@ -181,14 +192,15 @@ def main():
     if args.orient:
         out["oriented_points"] = torch.empty((n, p.oriented_cap, 6), dtype=torch.int32, device=dev)
         out["oriented_counts"] = torch.zeros(n, dtype=torch.int32, device=dev)
+    cdev = dev if backend == "nccl" else torch.device("cpu")  # where the collectives' tensors live
     counts_local = torch.zeros(2, dtype=torch.int64, device=dev)
-    counts_all = torch.zeros((world, 2), dtype=torch.int64, device=dev)
+    counts_all = torch.zeros((world, 2), dtype=torch.int64, device=cdev)
 
     def step():
         ctx.detect_batch(p, frames, **out)
         counts_local[0] = out["harris_counts"].sum()
         counts_local[1] = out["dog_counts"].sum()
-        sharding.gather_counts(counts_local, counts_all)  # the one collective of the path: 16 B per rank over RCCL
+        sharding.gather_counts(counts_local.to(cdev), counts_all)  # the one collective of the path: 16 B per rank over RCCL
 
     def fence():
         torch.cuda.synchronize()
@@ -210,7 +222,7 @@ def main():
     launches, kms = ctx.kernel_timing_read()
     ctx.kernel_timing_enable(None)
 
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
     if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
