@@ -1,0 +1,37 @@
+"""bench.py's N > 1 path end to end on the one-GPU box: two ranks under torch.distributed.run share
+cuda:0 and exchange their keypoint counts over gloo (RCCL refuses two ranks on one GPU; the
+collective calls, the barrier / max-over-ranks timing and the rank-0 JSON line are the same)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_share_one_gpu():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, VSLAM_BENCH_BACKEND="gloo", VSLAM_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--frames", "4", "--rows", "240", "--cols", "320",
+           "--steps", "2", "--warmup", "1", "--cpu-sample", "0"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout  # rank 0 prints the one JSON line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    # both ranks' streams are counted: the per-step totals are the sum over two different streams
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--frames", "4", "--rows", "240", "--cols", "320", "--steps", "2",
+                          "--warmup", "1", "--cpu-sample", "0"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert one.returncode == 0, one.stderr[-2000:]
+    d1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][0])
+    assert d["keypoints_per_step"]["harris"] > d1["keypoints_per_step"]["harris"]
+    assert d["keypoints_per_step"]["dog"] > d1["keypoints_per_step"]["dog"]
