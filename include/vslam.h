@@ -106,7 +106,9 @@ int vslam_resize_linear2x_u8(vslam_ctx* ctx, const uint8_t* src, int rows, int c
 /* cv::resize(src, dst, Size(), 0.5, 0.5, INTER_NEAREST), GaussPyramid.cpp:126. */
 int vslam_resize_nearest_half_u8(vslam_ctx* ctx, const uint8_t* src, int rows, int cols, size_t step,
                                  uint8_t* dst, size_t dst_step);
-/* cv::convertScaleAbs(src f32, dst u8), Harris_corners.cpp:176,181.  Saturating. */
+/* cv::convertScaleAbs(src f32, dst u8), Harris_corners.cpp:176,181, as the reference's x86-64 OpenCV
+ * build evaluates it: round_half_even(|x|) saturated to 255 for |x| < 2^31; NaN and |x| >= 2^31 give 0
+ * (cvRound = cvtss2si / cvtps2dq returns INT_MIN there and saturate_cast<uchar> maps it to 0). */
 int vslam_convert_scale_abs_f32(vslam_ctx* ctx, const float* src, int rows, int cols, size_t step, uint8_t* dst,
                                 size_t dst_step);
 

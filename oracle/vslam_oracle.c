@@ -250,9 +250,16 @@ int vo_resize_nearest_half_u8(const uint8_t* src, int rows, int cols, size_t ste
     return 0;
 }
 
+/* saturate_cast<uchar>(cvRound(|x|)) as the x86-64 OpenCV build the reference runs on evaluates it
+ * (Harris_corners.cpp:176,181; README.md:29-31: Ubuntu 22.04 / GCC 11): cvRound is cvtss2si
+ * (scalar tail) / cvtps2dq (v_round in cvtabs_32f), round half even, and returns INT_MIN -- the
+ * "integer indefinite" value -- for NaN and for |x| >= 2^31; saturate_cast<uchar>(INT_MIN), like
+ * v_pack + v_pack_u_store of it, is 0.  So responses in [255.5, 2^31) read 255 in the 8-bit view and
+ * responses >= 2^31 read 0: literal reference behaviour (an AArch64 build would saturate). */
 static inline uint8_t cvt_abs_u8(float x) {
     float a = fabsf(x);
-    if (!(a < 255.5f)) return a != a ? 0 : 255; /* saturate; NaN -> 0 */
+    if (!(a < 2147483648.0f)) return 0; /* INT_MIN -> 0; NaN -> 0 */
+    if (a >= 255.5f) return 255;
     return (uint8_t)lrintf(a);
 }
 

@@ -69,7 +69,8 @@ void vo_half_size(int rows, int cols, int* out_rows, int* out_cols);
 int vo_resize_nearest_half_u8(const uint8_t* src, int rows, int cols, size_t step, uint8_t* dst,
                               size_t dst_step);
 
-/* A7: convertScaleAbs f32 -> u8: saturate(round_half_even(|x|)). */
+/* A7: convertScaleAbs f32 -> u8 as x86-64 OpenCV: round_half_even(|x|) saturated to 255 below 2^31;
+ * NaN and |x| >= 2^31 give 0 (cvRound returns INT_MIN there). */
 int vo_convert_scale_abs_f32(const float* src, int rows, int cols, size_t step_bytes, uint8_t* dst,
                              size_t dst_step);
 

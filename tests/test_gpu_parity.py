@@ -82,7 +82,7 @@ def test_sobel_resize_convert(ctx, shape):
 def test_convert_scale_abs(ctx):
     rng = np.random.default_rng(5)
     x = (rng.standard_normal((37, 53)) * 300).astype(np.float32)
-    x[0, :8] = [0.5, 1.5, 2.5, 253.5, 254.5, 255.5, 1e12, -1e12]
+    x[0, :14] = [0.5, 1.5, 2.5, 253.5, 254.5, 255.5, 1e12, -1e12, 2147483520.0, 2147483648.0, -2147483648.0, np.nan, np.inf, 1e9]
     assert same(ctx.convert_scale_abs(x), oracle.convert_scale_abs(x))
 
 

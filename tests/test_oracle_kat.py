@@ -131,8 +131,11 @@ def test_resize_nearest_half_sizes():
 
 
 def test_convert_scale_abs_rounding():
-    x = np.array([[0.5, 1.5, 2.5, -3.5, 253.5, 254.5, 255.4, 255.5, 1e12, -1e12, 253.49]], np.float32)
-    assert oracle.convert_scale_abs(x).tolist() == [[0, 2, 2, 4, 254, 254, 255, 255, 255, 255, 253]]
+    # x86-64 OpenCV: round half even, saturation to 255 below 2^31, and 0 from 2^31 on (cvRound returns
+    # INT_MIN there); 2147483520 is the largest f32 below 2^31
+    x = np.array([[0.5, 1.5, 2.5, -3.5, 253.5, 254.5, 255.4, 255.5, 1e12, -1e12, 253.49, 2147483520.0, 2147483648.0,
+                   -2147483648.0, np.nan, np.inf, 1e9]], np.float32)
+    assert oracle.convert_scale_abs(x).tolist() == [[0, 2, 2, 4, 254, 254, 255, 255, 0, 0, 253, 255, 0, 0, 0, 0, 255]]
 
 
 def test_pyramid_shape_known_answers():

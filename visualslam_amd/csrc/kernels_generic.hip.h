@@ -22,11 +22,13 @@ __device__ __forceinline__ int reflect101(int p, int len) {
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-// cv::convertScaleAbs element: saturate_cast<uchar>(round_half_even(|x|)), NaN -> 0.
+// cv::convertScaleAbs element as the reference's x86-64 OpenCV evaluates it: cvRound (cvtss2si /
+// cvtps2dq, round half even) returns INT_MIN for NaN and for |x| >= 2^31, which
+// saturate_cast<uchar> maps to 0; [255.5, 2^31) saturates to 255.
 __device__ __forceinline__ int cvt_abs_u8(float x) {
     const float a = fabsf(x);
-    if (!(a < 255.5f)) return a != a ? 0 : 255;
-    return __float2int_rn(a);
+    if (!(a < 2147483648.0f)) return 0;
+    return __float2int_rn(fminf(a, 255.0f));
 }
 
 // ---- GaussianBlur CV_8U, separable, exact integer -------------

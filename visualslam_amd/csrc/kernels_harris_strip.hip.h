@@ -23,8 +23,11 @@
 // Exactness: all pre-response quantities are integers (16-bit lanes for
 // the blur and the gradients, int32 for products and 3x3 sums < 2^24); det is formed exactly
 // with one v_fma_f64 and rounded once to f32; the three f32 ops of :57 stay separate
-// (-ffp-contract=off).  cvt(x) = round_half_even(min(x, 255)) is monotone, so the 8-bit NMS
-// compares cvt(centre) with cvt(max of neighbours).
+// (-ffp-contract=off).  The 8-bit view of convertScaleAbs (:176) is NOT monotone on x86-64 --
+// responses >= 2^31 read 0 (cvRound returns INT_MIN, kernels_generic.hip.h: cvt_abs_u8) -- so
+// every response is converted once and the 3x3 NonMaximumSuppression runs on the converted
+// values; NMS2 runs on the raw f32 response (:179) and its survivors are keypoints when their
+// 8-bit view exceeds 253 (:139,181), i.e. for 253.5 <= max < 2^31.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -48,7 +51,8 @@ __device__ __forceinline__ float from_right_f(float v) { return __uint_as_float(
 __device__ __forceinline__ uint32_t pk_sub_i16(uint32_t a, uint32_t b) {
     return __builtin_bit_cast(uint32_t, (s2_t)(__builtin_bit_cast(s2_t, a) - __builtin_bit_cast(s2_t, b)));
 }
-__device__ __forceinline__ float cvt8(float x) { return __builtin_rintf(fminf(x, 255.0f)); }
+// 8-bit view of a non-negative response, kept as a float (0..255): see cvt_abs_u8
+__device__ __forceinline__ float cvt8(float x) { return x < 2147483648.0f ? __builtin_rintf(fminf(x, 255.0f)) : 0.0f; }
 
 struct HarrisStripArgs {
     const uint8_t* img;
@@ -100,9 +104,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     uint32_t e1 = 0, o1 = 0, e2 = 0, o2 = 0;          // raw rows t-2, t-1 as 16-bit lanes (p0,p2)/(p1,p3)
     uint32_t be2 = 0, bo2 = 0, be1 = 0, bo1 = 0;      // blurred rows t-3, t-2
     int hsA[3][4] = {}, hsB[3][4] = {};               // horizontal product sums of rows t-4, t-3
-    float h3a[4] = {}, h3b[4] = {};                   // max3 rows y-1, y      (y = t-4)
+    float h3a[4] = {}, h3b[4] = {};                   // max3 of the 8-bit view, rows y-1, y      (y = t-4)
     float h4a[4] = {}, h4b[4] = {}, h4c[4] = {};      // max4 rows y-2, y-1, y
-    float Ry[4] = {}, nby[4] = {};                    // response row y and its horizontal neighbour max
+    float Ry[4] = {}, Cy[4] = {}, nby[4] = {};        // response row y, its 8-bit view and that view's horizontal neighbour max
 
     const int t_begin = y_begin - 5, t_end = y_end + 3;
     uint32_t nxt0 = load_row(t_begin), nxt1 = load_row(t_begin + 1);
@@ -186,15 +190,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             for (int k = 0; k < 4; ++k) hsA[c][k] = hsB[c][k], hsB[c][k] = hsC[c][k];
 
         // ---- horizontal maxima of row b ------------------------------------------------------------
-        float h3n[4], h4n[4], nbn[4];
+        float h3n[4], h4n[4], nbn[4], Cb[4];
         {
             const float lm2 = from_left_f(Rb[2]), lm1 = from_left_f(Rb[3]), rp4 = from_right_f(Rb[0]);
             const float ext[7] = {lm2, lm1, Rb[0], Rb[1], Rb[2], Rb[3], rp4};  // x-2 .. x+4
 #pragma unroll
+            for (int k = 0; k < 4; ++k) h4n[k] = fmaxf(fmaxf(ext[k + 1], ext[k + 3]), fmaxf(ext[k + 2], ext[k]));
+#pragma unroll
+            for (int k = 0; k < 4; ++k) Cb[k] = cvt8(Rb[k]);
+            const float cext[6] = {from_left_f(Cb[3]), Cb[0], Cb[1], Cb[2], Cb[3], from_right_f(Cb[0])};  // x-1 .. x+4
+#pragma unroll
             for (int k = 0; k < 4; ++k) {
-                nbn[k] = fmaxf(ext[k + 1], ext[k + 3]);
-                h3n[k] = fmaxf(nbn[k], ext[k + 2]);
-                h4n[k] = fmaxf(h3n[k], ext[k]);
+                nbn[k] = fmaxf(cext[k], cext[k + 2]);
+                h3n[k] = fmaxf(nbn[k], cext[k + 1]);
             }
         }
 
@@ -208,11 +216,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const float mx = fmaxf(fmaxf(h3a[k], h3n[k]), nby[k]);  // 8 neighbours
-                if (cvt8(Ry[k]) > cvt8(mx)) mword |= 0xffu << (8 * k);
+                if (Cy[k] > mx) mword |= 0xffu << (8 * k);
                 const float w4 = fmaxf(fmaxf(h4a[k], h4b[k]), fmaxf(h4c[k], h4n[k]));  // rows y-2..y+1, cols x-2..x+1
                 const bool pass = yin && inter[k] && Ry[k] >= w4;
                 n2[k] = pass ? w4 : 0.0f;
-                kpw[k] = __ballot(pass && w4 >= 253.5f);  // cvt(w4) > 253, Harris_corners.cpp:139
+                kpw[k] = __ballot(pass && w4 >= 253.5f && w4 < 2147483648.0f);  // cvt(w4) > 253, Harris_corners.cpp:139
             }
             if (lane_out) {
                 const size_t off = blockIdx.z * N + (size_t)y * cols + x0;
@@ -244,7 +252,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         for (int k = 0; k < 4; ++k) {
             h3a[k] = h3b[k], h3b[k] = h3n[k];
             h4a[k] = h4b[k], h4b[k] = h4c[k], h4c[k] = h4n[k];
-            Ry[k] = Rb[k], nby[k] = nbn[k];
+            Ry[k] = Rb[k], Cy[k] = Cb[k], nby[k] = nbn[k];
         }
     }
 }
