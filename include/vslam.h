@@ -66,8 +66,17 @@ typedef struct {
 int vslam_version(void);
 const char* vslam_status_string(int status);
 
-/* device: HIP device ordinal.  stream: an existing hipStream_t to launch on (e.g.
- * torch.cuda.current_stream().cuda_stream) or NULL to let the context own one. */
+/* device: HIP device ordinal.
+ * stream: the hipStream_t every call of this context is enqueued on:
+ *   - a stream handle of the caller: work is ordered with whatever else the caller enqueues there;
+ *   - VSLAM_STREAM_LEGACY (= hipStreamLegacy): the device's legacy NULL stream.  A caller whose own
+ *     work runs on the NULL stream (handle 0, e.g. torch's default stream) must pass THIS, not NULL;
+ *   - NULL: the context creates and owns a non-blocking stream.  It is NOT ordered against the NULL
+ *     stream or any other stream: device buffers handed to vslam_detect_batch_dev must be complete
+ *     before the call, and its results are complete only after vslam_ctx_sync.
+ * The batched path forks internal side streams from this stream and joins them back before it
+ * returns, so ordering on this stream covers all of its work. */
+#define VSLAM_STREAM_LEGACY ((void*)1)
 int vslam_ctx_create(int device, void* stream, vslam_ctx** out);
 int vslam_ctx_destroy(vslam_ctx* ctx);
 int vslam_ctx_sync(vslam_ctx* ctx);
@@ -280,7 +289,11 @@ typedef struct {
     uint32_t* dog_counts;    /* [n] totals (may exceed cap) */
     vslam_point* oriented_points; /* [n][oriented_cap] filterKeypoints output: {row, col, angle, 0, octave, level},
                                    * order (octave, keypoint, histogram bin); params.orient = 1 */
-    uint32_t* oriented_counts;    /* [n] totals (may exceed cap) */
+    uint32_t* oriented_counts;    /* [n] oriented points of the EVALUATED survivors (may exceed cap): the true total
+                                   * iff oriented_survivors[f] <= oriented_cap */
+    uint32_t* oriented_survivors; /* [n] optional: keypoints of the frame that pass the edge test (Diff_of_Gauss.cpp:336).
+                                   * Only the first oriented_cap of them (list order) get their histogram evaluated, so
+                                   * oriented_survivors[f] > oriented_cap flags a truncated frame */
 } vslam_batch_out;
 
 void vslam_params_default(vslam_params* p, int rows, int cols);

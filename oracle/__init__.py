@@ -109,8 +109,19 @@ def lib():
         L.vo_compute_edge_response.restype = C.c_float
         L.vo_filter_keypoints.argtypes = [C.POINTER(_Pyr), C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
         L.vo_filter_keypoints.restype = C.c_size_t
+        L.vo_baseline_frames.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_ulonglong)]
         _lib = L
     return _lib
+
+
+def baseline_frames(frames, n_octaves: int = 4, threads: int = 1) -> int:
+    """The whole hot path (Harris + NMS + keypoints + pyramid + extrema) on frames [n, rows, cols]
+    with `threads` OpenMP threads over frames; returns the keypoint total.  bench.py times this."""
+    frames = np.ascontiguousarray(frames, dtype=np.uint8)
+    assert frames.ndim == 3
+    kp = C.c_ulonglong(0)
+    _chk(lib().vo_baseline_frames(frames.ctypes.data, frames.shape[0], frames.shape[1], frames.shape[2], n_octaves, threads, C.byref(kp)), "baseline_frames")
+    return kp.value
 
 
 def gauss_ksize_f32(sigma):

@@ -854,3 +854,48 @@ size_t vo_dog_extrema(const vo_pyramid* p, int octave, int window, int min_contr
 #undef DP
     return n;
 }
+
+/* ------------------------------------------------------------------------- */
+/* CPU baseline driver                                                        */
+/* ------------------------------------------------------------------------- */
+
+int vo_baseline_frames(const uint8_t* frames, int n, int rows, int cols, int n_octaves, int threads,
+                       unsigned long long* keypoints) {
+    if (!frames || n <= 0 || rows <= 0 || cols <= 0 || threads <= 0) return -1;
+    unsigned long long total = 0;
+    int bad = 0;
+    const size_t N = (size_t)rows * cols;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads) reduction(+ : total) reduction(| : bad)
+    for (int f = 0; f < n; f++) {
+        const uint8_t* img = frames + (size_t)f * N;
+        float* R = (float*)malloc(sizeof(float) * N);
+        float* n2 = (float*)malloc(sizeof(float) * N);
+        uint8_t* u8 = (uint8_t*)malloc(N);
+        uint8_t* mask = (uint8_t*)malloc(N);
+        if (!R || !n2 || !u8 || !mask) {
+            bad |= 1;
+        } else {
+            float tm;
+            bad |= vo_harris_response_u8(img, rows, cols, (size_t)cols, 0.04f, 3, R, sizeof(float) * (size_t)cols) != 0;
+            bad |= vo_convert_scale_abs_f32(R, rows, cols, sizeof(float) * (size_t)cols, u8, (size_t)cols) != 0;
+            bad |= vo_nms_strict_u8(u8, rows, cols, (size_t)cols, 3, mask, (size_t)cols) != 0;
+            bad |= vo_nms2_f32(R, rows, cols, sizeof(float) * (size_t)cols, 5, n2, sizeof(float) * (size_t)cols, &tm) != 0;
+            total += vo_harris_keypoints(n2, rows, cols, sizeof(float) * (size_t)cols, NULL, 0);
+            if (n_octaves > 0) {
+                vo_pyramid* p = vo_pyramid_build_u8(img, rows, cols, (size_t)cols, n_octaves, 1.6);
+                if (!p) {
+                    bad |= 1;
+                } else {
+                    for (int o = 0; o < p->n_octaves; o++) total += vo_dog_extrema(p, o, 3, 8, NULL, NULL, 0);
+                    vo_pyramid_free(p);
+                }
+            }
+        }
+        free(R);
+        free(n2);
+        free(u8);
+        free(mask);
+    }
+    if (keypoints) *keypoints = total;
+    return bad ? -1 : 0;
+}

@@ -164,6 +164,14 @@ int vo_feature_point_localization(int d_x, int d_y, int d_scale, int value, int*
  * the keypoints the reference appends, in its loop order.  Returns the total; writes <= cap. */
 size_t vo_dog_keypoints(const vo_pyramid* p, int octave, int window, vo_point* out, size_t cap);
 
+/* CPU baseline driver (bench.py's cpu_baseline leg): the whole hot path of BASELINE config 4 --
+ * Harris response, both NMS variants, keypoint list, GaussPyramid(img, n_octaves, 1.6), extrema
+ * candidates with value >= 8 -- on n dense frames, `threads` OpenMP threads over frames (the
+ * reference itself is single-threaded: threads = 1 is its figure).  Returns the keypoint
+ * total (Harris + DoG) in *keypoints; 0 on success. */
+int vo_baseline_frames(const uint8_t* frames, int n, int rows, int cols, int n_octaves, int threads,
+                       unsigned long long* keypoints);
+
 #ifdef __cplusplus
 }
 #endif

@@ -40,6 +40,7 @@ def run_batch(ctx, torch, frames_np, with_nms2=True, **pkw):
     if p.orient:
         o["oriented_points"] = torch.zeros((n, p.oriented_cap, 6), dtype=torch.int32, device=dev)
         o["oriented_counts"] = torch.zeros(n, dtype=torch.int32, device=dev)
+        o["oriented_survivors"] = torch.full((n,), -1, dtype=torch.int32, device=dev)
     ctx.detect_batch(p, frames, **o)
     torch.cuda.synchronize()
     return p, L, {k: (v.cpu().numpy() if v is not None else None) for k, v in o.items()}
@@ -86,6 +87,10 @@ def check_frame(p, L, out, f, img, n_oct):
     assert got.tobytes() == allp[:m].tobytes()
     if p.orient:  # filterKeypoints per octave, concatenated in octave order
         wo = np.concatenate([want.filter_keypoints(o, all_pts[o]) for o in range(n_oct)])
+        # survivors of the edge test = keypoints with at least one oriented point (every survivor has a peak)
+        n_surv = len({(int(q["octave"]), int(q["level"]), int(q["row"]), int(q["col"])) for q in wo})
+        assert out["oriented_survivors"][f] == n_surv, (f, int(out["oriented_survivors"][f]), n_surv)
+        assert n_surv <= p.oriented_cap, "check_frame compares whole lists: raise oriented_cap"
         assert out["oriented_counts"][f] == len(wo), (f, int(out["oriented_counts"][f]), len(wo))
         mo = min(len(wo), p.oriented_cap)
         goo = out["oriented_points"][f][:mo].copy().view(capi.POINT_DTYPE).reshape(-1)
@@ -148,9 +153,22 @@ def test_batch_oriented_keypoints(env, shape, n_oct):
     assert out["oriented_counts"].sum() > 0
     for f in range(4):
         check_frame(p, L, out, f, frames[f], n_oct)
-    # a tight survivor / output capacity truncates the lists but keeps the totals of what was processed
+    # overflow on purpose: with oriented_cap = 8 only the first 8 edge-test survivors are evaluated.  The
+    # contract (include/vslam.h): oriented_survivors still reports the true survivor count, which is how
+    # the caller sees the truncation; oriented_counts then covers the evaluated survivors only.
     p2, L2, out2 = run_batch(ctx, torch, frames[1:2], n_octaves=n_oct, localize=1, orient=1, oriented_cap=8)
     assert (out2["oriented_points"][0][:8] == out["oriented_points"][1][:8]).all()
+    assert out2["oriented_survivors"][0] == out["oriented_survivors"][1] > 8
+    full = out["oriented_points"][1][: out["oriented_counts"][1]].copy().view(capi.POINT_DTYPE).reshape(-1)
+    first8 = []
+    for q in full:  # oriented points of the first 8 distinct keypoints, in list order
+        key = (int(q["octave"]), int(q["level"]), int(q["row"]), int(q["col"]))
+        if key not in first8:
+            if len(first8) == 8:
+                break
+            first8.append(key)
+    n8 = sum((int(q["octave"]), int(q["level"]), int(q["row"]), int(q["col"])) in first8 for q in full)
+    assert out2["oriented_counts"][0] == n8 < out["oriented_counts"][1]
 
 
 def test_config1_640x480_plumbing(env):
@@ -316,3 +334,104 @@ def test_batch_random_shapes(env):
         p, L, out = run_batch(ctx, torch, frames, n_octaves=n_oct, localize=int(mode >= 1), orient=int(mode == 2))
         for f in range(2):
             check_frame(p, L, out, f, frames[f], n_oct)
+
+
+def test_results_are_ordered_by_the_stream_alone():
+    # the context must launch on the stream the caller works on.  Inputs are produced and
+    # counts are read with stream ordering only (no device-wide synchronize before the read): once on
+    # torch's default stream (handle 0 -> the legacy NULL stream) and once on a side stream.
+    import torch
+
+    capi.build()
+    rows, cols, n = 270, 480, 24
+    frames_np = synth.frames_np(n, rows, cols, stream_id=21)
+    want_h, want_d = [], []
+    for f in (0, n - 1):
+        R = oracle.harris_response(frames_np[f])
+        want_h.append(len(oracle.harris_keypoints(oracle.nms2(R, 5)[0])))
+        w = oracle.Pyramid(frames_np[f], 4, 1.6)
+        want_d.append(sum(len(w.extrema(o, 3, 8)[1]) for o in range(4)))
+        w.close()
+    side = torch.cuda.Stream()
+    for st in (torch.cuda.default_stream(), side):
+        with torch.cuda.stream(st):
+            ctx = capi.Context(0, torch.cuda.current_stream().cuda_stream)
+            p = capi.default_params(rows, cols)
+            L = capi.batch_layout(p)
+            dev = "cuda:0"
+            host = torch.from_numpy(frames_np).pin_memory()
+            for rep in range(3):
+                frames = host.to(dev, non_blocking=True)  # enqueued on `st`, not waited for
+                o = dict(
+                    response=torch.empty((n, rows, cols), dtype=torch.float32, device=dev),
+                    harris_kps=torch.empty((n, p.harris_cap, 3), dtype=torch.int32, device=dev),
+                    harris_counts=torch.full((n,), -7, dtype=torch.int32, device=dev),
+                    pyramid=torch.empty((n, L.pyramid_frame_bytes), dtype=torch.uint8, device=dev),
+                    dog_points=torch.empty((n, p.dog_cap, 6), dtype=torch.int32, device=dev),
+                    dog_counts=torch.full((n,), -7, dtype=torch.int32, device=dev),
+                )
+                ctx.detect_batch(p, frames, **o)
+                hc = o["harris_counts"].to("cpu", non_blocking=True)
+                dc = o["dog_counts"].to("cpu", non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(st)
+                ev.synchronize()  # waits for `st` only
+                assert [int(hc[0]), int(hc[-1])] == want_h, (st, rep, hc.tolist())
+                assert [int(dc[0]), int(dc[-1])] == want_d, (st, rep, dc.tolist())
+            st.synchronize()
+            ctx.close()
+
+
+def test_config4_full_batch_256_frames_1080p(env):
+    # BASELINE config 4 at its full size under -m gpu (not only inside bench.py): 256 x 1080p through
+    # one vslam_detect_batch_dev call.  No oracle run per frame -- size-independent properties:
+    # the batch holds 3 distinct frames (two synthetic streams and a constant one) replicated in an
+    # irregular pattern, replicas must agree bit for bit with their first occurrence (lists included),
+    # the first occurrences of frame 0 equal the oracle, and the constant frame has every one of its
+    # 3,672,000 lattice sites as a candidate and empty lists.
+    ctx, torch = env
+    n = 256
+    base = synth.frames_np(2, 1080, 1920, stream_id=4)
+    kind = np.array([(7 * i + i // 5) % 3 for i in range(n)])
+    kind[:3] = [0, 1, 2]
+    dev = "cuda:0"
+    src = torch.from_numpy(np.stack([base[0], base[1], np.full((1080, 1920), 128, np.uint8)])).to(dev)
+    frames = src[torch.from_numpy(kind).to(dev)].contiguous()
+    p = capi.default_params(1080, 1920)
+    L = capi.batch_layout(p)
+    o = dict(
+        response=torch.empty((n, 1080, 1920), dtype=torch.float32, device=dev),
+        nms_mask=torch.empty((n, 1080, 1920), dtype=torch.uint8, device=dev),
+        harris_kps=torch.zeros((n, p.harris_cap, 3), dtype=torch.int32, device=dev),
+        harris_counts=torch.zeros(n, dtype=torch.int32, device=dev),
+        pyramid=torch.empty((n, L.pyramid_frame_bytes), dtype=torch.uint8, device=dev),
+        extrema_bits=torch.zeros((n, L.bits_frame_words), dtype=torch.int64, device=dev),
+        dog_points=torch.zeros((n, p.dog_cap, 6), dtype=torch.int32, device=dev),
+        dog_counts=torch.zeros(n, dtype=torch.int32, device=dev),
+    )
+    ctx.detect_batch(p, frames, **o)
+    torch.cuda.synchronize()
+    hc, dc = o["harris_counts"].cpu().numpy(), o["dog_counts"].cpu().numpy()
+    assert (hc <= p.harris_cap).all() and (dc <= p.dog_cap).all()
+    for k in ("response", "nms_mask", "pyramid", "extrema_bits"):
+        for i in range(3, n):  # device-side compares: the 31 GB of pyramids stay in HBM
+            assert torch.equal(o[k][i], o[k][int(kind[i])]), (k, i)  # frames 0, 1, 2 are the first occurrences
+    assert (hc == hc[kind]).all() and (dc == dc[kind]).all()
+    for k, cnt in (("harris_kps", hc), ("dog_points", dc)):
+        for i in (3, 100, 255):
+            m = int(cnt[i])
+            assert bool((o[k][i][:m] == o[k][int(kind[i])][:m]).all()), (k, i)
+    # frame 0 against the oracle: lists and counts (images are covered by the one-frame tests)
+    R = oracle.harris_response(base[0])
+    kps = oracle.harris_keypoints(oracle.nms2(R, 5)[0])
+    assert hc[0] == len(kps)
+    assert o["harris_kps"][0][: len(kps)].cpu().numpy().view(capi.KP_DTYPE).reshape(-1).tobytes() == kps.tobytes()
+    want = oracle.Pyramid(base[0], 4, 1.6)
+    allp = np.concatenate([want.extrema(oc, 3, 8)[1] for oc in range(4)])
+    want.close()
+    assert dc[0] == len(allp)
+    assert o["dog_points"][0][: len(allp)].cpu().numpy().view(capi.POINT_DTYPE).reshape(-1).tobytes() == allp.tobytes()
+    # the constant frame
+    assert hc[2] == 0 and dc[2] == 0 and not bool(o["response"][2].any()) and not bool(o["nms_mask"][2].any())
+    bits = o["extrema_bits"][2].cpu().numpy().view(np.uint64)
+    assert int(np.unpackbits(bits.view(np.uint8)).sum()) == 3_672_000

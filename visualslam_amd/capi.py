@@ -60,7 +60,7 @@ class BatchOut(C.Structure):
         ("harris_kps", C.c_void_p), ("harris_counts", C.c_void_p),
         ("pyramid", C.c_void_p), ("extrema_bits", C.c_void_p),
         ("dog_points", C.c_void_p), ("dog_counts", C.c_void_p),
-        ("oriented_points", C.c_void_p), ("oriented_counts", C.c_void_p),
+        ("oriented_points", C.c_void_p), ("oriented_counts", C.c_void_p), ("oriented_survivors", C.c_void_p),
     ]
 
 
@@ -227,12 +227,25 @@ def _f32(a):
     return a
 
 
+STREAM_LEGACY = 1  # VSLAM_STREAM_LEGACY == hipStreamLegacy: the device's NULL stream
+
+
 class Context:
-    """One vslam_ctx: one GPU, one HIP stream."""
+    """One vslam_ctx: one GPU, one HIP stream.
+
+    stream: None -> the context owns a private non-blocking stream (results are complete after
+    ``sync()``; nothing orders it against torch's streams).  An integer is a hipStream_t handle, e.g.
+    ``torch.cuda.current_stream().cuda_stream``; torch's default stream has handle 0, which is passed
+    on as the legacy NULL stream (VSLAM_STREAM_LEGACY) -- NOT as "no stream" -- so that tensors made
+    and read on that stream are ordered with the kernels by the stream itself."""
 
     def __init__(self, device: int = 0, stream: int | None = None):
         h = C.c_void_p()
-        rc = lib().vslam_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(h))
+        if stream is None:
+            sp = None
+        else:
+            sp = C.c_void_p(int(stream) or STREAM_LEGACY)
+        rc = lib().vslam_ctx_create(device, sp, C.byref(h))
         if rc:
             raise VslamError(rc, "vslam_ctx_create", "no usable HIP device" if rc == -2 else "")
         self._h = h
@@ -369,10 +382,45 @@ class Context:
     # ---- device-resident batch (torch CUDA tensors)
     def detect_batch(self, params: Params, frames, **outs):
         """frames: uint8 CUDA tensor [n, rows, cols]; outs: CUDA tensors by BatchOut field name."""
+        import torch
+
         n = frames.shape[0]
+        L = batch_layout(params)  # raises on bad parameters before anything is checked against them
+        N = params.rows * params.cols
+
+        def need(name, t, dtype, numel):
+            # the C ABI carries no buffer sizes: an undersized or mis-typed tensor would be a silent
+            # out-of-bounds device write, so it is refused here
+            if not (t.is_cuda and t.device.index == self.device):
+                raise ValueError(f"detect_batch: {name} is not on cuda:{self.device}")
+            if t.dtype not in dtype:
+                raise ValueError(f"detect_batch: {name} has dtype {t.dtype}, expected one of {dtype}")
+            if not t.is_contiguous():
+                raise ValueError(f"detect_batch: {name} is not contiguous")
+            if t.numel() * t.element_size() < numel:
+                raise ValueError(f"detect_batch: {name} holds {t.numel() * t.element_size()} bytes, needs {numel}")
+
+        if frames.dim() != 3 or tuple(frames.shape[1:]) != (params.rows, params.cols) or frames.stride(2) != 1 or frames.stride(1) != params.cols:
+            raise ValueError("detect_batch: frames must be [n, rows, cols] uint8 with dense rows")
+        if not (frames.is_cuda and frames.device.index == self.device and frames.dtype == torch.uint8):
+            raise ValueError(f"detect_batch: frames must be uint8 on cuda:{self.device}")
+        if n > 1 and frames.stride(0) < N:
+            raise ValueError("detect_batch: frames overlap")
+        i32, u8, f32, i64 = (torch.int32,), (torch.uint8,), (torch.float32,), (torch.int64, torch.uint64)
+        spec = {
+            "response": (f32, 4 * n * N), "nms_mask": (u8, n * N), "nms2": (f32, 4 * n * N),
+            "harris_kps": (i32 + f32, 12 * n * params.harris_cap), "harris_counts": (i32, 4 * n),
+            "pyramid": (u8, n * L.pyramid_frame_bytes), "extrema_bits": (i64, 8 * n * L.bits_frame_words),
+            "dog_points": (i32, 24 * n * params.dog_cap), "dog_counts": (i32, 4 * n),
+            "oriented_points": (i32, 24 * n * params.oriented_cap), "oriented_counts": (i32, 4 * n),
+            "oriented_survivors": (i32, 4 * n),
+        }
         bo = BatchOut()
         for k, t in outs.items():
             if t is not None:
+                if k not in spec:
+                    raise ValueError(f"detect_batch: unknown output {k!r}")
+                need(k, t, *spec[k])
                 setattr(bo, k, t.data_ptr())
         self._chk(lib().vslam_detect_batch_dev(self._h, C.byref(params), frames.data_ptr(), frames.stride(0), n, C.byref(bo)), "vslam_detect_batch_dev")
 

@@ -1,7 +1,11 @@
 // Deterministic ordered compaction of ballot flag words into keypoint lists, any batch size:
 //   k_flag_count   : one 256-thread block per chunk of 256 flag entries -> chunk totals
 //   k_chunk_scan   : one block per frame: exclusive scan of its chunk totals, frame total
-//   k_flag_scatter : per chunk again: in-block exclusive scan (wave shuffles + LDS) and emission
+//   k_flag_scatter : per chunk again: in-block exclusive scan (wave shuffles + LDS), then every
+//                    non-empty entry is emitted by a whole wave - lane b owns bit b of the entry's
+//                    words, its list position is the entry's offset plus the popcount of the lower
+//                    bits (v_mbcnt-style), so the records of one entry leave as one coalesced burst
+//                    instead of one thread walking its bits while 63 lanes idle
 // List order = entry order, and inside an entry ascending bit order, which is the reference's
 // loop order (row-major pixels for Harris; octave, level, i, j for the DoG lattice).  Three
 // short launches instead of one serial workgroup per frame: a single 1080p frame compacts in
@@ -31,26 +35,26 @@ struct HarrisStripEntries {  // entry = (row, strip): 4 ballot words (pixel slot
         for (int k = 0; k < 4; ++k) w[k] = F[k];
         return __popcll(w[0]) + __popcll(w[1]) + __popcll(w[2]) + __popcll(w[3]);
     }
-    __device__ void emit(int f, size_t e, const unsigned long long (&w)[4], unsigned int pos, unsigned int cap) const {
+    // whole wave, uniform (f, e, w, pos): lane l owns pixel slots k = 0..3 of its dword; records in
+    // (lane, k) order = ascending columns
+    __device__ void emit_wave(int f, size_t e, const unsigned long long (&w)[4], unsigned int pos, unsigned int cap, int lane) const {
         const int r = (int)(e / nstrips), strip = (int)(e % nstrips);
-        unsigned long long m = w[0] | w[1] | w[2] | w[3];
-        while (m) {
-            const int l = __ffsll((long long)m) - 1;
-            m &= m - 1;
+        const unsigned long long below = (1ull << lane) - 1ull;
+        pos += __popcll(w[0] & below) + __popcll(w[1] & below) + __popcll(w[2] & below) + __popcll(w[3] & below);
+        const int c0 = strip * HS_STRIP_W + 4 * (lane - 2);
+        const float* rp = resp + f * rframe + (size_t)r * cols + c0;
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if ((w[k] >> l) & 1ull) {
-                    if (pos < cap) {
-                        const int c = strip * HS_STRIP_W + 4 * (l - 2) + k;
-                        vslam_kp kp;
-                        kp.row = r;
-                        kp.col = c;
-                        kp.response = resp[f * rframe + (size_t)r * cols + c];
-                        out[(size_t)f * cap + pos] = kp;
-                    }
-                    ++pos;
+        for (int k = 0; k < 4; ++k)
+            if ((w[k] >> lane) & 1ull) {
+                if (pos < cap) {
+                    vslam_kp kp;
+                    kp.row = r;
+                    kp.col = c0 + k;
+                    kp.response = rp[k];
+                    out[(size_t)f * cap + pos] = kp;
                 }
-        }
+                ++pos;
+            }
     }
 };
 
@@ -70,7 +74,7 @@ struct DogEntries {  // entry = one 64-site word of the (octave, level, lattice 
         w[0] = lflags[f * bframe + first() + e];
         return __popcll(w[0]);
     }
-    __device__ void emit(int f, size_t e, const unsigned long long (&w)[4], unsigned int pos, unsigned int cap) const {
+    __device__ void emit_wave(int f, size_t e, const unsigned long long (&w)[4], unsigned int pos, unsigned int cap, int lane) const {
         const size_t wi = first() + e;
         int o = o_begin;
         while (o + 1 < o_end && wi >= g.bits_off[o + 1]) ++o;
@@ -80,23 +84,18 @@ struct DogEntries {  // entry = one 64-site word of the (octave, level, lattice 
         const int li = (int)((wl / wpr) % lr), lj0 = (int)(wl % wpr) * 64;
         const size_t P = (size_t)g.rows[o] * g.pitch[o];
         const uint8_t* dog = pyr + f * pframe + g.oct_off[o] + (size_t)VSLAM_NUM_LEVELS * P;
-        unsigned long long m = w[0];
-        while (m) {
-            const int b = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            if (pos < cap) {
-                const int i = g.pad + li * g.window, j = g.pad + (lj0 + b) * g.window;
-                vslam_point pt;
-                pt.row = i;
-                pt.col = j;
-                pt.value = dog[(size_t)level * P + (size_t)(i - g.pad) * g.pitch[o] + (j - g.pad)];
-                pt.padding = g.pad;
-                pt.octave = o;
-                pt.level = level;
-                out[(size_t)f * cap + pos] = pt;
-            }
-            ++pos;
-        }
+        if (!((w[0] >> lane) & 1ull)) return;
+        pos += __popcll(w[0] & ((1ull << lane) - 1ull));
+        if (pos >= cap) return;
+        const int i = g.pad + li * g.window, j = g.pad + (lj0 + lane) * g.window;
+        vslam_point pt;
+        pt.row = i;
+        pt.col = j;
+        pt.value = dog[(size_t)level * P + (size_t)(i - g.pad) * g.pitch[o] + (j - g.pad)];
+        pt.padding = g.pad;
+        pt.octave = o;
+        pt.level = level;
+        out[(size_t)f * cap + pos] = pt;
     }
 };
 
@@ -110,24 +109,19 @@ struct OrientEntries {  // entry = one keypoint of filterKeypoints: 36-bit mask 
         w[0] = masks[e];
         return __popcll(w[0]);
     }
-    __device__ void emit(int, size_t e, const unsigned long long (&w)[4], unsigned int pos, unsigned int cap) const {
+    __device__ void emit_wave(int, size_t e, const unsigned long long (&w)[4], unsigned int pos, unsigned int cap, int lane) const {
+        if (!((w[0] >> lane) & 1ull)) return;
+        pos += __popcll(w[0] & ((1ull << lane) - 1ull));
+        if (pos >= cap) return;
         const vslam_point kp = kps[e];
-        unsigned long long m = w[0];
-        while (m) {
-            const int b = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            if (pos < cap) {  // SLAM::point{y, x, angle, 0, octave, level}, Diff_of_Gauss.cpp:365
-                vslam_point pt;
-                pt.row = kp.row;
-                pt.col = kp.col;
-                pt.value = b * 10;
-                pt.padding = 0;
-                pt.octave = kp.octave;
-                pt.level = kp.level;
-                out[pos] = pt;
-            }
-            ++pos;
-        }
+        vslam_point pt;  // SLAM::point{y, x, angle, 0, octave, level}, Diff_of_Gauss.cpp:365
+        pt.row = kp.row;
+        pt.col = kp.col;
+        pt.value = lane * 10;
+        pt.padding = 0;
+        pt.octave = kp.octave;
+        pt.level = kp.level;
+        out[pos] = pt;
     }
 };
 
@@ -140,14 +134,10 @@ struct SurvivorEntries {  // entry = 64 consecutive list records of a frame: bit
         w[0] = flags[f * fwords + e];
         return __popcll(w[0]);
     }
-    __device__ void emit(int f, size_t e, const unsigned long long (&w)[4], unsigned int pos, unsigned int cap) const {
-        unsigned long long m = w[0];
-        while (m) {
-            const int b = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            if (pos < cap) surv[(size_t)f * cap + pos] = (unsigned int)(e * 64 + b);
-            ++pos;
-        }
+    __device__ void emit_wave(int f, size_t e, const unsigned long long (&w)[4], unsigned int pos, unsigned int cap, int lane) const {
+        if (!((w[0] >> lane) & 1ull)) return;
+        pos += __popcll(w[0] & ((1ull << lane) - 1ull));
+        if (pos < cap) surv[(size_t)f * cap + pos] = (unsigned int)(e * 64 + lane);
     }
 };
 
@@ -164,24 +154,19 @@ struct OrientBatchEntries {  // entry = one survivor of a frame: 36-bit mask of 
         w[0] = e < min(scounts[f], scap) ? masks[(size_t)f * scap + e] : 0ull;
         return __popcll(w[0]);
     }
-    __device__ void emit(int f, size_t e, const unsigned long long (&w)[4], unsigned int pos, unsigned int cap) const {
+    __device__ void emit_wave(int f, size_t e, const unsigned long long (&w)[4], unsigned int pos, unsigned int cap, int lane) const {
+        if (!((w[0] >> lane) & 1ull)) return;
+        pos += __popcll(w[0] & ((1ull << lane) - 1ull));
+        if (pos >= cap) return;
         const vslam_point kp = pts[(size_t)f * pcap + surv[(size_t)f * scap + e]];
-        unsigned long long m = w[0];
-        while (m) {
-            const int b = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            if (pos < cap) {  // SLAM::point{y, x, angle, 0, octave, level}, Diff_of_Gauss.cpp:365
-                vslam_point pt;
-                pt.row = kp.row;
-                pt.col = kp.col;
-                pt.value = b * 10;
-                pt.padding = 0;
-                pt.octave = kp.octave;
-                pt.level = kp.level;
-                out[(size_t)f * cap + pos] = pt;
-            }
-            ++pos;
-        }
+        vslam_point pt;  // SLAM::point{y, x, angle, 0, octave, level}, Diff_of_Gauss.cpp:365
+        pt.row = kp.row;
+        pt.col = kp.col;
+        pt.value = lane * 10;
+        pt.padding = 0;
+        pt.octave = kp.octave;
+        pt.level = kp.level;
+        out[(size_t)f * cap + pos] = pt;
     }
 };
 
@@ -259,18 +244,38 @@ __global__ __launch_bounds__(256) void k_chunk_scan(unsigned int* __restrict__ c
     if (threadIdx.x == 0) counts[f] = running;
 }
 
-// grid = (chunks, 1, frames)
+__device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v, int src_lane) {
+    const unsigned int lo = __builtin_amdgcn_readlane((unsigned int)v, src_lane);
+    const unsigned int hi = __builtin_amdgcn_readlane((unsigned int)(v >> 32), src_lane);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// grid = (chunks, 1, frames).  Thread t of the block first plays entry t (count, exclusive offset);
+// then each wave walks the non-empty entries of its own 64 lanes: the entry's words and offset are
+// broadcast from the owning lane (v_readlane, the index is scalar) and all 64 lanes emit together.
 template <class E>
 __global__ __launch_bounds__(256) void k_flag_scatter(const E ent, const unsigned int* __restrict__ chunk_off, int nchunks,
                                                        unsigned int cap) {
     __shared__ unsigned int wsum[4];
     const int f = blockIdx.z;
+    const int lane = threadIdx.x & 63;
     const size_t e = (size_t)blockIdx.x * CMP_CHUNK + threadIdx.x;
     unsigned long long w[4] = {0, 0, 0, 0};
     const unsigned int cnt = e < ent.count() ? ent.load(f, e, w) : 0u;
     unsigned int total;
-    const unsigned int ex = block_excl_scan_256(cnt, wsum, total);
-    if (cnt) ent.emit(f, e, w, chunk_off[(size_t)f * nchunks + blockIdx.x] + ex, cap);
+    const unsigned int ex = block_excl_scan_256(cnt, wsum, total) + chunk_off[(size_t)f * nchunks + blockIdx.x];
+    unsigned long long todo = __ballot(cnt != 0);
+    const size_t e0 = e - lane;
+    while (todo) {  // wave-uniform
+        const int i = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        unsigned long long wi[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) wi[k] = readlane_u64(w[k], i);
+        const unsigned int pos = __builtin_amdgcn_readlane(ex, i);
+        if (pos >= cap) break;  // offsets ascend: nothing further fits
+        ent.emit_wave(f, e0 + i, wi, pos, cap, lane);
+    }
 }
 
 }  // namespace vslam

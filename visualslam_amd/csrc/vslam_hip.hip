@@ -196,6 +196,8 @@ static int ws_reserve(vslam_ctx* c, size_t bytes) {
     c->ws_off = 0;
     if (bytes <= c->ws_cap) return VSLAM_OK;
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 2; ++i)
+        if (c->aux[i]) HIPCHK(c, hipStreamSynchronize(c->aux[i]));
     if (c->ws) (void)hipFree(c->ws);
     c->ws = nullptr;
     c->ws_cap = 0;
@@ -399,8 +401,15 @@ static inline size_t compaction_ws_elems(size_t entries, int nf) { return (size_
 static int ensure_loc_lut(vslam_ctx* c) {
     if (c->loc_lut) return VSLAM_OK;
     constexpr int n = LOC_LUT_N * LOC_LUT_N * LOC_LUT_N;
-    HIPCHK(c, hipMalloc((void**)&c->loc_lut, sizeof(float) * n));
-    LAUNCH(c, "k_build_localization_lut", k_build_localization_lut, dim3((n + 255) / 256), dim3(256), c->loc_lut);
+    float* lut = nullptr;
+    HIPCHK(c, hipMalloc((void**)&lut, sizeof(float) * n));
+    hipLaunchKernelGGL(k_build_localization_lut, dim3((n + 255) / 256), dim3(256), 0, c->stream, lut);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {  // never leave a table that was not built
+        (void)hipFree(lut);
+        return fail(c, VSLAM_ERR_HIP, std::string("k_build_localization_lut: ") + hipGetErrorString(e));
+    }
+    c->loc_lut = lut;
     return VSLAM_OK;
 }
 
@@ -680,6 +689,8 @@ int vslam_ctx_destroy(vslam_ctx* c) {
     if (!c) return VSLAM_ERR_INVALID;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    for (int i = 0; i < 2; ++i)  // a failed batch call may have left side-stream work un-joined
+        if (c->aux[i]) (void)hipStreamSynchronize(c->aux[i]);
     for (auto& kv : c->taps) (void)hipFree(kv.second);
     for (auto& kv : c->strip_taps) (void)hipFree(kv.second);
     for (auto& kv : c->tile_taps) (void)hipFree(kv.second);
@@ -1412,6 +1423,18 @@ int vslam_detect_batch_dev(vslam_ctx* c, const vslam_params* pp, const uint8_t* 
         return !(e && e[0] == '0');
     }();
     hipStream_t sh = c->stream, sx = nullptr;  // Harris stream, extrema stream (nullptr = main)
+    // Any early return between the fork and the join must not leave the side streams running into
+    // buffers the caller (or the next ws_reserve) is about to reuse: drain them on the error path.
+    struct ForkGuard {
+        vslam_ctx* c;
+        bool armed = false;
+        ~ForkGuard() {
+            if (!armed) return;
+            for (int i = 0; i < 2; ++i)
+                if (c->aux[i]) (void)hipStreamSynchronize(c->aux[i]);
+            (void)hipStreamSynchronize(c->stream);
+        }
+    } guard{c};
     if (use_aux) {
         TRY(ensure_aux(c));
         HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
@@ -1419,6 +1442,7 @@ int vslam_detect_batch_dev(vslam_ctx* c, const vslam_params* pp, const uint8_t* 
         HIPCHK(c, hipStreamWaitEvent(c->aux[1], c->ev_fork, 0));
         sh = c->aux[0];
         sx = c->aux[1];
+        guard.armed = true;
     }
     for (int f0 = 0; f0 < n_frames; f0 += chunk) {
         const int nf = std::min(chunk, n_frames - f0);
@@ -1444,6 +1468,9 @@ int vslam_detect_batch_dev(vslam_ctx* c, const vslam_params* pp, const uint8_t* 
                 TRY(enqueue_orient_batch(c, p, L, nf, out->pyramid + (size_t)f0 * L.pyramid_frame_bytes, L.pyramid_frame_bytes,
                                          out->dog_points + (size_t)f0 * p.dog_cap, out->dog_counts + f0, os,
                                          out->oriented_points + (size_t)f0 * p.oriented_cap, out->oriented_counts + f0));
+                if (out->oriented_survivors)
+                    HIPCHK(c, hipMemcpyAsync(out->oriented_survivors + f0, os.scounts, sizeof(unsigned int) * (size_t)nf,
+                                             hipMemcpyDeviceToDevice, c->stream));
             }
         }
     }
@@ -1452,6 +1479,7 @@ int vslam_detect_batch_dev(vslam_ctx* c, const vslam_params* pp, const uint8_t* 
             HIPCHK(c, hipEventRecord(c->ev_join[i], c->aux[i]));
             HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[i], 0));
         }
+    guard.armed = false;
     return VSLAM_OK;
 }
 
