@@ -130,6 +130,8 @@ def main():
     ap.add_argument("--orient", type=int, default=0,
                     help="1: also run filterKeypoints on every frame's keypoint list (SURVEY 8f row 3); implies --localize 1")
     ap.add_argument("--cpu-sample", type=int, default=6, help="frames in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--stream", choices=["side", "null"], default="side",
+                    help="stream of the whole job: a torch side stream (default) or torch's default (NULL) stream")
     args = ap.parse_args()
 
     import torch
@@ -173,6 +175,11 @@ def main():
         dist.barrier()
     capi.build()
     rows, cols, n = args.rows, args.cols, args.frames
+    # One stream for the whole job: frame synthesis, the detection kernels, the count sums and the
+    # collective's input all run on it, so the stream alone orders them (capi.Context launches on
+    # the handle it is given; handle 0 = the NULL stream, passed on as VSLAM_STREAM_LEGACY).
+    job_stream = torch.cuda.Stream(device=dev) if args.stream == "side" else torch.cuda.default_stream(dev)
+    torch.cuda.set_stream(job_stream)
     ctx = capi.Context(local_rank_dev, torch.cuda.current_stream().cuda_stream)
     p = capi.default_params(rows, cols, n_octaves=args.octaves, localize=1 if args.orient else args.localize, orient=args.orient)
     L = capi.batch_layout(p)

@@ -69,8 +69,9 @@ const char* vslam_status_string(int status);
 /* device: HIP device ordinal.
  * stream: the hipStream_t every call of this context is enqueued on:
  *   - a stream handle of the caller: work is ordered with whatever else the caller enqueues there;
- *   - VSLAM_STREAM_LEGACY (= hipStreamLegacy): the device's legacy NULL stream.  A caller whose own
- *     work runs on the NULL stream (handle 0, e.g. torch's default stream) must pass THIS, not NULL;
+ *   - VSLAM_STREAM_LEGACY: the device's legacy NULL stream (the library then launches on stream 0).
+ *     A caller whose own work runs on the NULL stream (handle 0, e.g. torch's default stream) must
+ *     pass THIS, not NULL;
  *   - NULL: the context creates and owns a non-blocking stream.  It is NOT ordered against the NULL
  *     stream or any other stream: device buffers handed to vslam_detect_batch_dev must be complete
  *     before the call, and its results are complete only after vslam_ctx_sync.

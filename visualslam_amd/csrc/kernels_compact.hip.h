@@ -1,15 +1,15 @@
 // Deterministic ordered compaction of ballot flag words into keypoint lists, any batch size:
 //   k_flag_count   : one 256-thread block per chunk of 256 flag entries -> chunk totals
 //   k_chunk_scan   : one block per frame: exclusive scan of its chunk totals, frame total
-//   k_flag_scatter : per chunk again: in-block exclusive scan (wave shuffles + LDS), then every
-//                    non-empty entry is emitted by a whole wave - lane b owns bit b of the entry's
-//                    words, its list position is the entry's offset plus the popcount of the lower
-//                    bits (v_mbcnt-style), so the records of one entry leave as one coalesced burst
-//                    instead of one thread walking its bits while 63 lanes idle
+//   k_flag_scatter : per chunk again: in-block exclusive scan (wave shuffles + LDS); then ONE THREAD
+//                    PER RECORD: thread r of the chunk's records finds its entry by binary search in
+//                    the chunk's offsets (LDS) and its bit by rank-select inside the entry's words,
+//                    so all 256 threads write records and consecutive threads write consecutive
+//                    list slots.  (Round 1 let the entry's thread walk its own bits - up to 60
+//                    serial iterations with most lanes idle: 0.6 ms per 256-frame launch.)
 // List order = entry order, and inside an entry ascending bit order, which is the reference's
 // loop order (row-major pixels for Harris; octave, level, i, j for the DoG lattice).  Three
-// short launches instead of one serial workgroup per frame: a single 1080p frame compacts in
-// ~20 us instead of 250 us, and a 256-frame batch spreads over the whole chip.
+// short launches instead of one serial workgroup per frame.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -20,8 +20,27 @@ namespace vslam {
 
 constexpr int CMP_CHUNK = 256;  // entries per workgroup
 
-// Entry kinds: what one flag entry is and how its set bits turn into list records.
+// index of the k-th (0-based) set bit of w; k < popcount(w)
+__device__ __forceinline__ int select64(unsigned long long w, unsigned int k) {
+    unsigned int x = (unsigned int)w;
+    int pos = 0;
+    unsigned int c = __popc(x);
+    if (k >= c) k -= c, pos = 32, x = (unsigned int)(w >> 32);
+#pragma unroll
+    for (int s = 16; s >= 1; s >>= 1) {
+        c = __popc(x & ((1u << s) - 1u));
+        if (k >= c) k -= c, pos += s, x >>= s;
+    }
+    return pos;
+}
+
+// Entry kinds: what one flag entry is (load), what its thread precomputes once per entry (Info,
+// parked in LDS) and how the k-th set bit of the entry becomes a list record (emit).
 struct HarrisStripEntries {  // entry = (row, strip): 4 ballot words (pixel slot k = 0..3), lane-major order
+    static constexpr int WORDS = 4;
+    struct Info {
+        int row, c0;
+    };
     const unsigned long long* flags;
     size_t fframe;
     int rows, cols, nstrips;
@@ -35,30 +54,40 @@ struct HarrisStripEntries {  // entry = (row, strip): 4 ballot words (pixel slot
         for (int k = 0; k < 4; ++k) w[k] = F[k];
         return __popcll(w[0]) + __popcll(w[1]) + __popcll(w[2]) + __popcll(w[3]);
     }
-    // whole wave, uniform (f, e, w, pos): lane l owns pixel slots k = 0..3 of its dword; records in
-    // (lane, k) order = ascending columns
-    __device__ void emit_wave(int f, size_t e, const unsigned long long (&w)[4], unsigned int pos, unsigned int cap, int lane) const {
-        const int r = (int)(e / nstrips), strip = (int)(e % nstrips);
-        const unsigned long long below = (1ull << lane) - 1ull;
-        pos += __popcll(w[0] & below) + __popcll(w[1] & below) + __popcll(w[2] & below) + __popcll(w[3] & below);
-        const int c0 = strip * HS_STRIP_W + 4 * (lane - 2);
-        const float* rp = resp + f * rframe + (size_t)r * cols + c0;
+    __device__ Info info(int, size_t e) const {
+        const int r = (int)((unsigned int)e / (unsigned int)nstrips), strip = (int)((unsigned int)e % (unsigned int)nstrips);
+        return Info{r, strip * HS_STRIP_W - 8};
+    }
+    // records of an entry in (lane, slot) order = ascending columns
+    __device__ void emit(int f, const Info& in, const unsigned long long (&w)[4], unsigned int k, size_t slot) const {
+        int l = 0;  // largest lane with fewer than k+1 flags below it
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if ((w[k] >> lane) & 1ull) {
-                if (pos < cap) {
-                    vslam_kp kp;
-                    kp.row = r;
-                    kp.col = c0 + k;
-                    kp.response = rp[k];
-                    out[(size_t)f * cap + pos] = kp;
-                }
-                ++pos;
-            }
+        for (int s = 32; s >= 1; s >>= 1) {
+            const unsigned long long m = (1ull << (l + s)) - 1ull;
+            const unsigned int c = __popcll(w[0] & m) + __popcll(w[1] & m) + __popcll(w[2] & m) + __popcll(w[3] & m);
+            if (c <= k) l += s;
+        }
+        const unsigned long long m = (1ull << l) - 1ull;
+        k -= __popcll(w[0] & m) + __popcll(w[1] & m) + __popcll(w[2] & m) + __popcll(w[3] & m);
+        const unsigned int nib = (unsigned int)((w[0] >> l) & 1ull) | ((unsigned int)((w[1] >> l) & 1ull) << 1) |
+                                 ((unsigned int)((w[2] >> l) & 1ull) << 2) | ((unsigned int)((w[3] >> l) & 1ull) << 3);
+        unsigned int x = nib;
+        for (unsigned int i = 0; i < k; ++i) x &= x - 1;  // drop the k lowest set bits (k <= 3)
+        const int c = in.c0 + 4 * l + (__ffs((int)x) - 1);
+        vslam_kp kp;
+        kp.row = in.row;
+        kp.col = c;
+        kp.response = resp[f * rframe + (size_t)in.row * cols + c];
+        out[slot] = kp;
     }
 };
 
 struct DogEntries {  // entry = one 64-site word of the (octave, level, lattice row) bitmask layout
+    static constexpr int WORDS = 1;
+    struct Info {
+        int octave, level, i, j0, step;
+        unsigned int row_off;  // byte offset of DoG row (level, i - pad) in the frame's pyramid block
+    };
     const unsigned long long* lflags;
     size_t bframe;
     const uint8_t* pyr;
@@ -74,32 +103,37 @@ struct DogEntries {  // entry = one 64-site word of the (octave, level, lattice 
         w[0] = lflags[f * bframe + first() + e];
         return __popcll(w[0]);
     }
-    __device__ void emit_wave(int f, size_t e, const unsigned long long (&w)[4], unsigned int pos, unsigned int cap, int lane) const {
+    __device__ Info info(int, size_t e) const {
         const size_t wi = first() + e;
         int o = o_begin;
         while (o + 1 < o_end && wi >= g.bits_off[o + 1]) ++o;
-        const size_t wl = wi - g.bits_off[o];
-        const int wpr = g.wpr[o], lr = g.lat_rows[o];
-        const int level = (int)(wl / ((size_t)lr * wpr)) + 1;
+        const unsigned int wl = (unsigned int)(wi - g.bits_off[o]);
+        const unsigned int wpr = g.wpr[o], lr = g.lat_rows[o];
+        const int level = (int)(wl / (lr * wpr)) + 1;
         const int li = (int)((wl / wpr) % lr), lj0 = (int)(wl % wpr) * 64;
         const size_t P = (size_t)g.rows[o] * g.pitch[o];
-        const uint8_t* dog = pyr + f * pframe + g.oct_off[o] + (size_t)VSLAM_NUM_LEVELS * P;
-        if (!((w[0] >> lane) & 1ull)) return;
-        pos += __popcll(w[0] & ((1ull << lane) - 1ull));
-        if (pos >= cap) return;
-        const int i = g.pad + li * g.window, j = g.pad + (lj0 + lane) * g.window;
+        const int i = g.pad + li * g.window;
+        return Info{o, level, i, g.pad + lj0 * g.window, g.window,
+                    (unsigned int)(g.oct_off[o] + (size_t)(VSLAM_NUM_LEVELS + level) * P + (size_t)(i - g.pad) * g.pitch[o])};
+    }
+    __device__ void emit(int f, const Info& in, const unsigned long long (&w)[4], unsigned int k, size_t slot) const {
+        const int j = in.j0 + select64(w[0], k) * in.step;
         vslam_point pt;
-        pt.row = i;
+        pt.row = in.i;
         pt.col = j;
-        pt.value = dog[(size_t)level * P + (size_t)(i - g.pad) * g.pitch[o] + (j - g.pad)];
+        pt.value = pyr[f * pframe + in.row_off + (j - g.pad)];
         pt.padding = g.pad;
-        pt.octave = o;
-        pt.level = level;
-        out[(size_t)f * cap + pos] = pt;
+        pt.octave = in.octave;
+        pt.level = in.level;
+        out[slot] = pt;
     }
 };
 
 struct OrientEntries {  // entry = one keypoint of filterKeypoints: 36-bit mask of histogram peaks
+    static constexpr int WORDS = 1;
+    struct Info {
+        int row, col, octave, level;
+    };
     const unsigned long long* masks;
     const vslam_point* kps;
     size_t n;
@@ -109,23 +143,27 @@ struct OrientEntries {  // entry = one keypoint of filterKeypoints: 36-bit mask 
         w[0] = masks[e];
         return __popcll(w[0]);
     }
-    __device__ void emit_wave(int, size_t e, const unsigned long long (&w)[4], unsigned int pos, unsigned int cap, int lane) const {
-        if (!((w[0] >> lane) & 1ull)) return;
-        pos += __popcll(w[0] & ((1ull << lane) - 1ull));
-        if (pos >= cap) return;
+    __device__ Info info(int, size_t e) const {
         const vslam_point kp = kps[e];
+        return Info{kp.row, kp.col, kp.octave, kp.level};
+    }
+    __device__ void emit(int, const Info& in, const unsigned long long (&w)[4], unsigned int k, size_t slot) const {
         vslam_point pt;  // SLAM::point{y, x, angle, 0, octave, level}, Diff_of_Gauss.cpp:365
-        pt.row = kp.row;
-        pt.col = kp.col;
-        pt.value = lane * 10;
+        pt.row = in.row;
+        pt.col = in.col;
+        pt.value = select64(w[0], k) * 10;
         pt.padding = 0;
-        pt.octave = kp.octave;
-        pt.level = kp.level;
-        out[pos] = pt;
+        pt.octave = in.octave;
+        pt.level = in.level;
+        out[slot] = pt;
     }
 };
 
 struct SurvivorEntries {  // entry = 64 consecutive list records of a frame: bits = records that pass the edge test
+    static constexpr int WORDS = 1;
+    struct Info {
+        unsigned int first;
+    };
     const unsigned long long* flags;
     size_t fwords;
     unsigned int* surv;  // [frame][scap] record indices, ascending
@@ -134,14 +172,17 @@ struct SurvivorEntries {  // entry = 64 consecutive list records of a frame: bit
         w[0] = flags[f * fwords + e];
         return __popcll(w[0]);
     }
-    __device__ void emit_wave(int f, size_t e, const unsigned long long (&w)[4], unsigned int pos, unsigned int cap, int lane) const {
-        if (!((w[0] >> lane) & 1ull)) return;
-        pos += __popcll(w[0] & ((1ull << lane) - 1ull));
-        if (pos < cap) surv[(size_t)f * cap + pos] = (unsigned int)(e * 64 + lane);
+    __device__ Info info(int, size_t e) const { return Info{(unsigned int)(e * 64)}; }
+    __device__ void emit(int, const Info& in, const unsigned long long (&w)[4], unsigned int k, size_t slot) const {
+        surv[slot] = in.first + (unsigned int)select64(w[0], k);
     }
 };
 
 struct OrientBatchEntries {  // entry = one survivor of a frame: 36-bit mask of its histogram peaks
+    static constexpr int WORDS = 1;
+    struct Info {
+        int row, col, octave, level;
+    };
     const unsigned long long* masks;
     const unsigned int* surv;
     const unsigned int* scounts;
@@ -154,19 +195,19 @@ struct OrientBatchEntries {  // entry = one survivor of a frame: 36-bit mask of 
         w[0] = e < min(scounts[f], scap) ? masks[(size_t)f * scap + e] : 0ull;
         return __popcll(w[0]);
     }
-    __device__ void emit_wave(int f, size_t e, const unsigned long long (&w)[4], unsigned int pos, unsigned int cap, int lane) const {
-        if (!((w[0] >> lane) & 1ull)) return;
-        pos += __popcll(w[0] & ((1ull << lane) - 1ull));
-        if (pos >= cap) return;
+    __device__ Info info(int f, size_t e) const {
         const vslam_point kp = pts[(size_t)f * pcap + surv[(size_t)f * scap + e]];
+        return Info{kp.row, kp.col, kp.octave, kp.level};
+    }
+    __device__ void emit(int, const Info& in, const unsigned long long (&w)[4], unsigned int k, size_t slot) const {
         vslam_point pt;  // SLAM::point{y, x, angle, 0, octave, level}, Diff_of_Gauss.cpp:365
-        pt.row = kp.row;
-        pt.col = kp.col;
-        pt.value = lane * 10;
+        pt.row = in.row;
+        pt.col = in.col;
+        pt.value = select64(w[0], k) * 10;
         pt.padding = 0;
-        pt.octave = kp.octave;
-        pt.level = kp.level;
-        out[(size_t)f * cap + pos] = pt;
+        pt.octave = in.octave;
+        pt.level = in.level;
+        out[slot] = pt;
     }
 };
 
@@ -244,37 +285,38 @@ __global__ __launch_bounds__(256) void k_chunk_scan(unsigned int* __restrict__ c
     if (threadIdx.x == 0) counts[f] = running;
 }
 
-__device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v, int src_lane) {
-    const unsigned int lo = __builtin_amdgcn_readlane((unsigned int)v, src_lane);
-    const unsigned int hi = __builtin_amdgcn_readlane((unsigned int)(v >> 32), src_lane);
-    return ((unsigned long long)hi << 32) | lo;
-}
-
-// grid = (chunks, 1, frames).  Thread t of the block first plays entry t (count, exclusive offset);
-// then each wave walks the non-empty entries of its own 64 lanes: the entry's words and offset are
-// broadcast from the owning lane (v_readlane, the index is scalar) and all 64 lanes emit together.
+// grid = (chunks, 1, frames).  Thread t first plays entry t of the chunk (count, exclusive offset,
+// per-entry Info), then record t, t + 256, ... of the chunk.
 template <class E>
 __global__ __launch_bounds__(256) void k_flag_scatter(const E ent, const unsigned int* __restrict__ chunk_off, int nchunks,
                                                        unsigned int cap) {
     __shared__ unsigned int wsum[4];
-    const int f = blockIdx.z;
-    const int lane = threadIdx.x & 63;
-    const size_t e = (size_t)blockIdx.x * CMP_CHUNK + threadIdx.x;
+    __shared__ unsigned int s_ex[CMP_CHUNK];
+    __shared__ unsigned long long s_w[E::WORDS][CMP_CHUNK];
+    __shared__ typename E::Info s_info[CMP_CHUNK];
+    const int f = blockIdx.z, t = threadIdx.x;
+    const size_t e = (size_t)blockIdx.x * CMP_CHUNK + t;
     unsigned long long w[4] = {0, 0, 0, 0};
     const unsigned int cnt = e < ent.count() ? ent.load(f, e, w) : 0u;
     unsigned int total;
-    const unsigned int ex = block_excl_scan_256(cnt, wsum, total) + chunk_off[(size_t)f * nchunks + blockIdx.x];
-    unsigned long long todo = __ballot(cnt != 0);
-    const size_t e0 = e - lane;
-    while (todo) {  // wave-uniform
-        const int i = __ffsll((long long)todo) - 1;
-        todo &= todo - 1;
-        unsigned long long wi[4];
+    s_ex[t] = block_excl_scan_256(cnt, wsum, total);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) wi[k] = readlane_u64(w[k], i);
-        const unsigned int pos = __builtin_amdgcn_readlane(ex, i);
-        if (pos >= cap) break;  // offsets ascend: nothing further fits
-        ent.emit_wave(f, e0 + i, wi, pos, cap, lane);
+    for (int k = 0; k < E::WORDS; ++k) s_w[k][t] = w[k];
+    if (cnt) s_info[t] = ent.info(f, e);
+    __syncthreads();
+    const unsigned int base = chunk_off[(size_t)f * nchunks + blockIdx.x];
+    if (base >= cap) return;  // block-uniform: nothing of this chunk fits
+    for (unsigned int r = t; r < total; r += CMP_CHUNK) {
+        if (base + r >= cap) break;
+        // the entry holding record r: the last one whose exclusive offset is <= r (it is non-empty)
+        int lo = 0;
+#pragma unroll
+        for (int s = CMP_CHUNK / 2; s >= 1; s >>= 1)
+            if (s_ex[lo + s] <= r) lo += s;
+        unsigned long long we[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < E::WORDS; ++k) we[k] = s_w[k][lo];
+        ent.emit(f, s_info[lo], we, r - s_ex[lo], (size_t)f * cap + base + r);
     }
 }
 

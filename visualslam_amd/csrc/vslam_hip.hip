@@ -672,7 +672,9 @@ int vslam_ctx_create(int device, void* stream, vslam_ctx** out) {
     vslam_ctx* c = new (std::nothrow) vslam_ctx();
     if (!c) return VSLAM_ERR_NOMEM;
     c->device = device;
-    if (stream) {
+    if (stream == VSLAM_STREAM_LEGACY) {
+        c->stream = nullptr;  // the NULL stream itself: every HIP call below takes it as "stream 0"
+    } else if (stream) {
         c->stream = (hipStream_t)stream;
     } else {
         if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
