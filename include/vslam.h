@@ -236,6 +236,35 @@ int vslam_edge_response_windows(vslam_ctx* ctx, const float* gx_windows, const f
 int vslam_structure_matrix_windows(vslam_ctx* ctx, const float* gx_windows, const float* gy_windows, int window_elems,
                                    size_t n, float* sums);
 
+/* ------------------------------------------- SIFT descriptor stage (host buffers) */
+
+/* const Point2f Rotation::cos_sin_of_angle(float theta, bool degrees = true), rotation.cpp:9-17, with
+ * convertToRadians (:5-7): theta * (CV_PI / 180.0f) in double, narrowed to float, cos / sin of it
+ * (host libm, like the reference).  Pure host computation. */
+void vslam_cos_sin_deg(float theta_deg, float* cos_out, float* sin_out);
+/* std::vector<Point2i> Rotation::getRotatedWindowPoints(Mat& I, const Point2i& center, int windowSize,
+ * float theta, bool degrees = true), rotation.cpp:112-130 (with rotate_pt_CW :19-27): the
+ * (windowSize+1)^2 points of the square around `center` rotated clockwise, rows outer;
+ * xy[2q] = x, xy[2q+1] = y.  The Mat argument of the reference is unused.  Pure host computation. */
+int vslam_rotated_window_points(int cx, int cy, int window, float theta_deg, int32_t* xy);
+/* void SIFT(vector<SLAM::point>& reducedKeypoints, vector<vector<float>>& featureDescriptors_vec,
+ * GaussPyramid&, int octave), Diff_of_Gauss.cpp:561-693, with rotateImageSection (:528-559): one
+ * 128-float descriptor per oriented keypoint of the octave (vslam_filter_keypoints output: value =
+ * angle in degrees), desc = n x 128.  Literal reference behaviour, including the stride-16 walk of
+ * the 17 x 17 point list (:545) and Mat::at<>(point.x, point.y) with x as the ROW (:549-554) on the
+ * 20-padded level images.  Mat::at checks nothing, so a sample is linear element
+ * x * (cols + 40) + y of the padded Mat; a keypoint whose 256 samples all lie inside that buffer is
+ * DEFINED (always the case for square and portrait octaves away from the last rows), otherwise the
+ * reference reads foreign memory: defined[k] = 0 and a zero descriptor.  defined may be NULL, in
+ * which case any undefined keypoint makes the call return VSLAM_ERR_RANGE (after filling desc).
+ * A flat window gives the reference's all-NaN descriptor (0 / 0 at :661). */
+int vslam_sift_descriptors(vslam_ctx* ctx, const vslam_pyramid* pyr, int octave, const vslam_point* oriented, size_t n,
+                           float* desc, uint8_t* defined);
+/* featureDescriptors.dat, Diff_of_Gauss.cpp:837-863: int32 {n, 128, 24} (24 = sizeof(std::vector<float>)
+ * on LP64, what `sizeof(featureDescriptors_vec.front())` writes) followed by n x 128 float32,
+ * native byte order.  Pure host computation. */
+int vslam_descriptor_file_write(const char* path, const float* desc, size_t n);
+
 /* ------------------------------------------- device-resident batched detection */
 
 typedef struct {

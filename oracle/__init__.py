@@ -109,6 +109,11 @@ def lib():
         L.vo_compute_edge_response.restype = C.c_float
         L.vo_filter_keypoints.argtypes = [C.POINTER(_Pyr), C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
         L.vo_filter_keypoints.restype = C.c_size_t
+        L.vo_cos_sin_deg.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.vo_cos_sin_deg.restype = None
+        L.vo_rotated_window_points.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]
+        L.vo_sift_descriptors.argtypes = [C.POINTER(_Pyr), C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        L.vo_sift_descriptors.restype = C.c_size_t
         L.vo_baseline_frames.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_ulonglong)]
         _lib = L
     return _lib
@@ -122,6 +127,19 @@ def baseline_frames(frames, n_octaves: int = 4, threads: int = 1) -> int:
     kp = C.c_ulonglong(0)
     _chk(lib().vo_baseline_frames(frames.ctypes.data, frames.shape[0], frames.shape[1], frames.shape[2], n_octaves, threads, C.byref(kp)), "baseline_frames")
     return kp.value
+
+
+def cos_sin_deg(theta_deg):
+    c, s = C.c_float(), C.c_float()
+    lib().vo_cos_sin_deg(float(theta_deg), C.byref(c), C.byref(s))
+    return np.float32(c.value), np.float32(s.value)
+
+
+def rotated_window_points(cx, cy, window, theta_deg):
+    """Rotation::getRotatedWindowPoints: int32 [(window+1)^2, 2] = (x, y), rows outer."""
+    xy = np.zeros(((window + 1) ** 2, 2), np.int32)
+    _chk(lib().vo_rotated_window_points(int(cx), int(cy), int(window), float(theta_deg), xy.ctypes.data), "rotated_window_points")
+    return xy
 
 
 def gauss_ksize_f32(sigma):
@@ -345,6 +363,16 @@ class Pyramid:
         if n:
             lib().vo_filter_keypoints(self._p, octave, kps.ctypes.data, len(kps), out.ctypes.data, n)
         return out
+
+    def sift_descriptors(self, octave, oriented):
+        """SIFT() for one octave's oriented keypoints: (desc f32 [n, 128], defined bool [n])."""
+        kps = np.ascontiguousarray(oriented, dtype=POINT_DTYPE)
+        desc = np.zeros((len(kps), 128), np.float32)
+        ok = np.zeros(len(kps), np.uint8)
+        r = lib().vo_sift_descriptors(self._p, octave, kps.ctypes.data, len(kps), desc.ctypes.data, ok.ctypes.data)
+        if r == C.c_size_t(-1).value:
+            raise ValueError("SIFT: keypoint outside the pyramid data")
+        return desc, ok.astype(bool)
 
     def close(self):
         if self._p:

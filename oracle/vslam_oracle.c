@@ -899,3 +899,161 @@ int vo_baseline_frames(const uint8_t* frames, int n, int rows, int cols, int n_o
     if (keypoints) *keypoints = total;
     return bad ? -1 : 0;
 }
+
+/* ------------------------------------------------------------------------- */
+/* SIFT descriptor stage                            */
+/* ------------------------------------------------------------------------- */
+
+/* Rotation::cos_sin_of_angle (rotation.cpp:5-17): theta * (CV_PI / 180.0f) is evaluated in double
+ * (CV_PI is a double literal) and returned as float (:6); cos / sin of that float.  Whether the
+ * unqualified cos(angle) binds to ::cos(double) or to a float overload depends on what OpenCV's
+ * headers include; for the angles the pipeline produces (multiples of 10 degrees) both give the
+ * same float with glibc (checked in tests/test_sift_cpu.py), the double form is used here. */
+void vo_cos_sin_deg(float theta_deg, float* c, float* s) {
+    const float angle = (float)((double)theta_deg * (3.1415926535897932384626433832795 / (double)180.0f));
+    *c = (float)cos((double)angle);
+    *s = (float)sin((double)angle);
+}
+
+/* Rotation::rotate_pt_CW (rotation.cpp:19-27): int * float products and their difference / sum in
+ * f32 (x86-64 SSE, no FMA: CMakeLists.txt sets no -march), truncated to int (cvttss2si). */
+static void rotate_pt_cw(int px, int py, int cx, int cy, float c, float s, int* ox, int* oy) {
+    const int rx = px - cx, ry = py - cy;
+    const float a = (float)rx * c, b = (float)ry * s;
+    const int x_r = cvtt_f32_i32(a - b);
+    const float d = (float)rx * s, e = (float)ry * c;
+    const int y_r = cvtt_f32_i32(d + e);
+    *ox = x_r + cx;
+    *oy = y_r + cy;
+}
+
+/* Rotation::getRotatedWindowPoints (rotation.cpp:112-130): the (window+1)^2 points of the square
+ * [c - window/2, c + window/2]^2 rotated clockwise about the centre, rows (y) outer; xy[2q] = x,
+ * xy[2q+1] = y.  The Mat argument of the reference is unused. */
+int vo_rotated_window_points(int cx, int cy, int window, float theta_deg, int32_t* xy) {
+    if (!xy || window <= 0) return -1;
+    float c, s;
+    vo_cos_sin_deg(theta_deg, &c, &s);
+    const int padding = window / 2;
+    int q = 0;
+    for (int i = cy - padding; i <= cy + padding; i++)
+        for (int j = cx - padding; j <= cx + padding; j++, q++) {
+            int x, y;
+            rotate_pt_cw(j, i, cx, cy, c, s, &x, &y);
+            xy[2 * q] = x;
+            xy[2 * q + 1] = y;
+        }
+    return 0;
+}
+
+/* SIFT(), Diff_of_Gauss.cpp:561-693, with rotateImageSection (:528-559), for the oriented
+ * keypoints of one octave (output of vo_filter_keypoints: value = angle in degrees).
+ *   :578-580  level images padded by maxPadding = 20 (replicate): magnitude, orientation
+ *   :591      rotated window points about (col + 20, row + 20), window 16 -> 17 x 17 points
+ *   :545      rotatedPoints[i * imgROI.rows + j]: the 16 x 16 ROI walks the 17-wide list with stride
+ *             16 (literal; the list has 289 entries)
+ *   :549-554  Mat::at<>(rotatedPoint.x, rotatedPoint.y): x is used as the ROW and y as the COLUMN
+ *             (literal).  Mat::at does no range check in a release build, so the element read is
+ *             linear index x * (cols + 40) + y of the continuous padded Mat; a keypoint is DEFINED
+ *             iff all 256 indices lie inside the Mat's buffer -- otherwise the reference reads
+ *             foreign memory (its own comment at :541 mentions the segmentation fault), reported
+ *             here as defined[k] = 0 with an all-zero descriptor
+ *   :616-618  GaussianBlur of the 16 x 16 magnitude ROI (its own Mat: borders reflect inside it),
+ *             sigma = 1.5 * sigma(octave, level), CV_32F kernel width cvRound(8 sigma + 1) | 1
+ *   :629-653  sixteen 4 x 4 sub-regions, row-major, 8 orientation bins each, nearest-bin indexing
+ *             (int)(orientation * (8 / 360.0f)), magnitudes accumulated in pixel order
+ *   :659-675  divide by the max, clip at 0.2f with std::min semantics, divide by the new max (an
+ *             all-zero histogram gives 0/0 = NaN throughout, kept)
+ * desc: n x 128 floats; defined: n bytes (may be NULL).  Returns the number of undefined
+ * keypoints, or (size_t)-1 for invalid input (level / octave mismatch, histogram index out of range
+ * = the reference's vector::at would throw). */
+size_t vo_sift_descriptors(const vo_pyramid* p, int octave, const vo_point* kps, size_t n, float* desc, uint8_t* defined) {
+    if (!p || octave < 0 || octave >= p->n_octaves || (!kps && n) || (!desc && n)) return (size_t)-1;
+    const int rows = p->rows[octave], cols = p->cols[octave];
+    const int windowSize = 16, maxPadding = 20;
+    const int pr = rows + 2 * maxPadding, pc = cols + 2 * maxPadding;
+    const size_t P = (size_t)rows * cols;
+    float *pmag[VO_NUM_LEVELS] = {0}, *porient[VO_NUM_LEVELS] = {0}, *kern[VO_NUM_LEVELS] = {0};
+    int kn[VO_NUM_LEVELS] = {0};
+    size_t undefined = 0;
+    int bad = 0;
+    const int histoSize = 8, subregion = 4;
+    const float reductionCoeff = (float)histoSize / 360.0f;
+    for (size_t q = 0; q < n && !bad; q++) {
+        const int level = kps[q].level;
+        float* out = desc + q * 128;
+        if (level < 0 || level >= VO_NUM_LEVELS || kps[q].octave != octave) {
+            bad = 1;
+            break;
+        }
+        if (!pmag[level]) {
+            float* mag = (float*)malloc(4 * P);
+            float* ori = (float*)malloc(4 * P);
+            if (!mag || !ori) abort();
+            vo_level_gradients(p->gauss[octave][level], rows, cols, (size_t)cols, NULL, NULL, mag, ori, 4 * (size_t)cols);
+            pmag[level] = pad_replicate_f32(mag, rows, cols, maxPadding);
+            porient[level] = pad_replicate_f32(ori, rows, cols, maxPadding);
+            free(mag);
+            free(ori);
+            const double sigma = 1.5 * p->sigma[octave][level]; /* :616 */
+            kn[level] = vo_gauss_ksize_f32(sigma);
+            kern[level] = (float*)malloc(4 * (size_t)kn[level]);
+            if (!pmag[level] || !porient[level] || !kern[level]) abort();
+            vo_gauss_kernel_f32(kn[level], sigma, kern[level]);
+        }
+        int32_t pts[2 * 17 * 17];
+        vo_rotated_window_points(kps[q].col + maxPadding, kps[q].row + maxPadding, windowSize, (float)kps[q].value, pts);
+        float magROI[16 * 16], orientROI[16 * 16], magWeighted[16 * 16];
+        int ok = 1;
+        for (int i = 0; i < windowSize && ok; i++)
+            for (int j = 0; j < windowSize; j++) {
+                const int32_t* rp = pts + 2 * (i * windowSize + j); /* :545 */
+                const long long e = (long long)rp[0] * pc + rp[1];   /* at<>(rp.x, rp.y), :549-554 */
+                if (e < 0 || e >= (long long)pr * pc) {
+                    ok = 0;
+                    break;
+                }
+                magROI[i * windowSize + j] = pmag[level][e];
+                orientROI[i * windowSize + j] = porient[level][e];
+            }
+        if (defined) defined[q] = (uint8_t)ok;
+        if (!ok) {
+            undefined++;
+            for (int b = 0; b < 128; b++) out[b] = 0.0f;
+            continue;
+        }
+        if (blur_f32_roi(magROI, windowSize, windowSize, 0, 0, windowSize, windowSize, kern[level], kn[level], magWeighted) != 0) abort();
+        int nf = 0;
+        for (int r0 = 0; r0 < windowSize && !bad; r0 += subregion)
+            for (int c0 = 0; c0 < windowSize && !bad; c0 += subregion) { /* :637-652: columns advance first */
+                float histo[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (int i = r0; i < r0 + subregion && !bad; i++)
+                    for (int j = c0; j < c0 + subregion; j++) {
+                        const int index = (int)(orientROI[i * windowSize + j] * reductionCoeff); /* :126 */
+                        if (index < 0 || index >= histoSize) {
+                            bad = 1;
+                            break;
+                        }
+                        histo[index] += magWeighted[i * windowSize + j];
+                    }
+                for (int b = 0; b < histoSize; b++) out[nf++] = histo[b];
+            }
+        if (bad) break;
+        float maxPeak = out[0]; /* *max_element: operator< scan, first element kept on NaN */
+        for (int b = 1; b < 128; b++)
+            if (maxPeak < out[b]) maxPeak = out[b];
+        for (int b = 0; b < 128; b++) out[b] = out[b] / maxPeak; /* :661 */
+        const float threshold = 0.2f;
+        for (int b = 0; b < 128; b++) out[b] = threshold < out[b] ? threshold : out[b]; /* std::min(c, threshold), :668 */
+        maxPeak = out[0];
+        for (int b = 1; b < 128; b++)
+            if (maxPeak < out[b]) maxPeak = out[b];
+        for (int b = 0; b < 128; b++) out[b] = out[b] / maxPeak; /* :675 */
+    }
+    for (int l = 0; l < VO_NUM_LEVELS; l++) {
+        free(pmag[l]);
+        free(porient[l]);
+        free(kern[l]);
+    }
+    return bad ? (size_t)-1 : undefined;
+}

@@ -164,6 +164,16 @@ int vo_feature_point_localization(int d_x, int d_y, int d_scale, int value, int*
  * the keypoints the reference appends, in its loop order.  Returns the total; writes <= cap. */
 size_t vo_dog_keypoints(const vo_pyramid* p, int octave, int window, vo_point* out, size_t cap);
 
+/* ---- SIFT descriptor stage ---- */
+/* Rotation::cos_sin_of_angle(theta, degrees = true), rotation.cpp:5-17. */
+void vo_cos_sin_deg(float theta_deg, float* c, float* s);
+/* Rotation::getRotatedWindowPoints, rotation.cpp:112-130: (window+1)^2 points, xy[2q] = x, xy[2q+1] = y. */
+int vo_rotated_window_points(int cx, int cy, int window, float theta_deg, int32_t* xy);
+/* SIFT() + rotateImageSection, Diff_of_Gauss.cpp:561-693,528-559, for one octave's oriented keypoints:
+ * desc n x 128 floats, defined n bytes (optional).  Returns the number of keypoints whose rotated
+ * window leaves the padded level (undefined in the reference), or (size_t)-1 on invalid input. */
+size_t vo_sift_descriptors(const vo_pyramid* p, int octave, const vo_point* kps, size_t n, float* desc, uint8_t* defined);
+
 /* CPU baseline driver (bench.py's cpu_baseline leg): the whole hot path of BASELINE config 4 --
  * Harris response, both NMS variants, keypoint list, GaussPyramid(img, n_octaves, 1.6), extrema
  * candidates with value >= 8 -- on n dense frames, `threads` OpenMP threads over frames (the

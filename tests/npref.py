@@ -190,3 +190,70 @@ def filter_keypoints(gauss_level, kps_level, sigma_blur, kernel_f32):
         thr = f32(histo.max() * f32(0.8))
         out += [(y, x, 10 * b) for b in range(36) if histo[b] > thr]
     return out
+
+
+def rotated_window_points(cx, cy, window, theta_deg):
+    """Rotation::getRotatedWindowPoints (rotation.cpp:112-130) with numpy float32 arithmetic:
+    int32 [(window+1)^2, 2] = (x, y), rows outer."""
+    f32 = np.float32
+    ang = f32(np.float64(f32(theta_deg)) * (np.float64(3.1415926535897932384626433832795) / np.float64(f32(180.0))))
+    c, s = f32(np.cos(np.float64(ang))), f32(np.sin(np.float64(ang)))
+    pad = window // 2
+    jj, ii = np.meshgrid(np.arange(cx - pad, cx + pad + 1), np.arange(cy - pad, cy + pad + 1))
+    rx, ry = (jj - cx).astype(f32), (ii - cy).astype(f32)
+    xr = np.trunc((rx * c).astype(f32) - (ry * s).astype(f32)).astype(np.int32) + cx
+    yr = np.trunc((rx * s).astype(f32) + (ry * c).astype(f32)).astype(np.int32) + cy
+    return np.stack([xr.ravel(), yr.ravel()], axis=1).astype(np.int32)
+
+
+def sift_descriptor(gauss_level, kp_row, kp_col, angle_deg, kernel_f32):
+    """SIFT() (Diff_of_Gauss.cpp:561-693) for ONE oriented keypoint, whole-array numpy: returns the 128
+    floats, or None when the rotated window leaves the padded level's buffer."""
+    import oracle  # gradients only (tested on their own)
+
+    f32 = np.float32
+    _, _, mag, ori = oracle.level_gradients(gauss_level)
+    pmag, pori = np.pad(mag, 20, mode="edge"), np.pad(ori, 20, mode="edge")
+    pts = rotated_window_points(kp_col + 20, kp_row + 20, 16, angle_deg)
+    q = (np.arange(16)[:, None] * 16 + np.arange(16)[None, :]).ravel()       # :545, stride 16 into the 17-wide list
+    lin = pts[q, 0].astype(np.int64) * pmag.shape[1] + pts[q, 1]              # at<>(x, y): x is the row
+    if lin.min() < 0 or lin.max() >= pmag.size:
+        return None
+    m = pmag.ravel()[lin].reshape(16, 16)
+    o = pori.ravel()[lin].reshape(16, 16)
+    k = np.asarray(kernel_f32, f32)
+    n, R = len(k), len(k) // 2
+    ext = m
+    while ext.shape[0] < 16 + 2 * R:  # BORDER_REFLECT_101 of the 16 x 16 Mat itself, repeated
+        p = min(R - (ext.shape[0] - 16) // 2, ext.shape[0] - 1)
+        ext = np.pad(ext, p, mode="reflect")
+    off = (ext.shape[0] - 16) // 2 - R
+    ext = ext[off:off + 16 + 2 * R, off:off + 16 + 2 * R]
+    rowf = (k[0] * ext[:, 0:16]).astype(f32)
+    for i in range(1, n):
+        rowf = (rowf + (k[i] * ext[:, i:i + 16]).astype(f32)).astype(f32)
+    colf = (k[R] * rowf[R:R + 16]).astype(f32)
+    for i in range(1, R + 1):
+        colf = (colf + (k[R + i] * (rowf[R + i:R + i + 16] + rowf[R - i:R - i + 16]).astype(f32)).astype(f32)).astype(f32)
+    idx = (o * f32(f32(8) / f32(360.0))).astype(f32).astype(np.int32)
+    d = np.zeros(128, f32)
+    for rb in range(4):
+        for cb in range(4):
+            h = np.zeros(8, f32)
+            for i in range(4 * rb, 4 * rb + 4):
+                for j in range(4 * cb, 4 * cb + 4):
+                    h[idx[i, j]] += colf[i, j]
+            d[(rb * 4 + cb) * 8:(rb * 4 + cb) * 8 + 8] = h
+    with np.errstate(all="ignore"):
+        mx = d[0]
+        for v in d[1:]:
+            if mx < v:
+                mx = v
+        d = (d / mx).astype(f32)
+        d = np.where(f32(0.2) < d, f32(0.2), d).astype(f32)
+        mx = d[0]
+        for v in d[1:]:
+            if mx < v:
+                mx = v
+        d = (d / mx).astype(f32)
+    return d

@@ -37,9 +37,9 @@ def test_executables_fail_loudly_without_gpu(built):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("exe,arg", [("Harris", "640x480"), ("Harris", "1754x1240"), ("DoG", "512x384"), ("Pyramid_Test", None)])
-def test_executables_run(built, exe, arg):
+def test_executables_run(built, exe, arg, tmp_path):
     cmd = [os.path.join(built, exe)] + ([arg] if arg else [])
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=tmp_path)  # DoG writes featureDescriptors.dat into its cwd
     assert r.returncode == 0, r.stdout + r.stderr
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["exe"] == exe
@@ -47,6 +47,7 @@ def test_executables_run(built, exe, arg):
         assert out["keypoints_stagewise"] == out["keypoints_fused"] > 0 and out["structure_matrix_mismatch"] == 0
     if exe == "DoG":
         assert len(out["octaves"]) == 4 and out["keypoints"] > 0 and out["per_point_mismatch"] == 0
+        assert out["descriptors"] == out["oriented"] and os.path.exists(tmp_path / "featureDescriptors.dat")
     if exe == "Pyramid_Test":
         assert out["failures"] == 0
 
@@ -69,7 +70,7 @@ def test_cxx_results_match_oracle(built, tmp_path):
     assert json.loads(r.stdout.strip().splitlines()[-1])["keypoints_fused"] == want
     r = subprocess.run([os.path.join(built, "Harris"), "160x96"], capture_output=True, text=True, timeout=300)
     assert json.loads(r.stdout.strip().splitlines()[-1])["keypoints_fused"] == want  # imgio::synthetic == synth.py
-    r = subprocess.run([os.path.join(built, "DoG"), str(p)], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([os.path.join(built, "DoG"), str(p), str(tmp_path / "fd.dat")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
     pyr = oracle.Pyramid(img, 4, 1.6)
     want_oct = [len(pyr.extrema(o, 3, 8)[1]) for o in range(4)]
@@ -78,3 +79,36 @@ def test_cxx_results_match_oracle(built, tmp_path):
     assert [o["keypoints"] for o in got["octaves"]] == [len(pyr.keypoints(o, 3)) for o in range(4)]
     assert [o["oriented"] for o in got["octaves"]] == [len(pyr.filter_keypoints(o, pyr.keypoints(o, 3))) for o in range(4)]
     assert got["per_point_mismatch"] == 0
+
+
+@pytest.mark.gpu
+def test_dog_executable_writes_the_reference_descriptor_file(built, tmp_path):
+    # the one persisted artefact of the reference's DoG executable (Diff_of_Gauss.cpp:837-863): int32
+    # {n, 128, sizeof(std::vector<float>) = 24} then n x 128 float32 -- on the reference's square image
+    # (blox.jpg: every rotated window is defined), equal to the oracle's SIFT() output octave by octave
+    import numpy as np
+
+    import oracle
+    from tests import refimg
+
+    img = refimg.load("blox")
+    p = tmp_path / "blox.pgm"
+    with open(p, "wb") as f:
+        f.write(b"P5\n%d %d\n255\n" % (img.shape[1], img.shape[0]) + img.tobytes())
+    dat = tmp_path / "featureDescriptors.dat"
+    r = subprocess.run([os.path.join(built, "DoG"), str(p), str(dat)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    got = json.loads(r.stdout.strip().splitlines()[-1])
+    pyr = oracle.Pyramid(img, 4, 1.6)
+    want = []
+    for o in range(4):
+        d, ok = pyr.sift_descriptors(o, pyr.filter_keypoints(o, pyr.keypoints(o, 3)))
+        assert ok.all()
+        want.append(d)
+    want = np.concatenate(want)
+    raw = open(dat, "rb").read()
+    head = np.frombuffer(raw[:12], "<i4")
+    assert head.tolist() == [len(want), 128, 24] and len(raw) == 12 + 4 * 128 * len(want)
+    body = np.frombuffer(raw[12:], "<f4").reshape(-1, 128)
+    assert np.array_equal(body, want, equal_nan=True)
+    assert got["descriptors"] == len(want) > 0 and got["undefined_windows"] == 0

@@ -109,6 +109,10 @@ SIGNATURES = {
     "vslam_dog_keypoints": (_I, [_P, _P, _I, _I, _P, _Z, C.POINTER(_Z)]),
     "vslam_localize_points": (_I, [_P, _P, _Z, _P, _P]),
     "vslam_filter_keypoints": (_I, [_P, _P, _I, _P, _Z, _P, _Z, C.POINTER(_Z)]),
+    "vslam_cos_sin_deg": (None, [_F, C.POINTER(_F), C.POINTER(_F)]),
+    "vslam_rotated_window_points": (_I, [_I, _I, _I, _F, _P]),
+    "vslam_sift_descriptors": (_I, [_P, _P, _I, _P, _Z, _P, _P]),
+    "vslam_descriptor_file_write": (_I, [C.c_char_p, _P, _Z]),
     "vslam_edge_response_windows": (_I, [_P, _P, _P, _I, _Z, _P]),
     "vslam_structure_matrix_windows": (_I, [_P, _P, _P, _I, _Z, _P]),
     "vslam_params_default": (None, [C.POINTER(Params), _I, _I]),
@@ -195,6 +199,29 @@ def extrema_lattice(rows: int, cols: int, window: int = 3):
     r, c = C.c_int(), C.c_int()
     lib().vslam_extrema_lattice(rows, cols, window, C.byref(r), C.byref(c))
     return r.value, c.value
+
+
+def cos_sin_deg(theta_deg: float):
+    c, s = C.c_float(), C.c_float()
+    lib().vslam_cos_sin_deg(float(theta_deg), C.byref(c), C.byref(s))
+    return np.float32(c.value), np.float32(s.value)
+
+
+def rotated_window_points(cx: int, cy: int, window: int, theta_deg: float) -> np.ndarray:
+    """Rotation::getRotatedWindowPoints: int32 [(window+1)^2, 2] = (x, y), rows outer."""
+    xy = np.zeros(((max(window, 0) + 1) ** 2, 2), np.int32)
+    rc = lib().vslam_rotated_window_points(int(cx), int(cy), int(window), float(theta_deg), xy.ctypes.data)
+    if rc:
+        raise VslamError(rc, "vslam_rotated_window_points")
+    return xy
+
+
+def descriptor_file_write(path: str, desc) -> None:
+    """featureDescriptors.dat (Diff_of_Gauss.cpp:837-863): int32 {n, 128, 24} + n x 128 float32."""
+    d = np.ascontiguousarray(desc, dtype=np.float32).reshape(-1, 128)
+    rc = lib().vslam_descriptor_file_write(os.fsencode(path), d.ctypes.data, d.shape[0])
+    if rc:
+        raise VslamError(rc, "vslam_descriptor_file_write", path)
 
 
 def default_params(rows: int, cols: int, **kw) -> Params:
@@ -498,6 +525,14 @@ class Pyramid:
         n = C.c_size_t()
         self.ctx._chk(lib().vslam_filter_keypoints(self.ctx._h, self._h, octave, kps.ctypes.data, len(kps), out.ctypes.data, cap, C.byref(n)), "vslam_filter_keypoints")
         return out[: min(n.value, cap)], n.value
+
+    def sift_descriptors(self, octave: int, oriented):
+        """SIFT() for one octave's oriented keypoints: (desc f32 [n, 128], defined bool [n])."""
+        kps = np.ascontiguousarray(oriented, dtype=POINT_DTYPE)
+        desc = np.zeros((len(kps), 128), np.float32)
+        ok = np.zeros(max(len(kps), 1), np.uint8)
+        self.ctx._chk(lib().vslam_sift_descriptors(self.ctx._h, self._h, octave, kps.ctypes.data, len(kps), desc.ctypes.data, ok.ctypes.data), "vslam_sift_descriptors")
+        return desc, ok[: len(kps)].astype(bool)
 
     def close(self):
         if getattr(self, "_h", None):

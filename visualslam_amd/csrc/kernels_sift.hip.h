@@ -1,0 +1,137 @@
+// SIFT descriptor stage (Diff_of_Gauss.cpp:561-693 with rotateImageSection :528-559 and
+// Rotation::getRotatedWindowPoints rotation.cpp:112-130).
+//
+// One 256-thread workgroup per oriented keypoint, thread (i, j) = ROI pixel:
+//   1. its rotated sample point: entry 16 i + j of the 17 x 17 point list (:545 walks the 17-wide
+//      list with stride 16), rotate_pt_CW in separately rounded f32 (rotation.cpp:22-23), the cosine
+//      and sine of the keypoint's angle computed by the host (libm, like the reference);
+//   2. the sample itself: Mat::at<>(point.x, point.y) on the 20-padded level images uses x as the ROW
+//      (:549-554) and checks nothing, i.e. it reads linear element x * (cols + 40) + y of the padded
+//      Mat.  All 256 indices inside the buffer -> defined; otherwise the reference reads foreign
+//      memory and the keypoint is reported undefined (zero descriptor, defined[k] = 0).  Magnitude
+//      and orientation of the sampled pixel are formed on the fly from the 8-bit Gaussian level
+//      (processGradients, GaussPyramid.cpp:65-104: Sobel ksize 1, correctly rounded sqrt, fastAtan2),
+//      the 20-pixel padding is replicate (clamp);
+//   3. GaussianBlur of the 16 x 16 magnitude ROI (an isolated Mat: reflect-101 inside the 16 x 16,
+//      repeated for the 25 ... 309-tap kernels), row pass then symmetric column pass in OpenCV's
+//      accumulation order;
+//   4. sixteen 4 x 4 sub-regions x 8 bins: thread (region, bin) walks its region's 16 pixels in
+//      row-major order (the reference's += order);
+//   5. the two max-normalisations with the 0.2 clip (:659-675), IEEE f32 division.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "kernels_aux.hip.h"
+#include "kernels_generic.hip.h"
+
+namespace vslam {
+
+constexpr int SIFT_WIN = 16;       // windowSize, Diff_of_Gauss.cpp:565
+constexpr int SIFT_PAD = 20;       // maxPadding, :571
+constexpr int SIFT_DESC = 128;     // 16 sub-regions x 8 bins
+
+struct SiftLevels {  // per Gaussian level of the octave (null / 0 when no keypoint uses it)
+    const uint8_t* gauss[VSLAM_NUM_LEVELS];
+    const float* kern[VSLAM_NUM_LEVELS];
+    int kn[VSLAM_NUM_LEVELS];
+};
+
+// grid = (keypoints), block = 256.  cs[q] = (cos, sin) of keypoint q's angle.
+__global__ __launch_bounds__(256) void k_sift_descriptors(const vslam_point* __restrict__ kps, const float2* __restrict__ cs, int n, SiftLevels lv,
+                                                           int gpitch, int rows, int cols, float* __restrict__ desc,
+                                                           uint8_t* __restrict__ defined) {
+    __shared__ float mag[SIFT_WIN * SIFT_WIN];   // magROI, then reused as the row-filtered image
+    __shared__ float rowf[SIFT_WIN * SIFT_WIN];
+    __shared__ float mw[SIFT_WIN * SIFT_WIN];    // magWeighted
+    __shared__ uint8_t bin[SIFT_WIN * SIFT_WIN];
+    __shared__ float d[SIFT_DESC];
+    __shared__ int bad_s;
+    const int q = blockIdx.x, t = threadIdx.x;
+    const vslam_point kp = kps[q];
+    const int level = kp.level;
+    if (t == 0) bad_s = 0;
+    __syncthreads();
+    const int i = t >> 4, j = t & 15;
+    const uint8_t* __restrict__ G = lv.gauss[level];
+    const int pr = rows + 2 * SIFT_PAD, pc = cols + 2 * SIFT_PAD;
+    float o = 0.0f;
+    {
+        const int cx = kp.col + SIFT_PAD, cy = kp.row + SIFT_PAD;  // :591
+        const int e = t;                                            // rotatedPoints[i * imgROI.rows + j], :545
+        const int iy = e / (SIFT_WIN + 1), jx = e - iy * (SIFT_WIN + 1);
+        const int rx = jx - SIFT_WIN / 2, ry = iy - SIFT_WIN / 2;  // pt - center
+        const float2 a = cs[q];
+        const float xr = (float)rx * a.x - (float)ry * a.y;        // rotation.cpp:22 (no FMA: -ffp-contract=off)
+        const float yr = (float)rx * a.y + (float)ry * a.x;        // :23
+        const int px = (int)xr + cx, py = (int)yr + cy;            // truncation; |xr|, |yr| < 16
+        const long long lin = (long long)px * pc + py;             // at<>(x, y): x is the row (:549-554)
+        if (lin < 0 || lin >= (long long)pr * pc) {
+            atomicOr(&bad_s, 1);
+        } else {
+            const int prow = (int)(lin / pc), pcol = (int)(lin - (long long)prow * pc);
+            const int r = clampi(prow - SIFT_PAD, 0, rows - 1), c = clampi(pcol - SIFT_PAD, 0, cols - 1);  // padOctave(20): replicate
+            const float gx = (float)((int)G[(size_t)r * gpitch + reflect101(c + 1, cols)] - (int)G[(size_t)r * gpitch + reflect101(c - 1, cols)]);
+            const float gy = (float)((int)G[(size_t)reflect101(r + 1, rows) * gpitch + c] - (int)G[(size_t)reflect101(r - 1, rows) * gpitch + c]);
+            const float xx = gx * gx, yy = gy * gy;
+            mag[t] = (float)sqrt((double)(xx + yy));  // cv::magnitude, correctly rounded (kernels_aux.hip.h)
+            o = fast_atan2_deg(gy, gx);               // cv::phase(..., true)
+        }
+    }
+    __syncthreads();
+    if (bad_s) {  // block-uniform
+        if (t < SIFT_DESC) desc[(size_t)q * SIFT_DESC + t] = 0.0f;
+        if (t == 0 && defined) defined[q] = 0;
+        return;
+    }
+    {
+        const float reductionCoeff = (float)8 / 360.0f;  // :114 with size = 8 (:631)
+        const int index = (int)(o * reductionCoeff);     // :126
+        bin[t] = (uint8_t)min(max(index, 0), 7);
+    }
+    const int kn = lv.kn[level], R = kn >> 1;
+    const float* __restrict__ k = lv.kern[level];
+    {   // row filter of ROI row i: s = k[0]*S[0]; s += k[m]*S[m], S = the row extended by reflect-101
+        const float* S = mag + i * SIFT_WIN;
+        float s0 = k[0] * S[reflect101(j - R, SIFT_WIN)];
+        for (int m = 1; m < kn; ++m) s0 += k[m] * S[reflect101(j + m - R, SIFT_WIN)];
+        rowf[t] = s0;
+    }
+    __syncthreads();
+    {   // symmetric column filter: s = k[R]*S(0); s += k[R+m]*(S(+m) + S(-m)), rows reflected likewise
+        float s0 = k[R] * rowf[i * SIFT_WIN + j];
+        for (int m = 1; m <= R; ++m)
+            s0 += k[R + m] * (rowf[reflect101(i + m, SIFT_WIN) * SIFT_WIN + j] + rowf[reflect101(i - m, SIFT_WIN) * SIFT_WIN + j]);
+        mw[t] = s0;
+    }
+    __syncthreads();
+    if (t < SIFT_DESC) {  // thread = (sub-region, bin); regions row-major, columns advance first (:637-652)
+        const int region = t >> 3, b = t & 7;
+        const int r0 = (region >> 2) * 4, c0 = (region & 3) * 4;
+        float h = 0.0f;
+        for (int u = r0; u < r0 + 4; ++u)
+            for (int v = c0; v < c0 + 4; ++v)
+                if (bin[u * SIFT_WIN + v] == b) h += mw[u * SIFT_WIN + v];
+        d[t] = h;
+    }
+    __syncthreads();
+    // *max_element (operator< scan: a NaN first element stays), c / max, min(c, 0.2f) as std::min,
+    // again c / max (:659-675).  Every thread scans the 128 values itself: same result everywhere.
+    float v = 0.0f;
+    if (t < SIFT_DESC) {
+        float mx = d[0];
+        for (int b = 1; b < SIFT_DESC; ++b) mx = mx < d[b] ? d[b] : mx;
+        v = d[t] / mx;
+        v = 0.2f < v ? 0.2f : v;
+    }
+    __syncthreads();
+    if (t < SIFT_DESC) d[t] = v;
+    __syncthreads();
+    if (t < SIFT_DESC) {
+        float mx = d[0];
+        for (int b = 1; b < SIFT_DESC; ++b) mx = mx < d[b] ? d[b] : mx;
+        desc[(size_t)q * SIFT_DESC + t] = v / mx;
+    }
+    if (t == 0 && defined) defined[q] = 1;
+}
+
+}  // namespace vslam

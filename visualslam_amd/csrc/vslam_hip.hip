@@ -21,6 +21,7 @@
 #include "kernels_orient.hip.h"
 #include "kernels_orient_batch.hip.h"
 #include "kernels_compact.hip.h"
+#include "kernels_sift.hip.h"
 #include "vslam_internal.h"
 
 using namespace vslam;
@@ -91,7 +92,7 @@ static const char* const kKernelNames =
     "k_resize_linear2x\nk_blur_h_generic\nk_blur_v_generic\n"
     "k_dog5\nk_resize_nearest_half\nk_extrema\nk_pyr_octave\n"
     "k_gauss_v_strip\nk_gauss_h_strip\nk_resize_linear2x_slide\nk_resize_nearest_half_v4\nk_extrema_w3\nk_localize_points\nk_points_localize_value\nk_orient_keypoints\nk_edge_response_windows\nk_level_gradients\nk_pack_rows\nk_edge_flags\nk_orient_survivors\n"
-    "k_harris_strip\nk_flag_count\nk_chunk_scan\nk_flag_scatter\nk_level_gradients";
+    "k_harris_strip\nk_flag_count\nk_chunk_scan\nk_flag_scatter\nk_level_gradients\nk_sift_descriptors";
 
 static std::pair<hipEvent_t, hipEvent_t>* timing_slot(vslam_ctx* c);
 
@@ -1242,6 +1243,66 @@ int vslam_filter_keypoints(vslam_ctx* c, const vslam_pyramid* py, int octave, co
     *count = total;
     const size_t m = std::min<size_t>(total, ocap);
     if (m) HIPCHK(c, hipMemcpy(out, d_out, m * sizeof(vslam_point), hipMemcpyDeviceToHost));
+    return VSLAM_OK;
+}
+
+int vslam_sift_descriptors(vslam_ctx* c, const vslam_pyramid* py, int octave, const vslam_point* kps, size_t n, float* desc,
+                           uint8_t* defined) {
+    TRY(bind_device(c));
+    ARGCHK(c, py && py->ctx == c && (kps || n == 0) && (desc || n == 0), "SIFT: bad arguments");
+    if (octave < 0 || octave >= py->layout.n_octaves) return fail(c, VSLAM_ERR_RANGE, "octave out of range");
+    ARGCHK(c, n <= 0x7fffffff / 128, "SIFT: too many keypoints");
+    if (n == 0) return VSLAM_OK;
+    const int rows = py->layout.rows[octave], cols = py->layout.cols[octave], pitch = py->layout.pitch[octave];
+    bool used[VSLAM_NUM_LEVELS] = {};
+    std::vector<float2> cs(n);
+    for (size_t i = 0; i < n; ++i) {
+        const vslam_point& k = kps[i];
+        // what the reference would throw on (vector::at(level)) or could not have produced is an error here
+        if (k.level < 0 || k.level >= VSLAM_NUM_LEVELS || k.octave != octave || k.col < -SIFT_PAD || k.row < -SIFT_PAD ||
+            k.col > cols + SIFT_PAD || k.row > rows + SIFT_PAD)
+            return fail(c, VSLAM_ERR_RANGE, "SIFT: keypoint outside the octave's data");
+        used[k.level] = true;
+        vslam_cos_sin_deg((float)k.value, &cs[i].x, &cs[i].y);  // keypoint.value holds the angle in degrees (:594)
+    }
+    std::vector<float> taps[VSLAM_NUM_LEVELS];
+    size_t tap_elems = 0;
+    for (int l = 0; l < VSLAM_NUM_LEVELS; ++l) {
+        if (!used[l]) continue;
+        const double sigma = 1.5 * py->info.sigma[octave][l];  // Diff_of_Gauss.cpp:616
+        if (!gauss_kernel_f32(gauss_ksize_f32(sigma), sigma, taps[l])) return fail(c, VSLAM_ERR_INVALID, "SIFT: bad blur kernel");
+        tap_elems += align_up(taps[l].size(), 64);
+    }
+    TRY(ws_reserve(c, ws_need(sizeof(vslam_point) * n) + ws_need(sizeof(float2) * n) + ws_need(sizeof(float) * 128 * n) + ws_need(n) +
+                          ws_need(4 * tap_elems)));
+    vslam_point* d_kps = ws_take<vslam_point>(c, n);
+    float2* d_cs = ws_take<float2>(c, n);
+    float* d_desc = ws_take<float>(c, 128 * n);
+    uint8_t* d_def = ws_take<uint8_t>(c, n);
+    float* d_taps = ws_take<float>(c, tap_elems);
+    if (!d_kps || !d_cs || !d_desc || !d_def || !d_taps) return fail(c, VSLAM_ERR_NOMEM, "workspace sizing error (sift)");
+    HIPCHK(c, hipMemcpyAsync(d_kps, kps, sizeof(vslam_point) * n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_cs, cs.data(), sizeof(float2) * n, hipMemcpyHostToDevice, c->stream));
+    SiftLevels lv{};
+    size_t toff = 0;
+    for (int l = 0; l < VSLAM_NUM_LEVELS; ++l) {
+        if (!used[l]) continue;
+        HIPCHK(c, hipMemcpyAsync(d_taps + toff, taps[l].data(), 4 * taps[l].size(), hipMemcpyHostToDevice, c->stream));
+        lv.gauss[l] = py->d_block + py->layout.octave_offset[octave] + (size_t)l * rows * pitch;
+        lv.kern[l] = d_taps + toff;
+        lv.kn[l] = (int)taps[l].size();
+        toff += align_up(taps[l].size(), 64);
+    }
+    LAUNCH(c, "k_sift_descriptors", k_sift_descriptors, dim3((unsigned)n), dim3(256), d_kps, d_cs, (int)n, lv, pitch, rows, cols, d_desc, d_def);
+    std::vector<uint8_t> h_def(n);
+    HIPCHK(c, hipMemcpyAsync(desc, d_desc, sizeof(float) * 128 * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(h_def.data(), d_def, n, hipMemcpyDeviceToHost, c->stream));
+    TRY(vslam_ctx_sync(c));
+    size_t undefined = 0;
+    for (size_t i = 0; i < n; ++i) undefined += h_def[i] == 0;
+    if (defined) std::memcpy(defined, h_def.data(), n);
+    if (undefined && !defined)
+        return fail(c, VSLAM_ERR_RANGE, "SIFT: " + std::to_string(undefined) + " keypoint window(s) leave the padded level (undefined in the reference)");
     return VSLAM_OK;
 }
 

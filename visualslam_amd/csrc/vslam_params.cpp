@@ -3,6 +3,7 @@
 // behaviour is isolated in one function so it can be corrected if an OpenCV build ever
 // becomes available (SURVEY.md section 7 "No external truth").
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <vector>
 
@@ -198,5 +199,39 @@ void vslam_params_default(vslam_params* p, int rows, int cols) {
 }
 
 int vslam_batch_layout_query(const vslam_params* p, vslam_batch_layout* out) { return vslam::make_layout(p, out); }
+
+void vslam_cos_sin_deg(float theta_deg, float* c, float* s) {
+    // rotation.cpp:5-7: theta * (CV_PI / 180.0f) -- double arithmetic, float result; :16 cos / sin
+    const float angle = (float)((double)theta_deg * (3.1415926535897932384626433832795 / (double)180.0f));
+    if (c) *c = (float)std::cos((double)angle);
+    if (s) *s = (float)std::sin((double)angle);
+}
+
+int vslam_rotated_window_points(int cx, int cy, int window, float theta_deg, int32_t* xy) {
+    if (!xy || window <= 0) return VSLAM_ERR_INVALID;
+    float c, s;
+    vslam_cos_sin_deg(theta_deg, &c, &s);
+    const int padding = window / 2;  // rotation.cpp:114
+    int q = 0;
+    for (int i = cy - padding; i <= cy + padding; ++i)      // :123
+        for (int j = cx - padding; j <= cx + padding; ++j, ++q) {  // :124
+            const int rx = j - cx, ry = i - cy;             // rotate_pt_CW, :19-27
+            const float a = (float)rx * c, b = (float)ry * s, d = (float)rx * s, e = (float)ry * c;
+            xy[2 * q] = (int)(a - b) + cx;
+            xy[2 * q + 1] = (int)(d + e) + cy;
+        }
+    return VSLAM_OK;
+}
+
+int vslam_descriptor_file_write(const char* path, const float* desc, size_t n) {
+    if (!path || (!desc && n) || n > 0x7fffffff) return VSLAM_ERR_INVALID;
+    std::FILE* f = std::fopen(path, "wb");
+    if (!f) return VSLAM_ERR_INVALID;
+    const int32_t head[3] = {(int32_t)n, 128, 24};  // vecSize, histoLength, sizeof(std::vector<float>) (:843-845)
+    bool ok = std::fwrite(head, sizeof(int32_t), 3, f) == 3;
+    if (n) ok = ok && std::fwrite(desc, sizeof(float) * 128, n, f) == n;
+    ok = (std::fclose(f) == 0) && ok;
+    return ok ? VSLAM_OK : VSLAM_ERR_INVALID;
+}
 
 }  // extern "C"

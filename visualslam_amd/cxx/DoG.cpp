@@ -1,7 +1,8 @@
-// Headless counterpart of the reference's `DoG` executable up to the end of the hot path
-// (Diff_of_Gauss.cpp:727-785): build the pyramid, run initialKeypointDetection (with its
-// FeaturePointLocalization filter) and filterKeypoints per octave.
-//   usage: DoG [image.pgm | WxH]
+// Headless counterpart of the reference's `DoG` executable (Diff_of_Gauss.cpp:727-863): build the
+// pyramid, run initialKeypointDetection (with its FeaturePointLocalization filter), filterKeypoints and
+// SIFT per octave, write featureDescriptors.dat.  Drawing / imshow (:796-832, :868-873) have no
+// counterpart.
+//   usage: DoG [image.pgm | WxH] [descriptor file, default featureDescriptors.dat]
 #include <chrono>
 #include <cstdio>
 
@@ -19,12 +20,16 @@ int main(int argc, char** argv) {
         GaussPyramid pyramid{img, numOctaves, pyr_sigma};  // :746
         const int windowSize = 3;       // :772
         std::vector<SLAM::point> all;
-        size_t perPointMismatch = 0, oriented = 0;
+        size_t perPointMismatch = 0, oriented = 0, undefined = 0;
+        std::vector<std::vector<float>> featureDescriptors_vec;  // :779
         std::printf("{\"exe\": \"DoG\", \"rows\": %d, \"cols\": %d, \"octaves\": [", img.rows, img.cols);
         for (int octave = 0; octave < pyramid.getNumOctaves(); ++octave) {  // :780
             std::vector<SLAM::point> keypoints, candidates, reducedKeypoints;
             initialKeypointDetection(keypoints, pyramid, octave, windowSize);  // :785
             filterKeypoints(pyramid, octave, keypoints, reducedKeypoints);     // :787
+            std::vector<unsigned char> defined;
+            SIFT(reducedKeypoints, featureDescriptors_vec, pyramid, octave, &defined);  // :791
+            for (unsigned char d : defined) undefined += d == 0;
             scaleSpaceCandidates(candidates, pyramid, octave, windowSize);
             std::printf("%s{\"octave\": %d, \"candidates\": %zu, \"keypoints\": %zu, \"oriented\": %zu}", octave ? ", " : "", octave,
                         candidates.size(), keypoints.size(), reducedKeypoints.size());
@@ -51,7 +56,11 @@ int main(int argc, char** argv) {
             all.insert(all.end(), keypoints.begin(), keypoints.end());
         }
         const auto t1 = std::chrono::steady_clock::now();
-        std::printf("], \"keypoints\": %zu, \"oriented\": %zu, \"per_point_mismatch\": %zu, \"ms\": %.3f}\n", all.size(), oriented, perPointMismatch, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        const std::string file_name = argc > 2 ? argv[2] : "featureDescriptors.dat";  // :838
+        writeFeatureDescriptors(file_name, featureDescriptors_vec);                    // :839-863
+        std::printf("], \"keypoints\": %zu, \"oriented\": %zu, \"descriptors\": %zu, \"undefined_windows\": %zu, \"descriptor_file\": \"%s\", \"per_point_mismatch\": %zu, \"ms\": %.3f}\n",
+                    all.size(), oriented, featureDescriptors_vec.size(), undefined, file_name.c_str(), perPointMismatch,
+                    std::chrono::duration<double, std::milli>(t1 - t0).count());
         return 0;
     } catch (const std::exception& e) {
         std::fprintf(stderr, "DoG: %s\n", e.what());

@@ -25,6 +25,21 @@ struct Size {
     bool operator==(const Size& o) const { return width == o.width && height == o.height; }
 };
 
+template <typename T>
+struct Point_ {
+    T x{}, y{};
+    Point_() = default;
+    Point_(T x_, T y_) : x(x_), y(y_) {}
+    Point_& operator-=(const Point_& o) {
+        x -= o.x, y -= o.y;
+        return *this;
+    }
+    bool operator==(const Point_& o) const { return x == o.x && y == o.y; }
+};
+typedef Point_<int> Point2i;
+typedef Point_<float> Point2f;
+typedef Point2i Point;
+
 class Mat {
 public:
     int rows = 0, cols = 0;

@@ -352,3 +352,73 @@ void StructureMatrix(cv::Mat& M, cv::Mat& Ix, cv::Mat& Iy, int padding, int i, i
     M.at<float>(1, 0) = m[1];
     M.at<float>(1, 1) = m[2];
 }
+
+// ---- Rotation (include/src/Rotation/rotation.cpp) ------------------------------------------------
+
+namespace SLAM {
+float Rotation::convertToRadians(float theta) {  // rotation.cpp:5-7
+    return (float)((double)theta * (3.1415926535897932384626433832795 / (double)180.0f));
+}
+const cv::Point2f Rotation::cos_sin_of_angle(float theta, bool degrees) {  // :9-17
+    if (degrees) {
+        float c, s;
+        vslam_cos_sin_deg(theta, &c, &s);
+        return cv::Point2f(c, s);
+    }
+    return cv::Point2f((float)std::cos((double)theta), (float)std::sin((double)theta));
+}
+cv::Point2i Rotation::rotate_pt_CW(const cv::Point2i& pt, const cv::Point2i& center, const cv::Point2f& angles) {  // :19-27
+    cv::Point2i rot(pt.x, pt.y);
+    rot -= center;
+    const float a = (float)rot.x * angles.x, b = (float)rot.y * angles.y, d = (float)rot.x * angles.y, e = (float)rot.y * angles.x;
+    const int x_r = (int)(a - b), y_r = (int)(d + e);
+    return cv::Point2i(x_r + center.x, y_r + center.y);
+}
+cv::Point2i Rotation::rotate_pt_CW(const cv::Point2i& pt, const cv::Point2i& center, float theta, bool degrees) {  // :53-63
+    return rotate_pt_CW(pt, center, cos_sin_of_angle(theta, degrees));
+}
+std::vector<cv::Point2i> Rotation::getRotatedWindowPoints(cv::Mat&, const cv::Point2i& center, int windowSize, float theta, bool degrees) {  // :112-130
+    std::vector<cv::Point2i> out;
+    if (windowSize <= 0) return out;
+    if (!degrees) {
+        const int padding = windowSize / 2;
+        const cv::Point2f angles = cos_sin_of_angle(theta, false);
+        for (int i = center.y - padding; i <= center.y + padding; ++i)
+            for (int j = center.x - padding; j <= center.x + padding; ++j) out.push_back(rotate_pt_CW(cv::Point2i(j, i), center, angles));
+        return out;
+    }
+    std::vector<int32_t> xy(2 * (size_t)(windowSize + 1) * (windowSize + 1));
+    if (vslam_rotated_window_points(center.x, center.y, windowSize, theta, xy.data()) != VSLAM_OK)
+        throw vslam::Error(VSLAM_ERR_INVALID, "getRotatedWindowPoints: bad arguments");
+    for (size_t q = 0; q < xy.size() / 2; ++q) out.emplace_back(xy[2 * q], xy[2 * q + 1]);
+    return out;
+}
+}  // namespace SLAM
+
+// ---- SIFT (Diff_of_Gauss.cpp:561-693) ---------------------------------------------------------------
+
+void SIFT(std::vector<SLAM::point>& reducedKeypoints, std::vector<std::vector<float>>& featureDescriptors_vec, GaussPyramid& pyramid,
+          int octave, std::vector<unsigned char>* defined) {
+    vslam_ctx* c = vslam::default_context();
+    const size_t n = reducedKeypoints.size();
+    if (defined) defined->assign(n, 1);
+    if (n == 0) return;
+    std::vector<float> desc(128 * n);
+    std::vector<unsigned char> def(n, 1);
+    vslam::check(vslam_sift_descriptors(c, pyramid.handle(), octave, reinterpret_cast<const vslam_point*>(reducedKeypoints.data()), n,
+                                        desc.data(), defined ? def.data() : nullptr),
+                 c, "SIFT");
+    for (size_t i = 0; i < n; ++i) featureDescriptors_vec.emplace_back(desc.begin() + 128 * i, desc.begin() + 128 * (i + 1));  // :678
+    if (defined) *defined = def;
+}
+
+void writeFeatureDescriptors(const std::string& file_name, const std::vector<std::vector<float>>& v) {
+    std::vector<float> flat;
+    flat.reserve(128 * v.size());
+    for (const auto& d : v) {
+        if (d.size() != 128) throw vslam::Error(VSLAM_ERR_INVALID, "writeFeatureDescriptors: a descriptor is not 128 floats");
+        flat.insert(flat.end(), d.begin(), d.end());
+    }
+    if (vslam_descriptor_file_write(file_name.c_str(), flat.data(), v.size()) != VSLAM_OK)
+        throw vslam::Error(VSLAM_ERR_INVALID, "writeFeatureDescriptors: cannot write " + file_name);
+}

@@ -13,6 +13,9 @@
 //   float computeEdgeResponse(const SLAM::point&, const Mat&, const Mat&)
 //   void filterKeypoints(GaussPyramid&, int, std::vector<SLAM::point>&, std::vector<SLAM::point>&)
 //                                                              Diff_of_Gauss.cpp:254
+//   void SIFT(std::vector<SLAM::point>&, std::vector<std::vector<float>>&, GaussPyramid&, int)
+//                                                              Diff_of_Gauss.cpp:561
+//   class SLAM::Rotation (the members the descriptor stage uses)   include/src/Rotation/rotation.h:11
 // plus the OpenCV calls on the path (vslamcv::GaussianBlur / Sobel / convertScaleAbs / resize).
 // StructureMatrix (:10) is also provided as a per-pixel call; HarrisCorner itself runs the whole
 // image in one kernel.  Errors of the C ABI surface as vslam::Error (the reference relies on cv::Exception).
@@ -48,6 +51,22 @@ struct point {  // Diff_of_Gauss.cpp:27-35
     int row = 0, col = 0, value = 0, padding = 0, octave = 0, level = 0;
 };
 static_assert(sizeof(point) == sizeof(vslam_point), "SLAM::point must stay six ints");
+}  // namespace SLAM
+
+namespace SLAM {
+// include/src/Rotation/rotation.h:8-24: the members on the descriptor path (SIFT -> getRotatedWindowPoints
+// -> rotate_pt_CW -> cos_sin_of_angle).  Host arithmetic, identical to the C ABI's
+// vslam_cos_sin_deg / vslam_rotated_window_points.
+class Transform {};
+class Rotation : public Transform {
+public:
+    static float convertToRadians(float theta);
+    static const cv::Point2f cos_sin_of_angle(float theta, bool degrees = true);
+    static cv::Point2i rotate_pt_CW(const cv::Point2i& pt, const cv::Point2i& center, const cv::Point2f& angles);
+    static cv::Point2i rotate_pt_CW(const cv::Point2i& pt, const cv::Point2i& center, float theta, bool degrees = true);
+    static std::vector<cv::Point2i> getRotatedWindowPoints(cv::Mat& I, const cv::Point2i& center, int windowSize, float theta,
+                                                           bool degrees = true);
+};
 }  // namespace SLAM
 
 namespace vslamcv {  // the OpenCV call sites of the hot path
@@ -137,3 +156,12 @@ float computeEdgeResponse(const SLAM::point& keypoint, const cv::Mat& grad_x, co
 // vector<SLAM::point>& reducedKeypoints), Diff_of_Gauss.cpp:301-372 (vslam_filter_keypoints).
 void filterKeypoints(GaussPyramid& pyramid, int octave, std::vector<SLAM::point>& keypoints,
                      std::vector<SLAM::point>& reducedKeypoints);
+// void SIFT(vector<SLAM::point>& reducedKeypoints, vector<vector<float>>& featureDescriptors_vec,
+// GaussPyramid&, int octave), Diff_of_Gauss.cpp:561-693 (vslam_sift_descriptors): appends one
+// 128-float descriptor per oriented keypoint.  A keypoint whose rotated window leaves the padded level
+// (the reference then reads foreign memory, :541) throws vslam::Error(VSLAM_ERR_RANGE) unless
+// `defined` is given, in which case it receives one flag per keypoint and the descriptor is all zero.
+void SIFT(std::vector<SLAM::point>& reducedKeypoints, std::vector<std::vector<float>>& featureDescriptors_vec,
+          GaussPyramid& pyramid, int octave, std::vector<unsigned char>* defined = nullptr);
+// featureDescriptors.dat exactly as Diff_of_Gauss.cpp:837-863 writes it (vslam_descriptor_file_write).
+void writeFeatureDescriptors(const std::string& file_name, const std::vector<std::vector<float>>& featureDescriptors_vec);
