@@ -21,86 +21,52 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s achievable
 
-# Algorithmic HBM bytes per frame attributed to each kernel of the batch (DESIGN.md
-# "Kernels"): the API-contract bytes the kernel is the one to read/write:
-# inputs read once, every returned image written once, intermediates not counted.  The
-# entries sum to 6N + 11*sumP = 133,617,600 B per 1080p frame.
+# Algorithmic HBM bytes per frame attributed to each kernel of the batch (DESIGN.md "Kernels"): the
+# API-contract bytes the kernel is the one to read / write: inputs read once, every
+# returned image written once, intermediates not counted.  The DoG path's read of the frame belongs to
+# the upsample kernel, so the entries sum to 6N + N + 11*sumP = 135,691,200 B per 1080p frame; the
+# fused figure of BASELINE config 4 counts the frame once (6N + 11*sumP = 133,617,600 B) and is what
+# `pipeline_hbm` reports.
 def kernel_algorithmic_bytes(L, rows, cols):
     N = rows * cols
     P = [L.rows[o] * L.cols[o] for o in range(L.n_octaves)]
     return {
         "k_harris_strip": 6 * N,                 # u8 frame in, f32 response + u8 NMS mask out (one pass)
-        "k_resize_linear2x_slide": N,               # DoG path's read of the frame
+        "k_resize_linear2x_slide": N,            # DoG path's read of the frame
         "k_pyr_octave": 11 * sum(P[:2]),         # 6 Gaussian + 5 DoG images of octaves 0-1 (LDS-tiled)
         "k_gauss_h_strip": 11 * sum(P[2:]),      # the same for the coarse octaves (strip kernels)
     }
 
 
-def _cpu_frames(rows, cols, n_oct, n, stream_id):
-    """Oracle on n frames of one synthetic stream (worker of the all-cores baseline)."""
-    import oracle
-    from visualslam_amd import synth
-
-    kp = 0
-    for f in range(n):
-        img = synth.frame_np(rows, cols, f, stream_id)
-        R = oracle.harris_response(img)
-        oracle.nms_strict(oracle.convert_scale_abs(R), 3)
-        kp += len(oracle.harris_keypoints(oracle.nms2(R, 5)[0]))
-        p = oracle.Pyramid(img, n_oct, 1.6)
-        for o in range(n_oct):
-            kp += len(p.extrema(o, 3, 8)[1])
-        p.close()
-    return kp
+def gauss_trimmed_width(capi, sigma):
+    """Width of the Gaussian kernel of one pyramid level after dropping its zero outer taps."""
+    t = capi.gauss_taps_q8(capi.gauss_ksize_u8(sigma), sigma)
+    nz = t.nonzero()[0]
+    return int(nz[-1] - nz[0] + 1)
 
 
 def cpu_baseline(rows, cols, n_oct, sample_frames):
-    """Time the CPU oracle (single thread, like the reference) on a bounded sample."""
-    import numpy as np
-
+    """Time the CPU oracle on a bounded sample of the same workload: 1 thread (the reference is
+    single-threaded: the reported baseline) and all host CPUs of this box's share with OpenMP over
+    frames inside the oracle (SURVEY 8d ii)."""
     import oracle
     from visualslam_amd import synth
 
     oracle.build()
     frames = synth.frames_np(sample_frames, rows, cols, stream_id=0)
-    kp = 0
     t0 = time.perf_counter()
-    for f in range(sample_frames):
-        R = oracle.harris_response(frames[f])
-        oracle.nms_strict(oracle.convert_scale_abs(R), 3)
-        kp += len(oracle.harris_keypoints(oracle.nms2(R, 5)[0]))
-        p = oracle.Pyramid(frames[f], n_oct, 1.6)
-        for o in range(n_oct):
-            kp += len(p.extrema(o, 3, 8)[1])
-        p.close()
+    kp = oracle.baseline_frames(frames, n_oct, threads=1)
     dt = time.perf_counter() - t0
-    # secondary figure (BASELINE.md section 3 ii): all host cores, independent worker processes
-    # (plain subprocesses with a hard timeout; the parent holds a HIP context, so no fork)
     allcores = None
     try:
-        import subprocess
-
-        workers = min(os.cpu_count() or 1, 64)
-        if workers > 1:
-            per = 2
-            code = ("import sys; sys.path.insert(0, %r); import bench; "
-                    "print(bench._cpu_frames(%d, %d, %d, %d, int(sys.argv[1])))" % (ROOT, rows, cols, n_oct, per))
+        cores = min(len(os.sched_getaffinity(0)), 64)
+        if cores > 1:
+            many = synth.frames_np(2 * cores, rows, cols, stream_id=0)
             t1 = time.perf_counter()
-            procs = [subprocess.Popen([sys.executable, "-c", code, str(w)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
-                     for w in range(workers)]
-            ok = 0
-            for pr in procs:
-                try:
-                    pr.communicate(timeout=max(5.0, 180.0 - (time.perf_counter() - t1)))
-                    ok += pr.returncode == 0
-                except subprocess.TimeoutExpired:
-                    pr.kill()
+            oracle.baseline_frames(many, n_oct, threads=cores)
             d2 = time.perf_counter() - t1
-            if ok == workers:
-                allcores = {"value": workers * per / d2, "unit": "frames/s", "cores": workers,
-                            "sample": f"{workers * per} frames, {workers} processes x {per} frames (includes interpreter start-up)"}
-            else:
-                allcores = {"error": f"{workers - ok} of {workers} workers failed or timed out"}
+            allcores = {"value": len(many) / d2, "unit": "frames/s", "cores": cores,
+                        "sample": f"{len(many)} frames, OpenMP over frames in oracle/vslam_oracle.c ({cores} threads)"}
     except Exception as e:  # the single-thread figure is the reported baseline
         allcores = {"error": repr(e)}
     return {
@@ -130,6 +96,7 @@ def main():
     ap.add_argument("--orient", type=int, default=0,
                     help="1: also run filterKeypoints on every frame's keypoint list (SURVEY 8f row 3); implies --localize 1")
     ap.add_argument("--cpu-sample", type=int, default=6, help="frames in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--modes", type=int, default=1, help="1: also time the localize / orient list modes (the `modes` object)")
     ap.add_argument("--stream", choices=["side", "null"], default="side",
                     help="stream of the whole job: a torch side stream (default) or torch's default (NULL) stream")
     args = ap.parse_args()
@@ -181,33 +148,9 @@ def main():
     job_stream = torch.cuda.Stream(device=dev) if args.stream == "side" else torch.cuda.default_stream(dev)
     torch.cuda.set_stream(job_stream)
     ctx = capi.Context(local_rank_dev, torch.cuda.current_stream().cuda_stream)
-    p = capi.default_params(rows, cols, n_octaves=args.octaves, localize=1 if args.orient else args.localize, orient=args.orient)
-    L = capi.batch_layout(p)
-
+    cdev = dev if backend == "nccl" else torch.device("cpu")  # where the collectives' tensors live
     # one camera stream per GPU: stream_id = rank
     frames = synth.frames_torch(n, rows, cols, stream_id=rank, device=dev)
-    out = dict(
-        response=torch.empty((n, rows, cols), dtype=torch.float32, device=dev),
-        nms_mask=torch.empty((n, rows, cols), dtype=torch.uint8, device=dev),
-        harris_kps=torch.empty((n, p.harris_cap, 3), dtype=torch.int32, device=dev),
-        harris_counts=torch.zeros(n, dtype=torch.int32, device=dev),
-        pyramid=torch.empty((n, L.pyramid_frame_bytes), dtype=torch.uint8, device=dev),
-        extrema_bits=torch.empty((n, L.bits_frame_words), dtype=torch.int64, device=dev),
-        dog_points=torch.empty((n, p.dog_cap, 6), dtype=torch.int32, device=dev),
-        dog_counts=torch.zeros(n, dtype=torch.int32, device=dev),
-    )
-    if args.orient:
-        out["oriented_points"] = torch.empty((n, p.oriented_cap, 6), dtype=torch.int32, device=dev)
-        out["oriented_counts"] = torch.zeros(n, dtype=torch.int32, device=dev)
-    cdev = dev if backend == "nccl" else torch.device("cpu")  # where the collectives' tensors live
-    counts_local = torch.zeros(2, dtype=torch.int64, device=dev)
-    counts_all = torch.zeros((world, 2), dtype=torch.int64, device=cdev)
-
-    def step():
-        ctx.detect_batch(p, frames, **out)
-        counts_local[0] = out["harris_counts"].sum()
-        counts_local[1] = out["dog_counts"].sum()
-        sharding.gather_counts(counts_local.to(cdev), counts_all)  # the one collective of the path: 16 B per rank over RCCL
 
     def fence():
         torch.cuda.synchronize()
@@ -215,62 +158,119 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    algo = kernel_algorithmic_bytes(L, rows, cols)
-    kname = args.kernel or "k_pyr_octave"
-    fence()
-    ctx.kernel_timing_enable(kname)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    launches, kms = ctx.kernel_timing_read()
-    ctx.kernel_timing_enable(None)
+    shared = {}  # the big output buffers are shared by the modes (the pyramids alone are 31 GB)
 
-    tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
-    if use_dist:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
-    totals = counts_all.sum(0).tolist()
-    overflow = bool((out["harris_counts"] > p.harris_cap).any() or (out["dog_counts"] > p.dog_cap).any())
+    def run_mode(localize, orient, steps, warmup, kname):
+        """K timed steps of one list mode; returns per-mode results (times: max over ranks)."""
+        p = capi.default_params(rows, cols, n_octaves=args.octaves, localize=1 if orient else localize, orient=orient)
+        L = capi.batch_layout(p)
+        if not shared:
+            shared.update(
+                response=torch.empty((n, rows, cols), dtype=torch.float32, device=dev),
+                nms_mask=torch.empty((n, rows, cols), dtype=torch.uint8, device=dev),
+                harris_kps=torch.empty((n, p.harris_cap, 3), dtype=torch.int32, device=dev),
+                harris_counts=torch.zeros(n, dtype=torch.int32, device=dev),
+                pyramid=torch.empty((n, L.pyramid_frame_bytes), dtype=torch.uint8, device=dev),
+                extrema_bits=torch.empty((n, L.bits_frame_words), dtype=torch.int64, device=dev),
+                dog_points=torch.empty((n, p.dog_cap, 6), dtype=torch.int32, device=dev),
+                dog_counts=torch.zeros(n, dtype=torch.int32, device=dev),
+            )
+        out = dict(shared)
+        if orient:
+            out["oriented_points"] = torch.empty((n, p.oriented_cap, 6), dtype=torch.int32, device=dev)
+            out["oriented_counts"] = torch.zeros(n, dtype=torch.int32, device=dev)
+            out["oriented_survivors"] = torch.zeros(n, dtype=torch.int32, device=dev)
+        counts_local = torch.zeros(2, dtype=torch.int64, device=dev)
+        counts_all = torch.zeros((world, 2), dtype=torch.int64, device=cdev)
+
+        def step():
+            ctx.detect_batch(p, frames, **out)
+            counts_local[0] = out["harris_counts"].sum()
+            counts_local[1] = out["dog_counts"].sum()
+            sharding.gather_counts(counts_local.to(cdev), counts_all)  # the one collective of the path: 16 B per rank over RCCL
+
+        for _ in range(warmup):
+            step()
+        fence()
+        if kname:
+            ctx.kernel_timing_enable(kname)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        fence()
+        dt = time.perf_counter() - t0
+        launches, kms = ctx.kernel_timing_read() if kname else (0, 0.0)
+        ctx.kernel_timing_enable(None)
+        # max over ranks of the time; sums over ranks of the list flags
+        red = torch.tensor([dt], dtype=torch.float64, device=cdev)
+        flags = torch.tensor([int((out["harris_counts"] > p.harris_cap).any() or (out["dog_counts"] > p.dog_cap).any()),
+                              int(out["oriented_counts"].sum()) if orient else 0,
+                              int((out["oriented_survivors"] > p.oriented_cap).any()) if orient else 0], dtype=torch.int64, device=cdev)
+        if use_dist:
+            dist.all_reduce(red, op=dist.ReduceOp.MAX)
+            dist.all_reduce(flags, op=dist.ReduceOp.SUM)
+        totals = counts_all.sum(0).tolist()
+        fl = flags.tolist()
+        return {"p": p, "L": L, "dt": float(red.item()), "launches": launches, "kms": kms, "harris": totals[0], "dog": totals[1],
+                "list_overflow": bool(fl[0]), "oriented": fl[1], "oriented_truncated": bool(fl[2])}
+
+    kname = args.kernel or "k_pyr_octave"
+    main = run_mode(args.localize, args.orient, args.steps, args.warmup, kname)
+    p, L, dt, launches, kms = main["p"], main["L"], main["dt"], main["launches"], main["kms"]
+    # the list modes the reference's own functions produce (initialKeypointDetection appends the
+    # FeaturePointLocalization survivors, Diff_of_Gauss.cpp:290; filterKeypoints the oriented points,
+    # :787), measured in the same process on the same frames with fewer steps
+    modes = None
+    if args.modes and args.octaves > 0 and not (args.localize or args.orient):
+        modes = {}
+        for name, (lz, orr) in (("localize", (1, 0)), ("orient", (1, 1))):
+            m = run_mode(lz, orr, max(2, args.steps // 2), 1, None)
+            ms = max(2, args.steps // 2)
+            modes[name] = {"frames_per_sec": n * world * ms / m["dt"], "ms_per_step": m["dt"] / ms * 1e3, "steps": ms,
+                           "dog_points_per_step": m["dog"], "list_overflow": m["list_overflow"],
+                           **({"oriented_points_per_step": m["oriented"], "oriented_truncated": m["oriented_truncated"]} if orr else {})}
 
     if rank == 0:
+        algo = kernel_algorithmic_bytes(L, rows, cols)
         total_frames = n * world * args.steps
         fps = total_frames / dt
-        kp_per_step = totals[0] + totals[1]
+        kp_per_step = main["harris"] + main["dog"]
         bytes_frame = L.algorithmic_bytes_harris + L.algorithmic_bytes_dog - rows * cols  # fused: input counted once
         roof = None
         if launches and kms > 0:
             ach = algo.get(kname, 0) * n * args.steps / (kms * 1e-3) / 1e9
-            # measured HBM bytes per launch from the committed PMC passes (profiles/traffic.json,
-            # made by tools/pmc_summary.py), scaled to this run's frames per launch
-            traffic = None
+            # HBM bytes per launch measured by rocprofv3 PMC passes of this same command (separate
+            # --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled per MI355X_MICROARCH.md) and
+            # committed as profiles/traffic.json; counters cannot be read from inside this process,
+            # so the figure is the committed profile's, scaled to this run's frames per launch
+            traffic = tsrc = None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tpath):
-                t = json.load(open(tpath)).get(kname)
+                tj = json.load(open(tpath))
+                t = tj.get(kname)
                 if t:
                     traffic = t["hbm_bytes_per_frame"] * n * args.steps / launches
+                    tsrc = "profiles/traffic.json: " + tj.get("_round", "rocprofv3 --pmc passes")
             roof = {
                 "kernel": kname, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBPS, "traffic": traffic,
+                "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": tsrc,
+                "limited_by": "valu-dot issue rate, see roofline_valu" if kname == "k_pyr_octave" else None,
                 "launches": launches, "avg_launch_ms": kms / launches,
                 "algorithmic_bytes_per_frame": algo.get(kname, 0),
                 "algorithmic_bytes_per_launch": algo.get(kname, 0) * n * args.steps / launches,
             }
-        # secondary view of the same kernel: it is bound by VALU issue of the packed dot
-        # instructions, not by HBM.  Algorithmic dot instructions per pixel =
-        # sum over levels of n/4 (v_dot4_u32_u8, vertical) + n/2 (v_dot2_u32_u16, horizontal) with
-        # the zero-trimmed kernel widths n; peak = 32.8e12 lane-instr/s measured by
-        # tools/ubench_valu.hip (4.3 cycles per wave64 dot instruction per SIMD).
+        # second roof of the same kernel: it is bound by VALU issue of the packed dot instructions,
+        # not by HBM (DESIGN.md section 5).  Algorithmic dot instructions per pixel = sum over levels of
+        # n/4 (v_dot4_u32_u8, vertical) + n/2 (v_dot2_u32_u16, horizontal) with the zero-trimmed
+        # kernel widths n; peak = measured issue rate of a wave64 dot instruction, 2.0 ns per SIMD on
+        # 1024 SIMDs = 32.8e12 lane-instr/s (tools/ubench_valu.hip, tools/ubench_valu2.hip).
         valu = None
-        if roof and kname == "k_pyr_octave" and args.octaves >= 2 and (rows, cols) == (1080, 1920):
-            widths = [[9, 13, 15, 19, 23, 29], [19, 23, 29, 37, 45, 57]]
+        if roof and kname == "k_pyr_octave" and args.octaves >= 2:
+            widths = [[gauss_trimmed_width(capi, capi.sigma_at(p.sigma0, o, l)) for l in range(6)] for o in range(2)]
             per_frame = sum(0.75 * sum(w) * L.rows[o] * L.cols[o] for o, w in enumerate(widths))
             ach = per_frame * n * args.steps / (kms * 1e-3)
             valu = {"bound": "valu-dot", "achieved": ach / 1e12, "peak": 32.8, "unit": "T lane-instr/s",
-                    "frac": ach / 32.8e12, "algorithmic_dot_instr_per_frame": per_frame}
+                    "frac": ach / 32.8e12, "algorithmic_dot_instr_per_frame": per_frame, "trimmed_widths": widths}
         line = {
             "metric": "frames/sec @1080p (Harris + DoG keypoint detection)",
             "value": fps,
@@ -290,9 +290,12 @@ def main():
                 "frames_per_gpu": n, "rows": rows, "cols": cols, "octaves": args.octaves, "localize": p.localize, "orient": args.orient,
                 "parallelism": f"frames sharded 1 stream/GPU x{world}; RCCL all-gather of counts only",
             },
+            "distributed": {"initialized": bool(use_dist), "world_size": dist.get_world_size() if use_dist else 1,
+                            "backend": dist.get_backend() if use_dist else None, "ranks_gathered": int(world)},
             "keypoints_per_sec": kp_per_step * args.steps / dt,
-            "keypoints_per_step": {"harris": totals[0], "dog": totals[1], "list_overflow": overflow,
-                                   **({"oriented_rank0": int(out["oriented_counts"].sum())} if args.orient else {})},
+            "keypoints_per_step": {"harris": main["harris"], "dog": main["dog"], "list_overflow": main["list_overflow"],
+                                   **({"oriented": main["oriented"], "oriented_truncated": main["oriented_truncated"]} if args.orient else {})},
+            "modes": modes,
             "pipeline_hbm": {
                 "algorithmic_bytes_per_frame": bytes_frame,
                 "achieved_GBps": bytes_frame * fps / world / 1e9,
