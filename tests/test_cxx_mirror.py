@@ -22,8 +22,41 @@ def built():
 
 
 def test_cxx_mirror_builds(built):
-    for exe in ("Harris", "DoG", "Pyramid_Test"):
+    for exe in ("Harris", "DoG", "Pyramid_Test", "RotateImgTest"):
         assert os.access(os.path.join(built, exe), os.X_OK)
+
+
+def test_rotate_img_test_runs_without_a_gpu(built):
+    # the Rotation members on the descriptor path are host arithmetic (rotation.cpp:5-27,112-130)
+    r = subprocess.run([os.path.join(built, "RotateImgTest")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["exe"] == "RotateImgTest" and out["points"] == 289 and out["failures"] == 0
+
+
+def test_cmake_build_registers_the_reference_targets(built, tmp_path):
+    # CMake >= 3.21 + CTest with the reference's target names (KeyPointDetection/CMakeLists.txt:7-13,
+    # include/CMakeLists.txt:1-5, tests/CMakeLists.txt:1-5); the HIP library is taken prebuilt here
+    from visualslam_amd import capi
+
+    b = str(tmp_path / "build")
+    src = os.path.join(ROOT, "visualslam_amd", "cxx")
+    r = subprocess.run(["cmake", "-S", src, "-B", b, "-DVSLAM_PREBUILT_LIB=" + capi.LIB_PATH], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    r = subprocess.run(["cmake", "--build", b, "-j", "4"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    for exe in ("Harris", "DoG", "Pyramid_Test", "RotateImgTest"):
+        assert os.access(os.path.join(b, exe), os.X_OK)
+    r = subprocess.run(["ctest", "-N"], capture_output=True, text=True, timeout=120, cwd=b)
+    for name in ("Harris", "DoG", "Pyramid_Test", "RotateImgTest"):
+        assert ": " + name in r.stdout, r.stdout
+    r = subprocess.run(["ctest", "-R", "RotateImgTest", "--output-on-failure"], capture_output=True, text=True, timeout=120, cwd=b)
+    assert r.returncode == 0, r.stdout + r.stderr
+    import torch
+
+    if torch.cuda.is_available():  # the GPU-backed tests of the same CTest project
+        r = subprocess.run(["ctest", "--output-on-failure"], capture_output=True, text=True, timeout=600, cwd=b)
+        assert r.returncode == 0 and "100% tests passed" in r.stdout, r.stdout + r.stderr
 
 
 def test_executables_fail_loudly_without_gpu(built):
