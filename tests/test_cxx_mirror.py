@@ -52,11 +52,14 @@ def test_cmake_build_registers_the_reference_targets(built, tmp_path):
         assert ": " + name in r.stdout, r.stdout
     r = subprocess.run(["ctest", "-R", "RotateImgTest", "--output-on-failure"], capture_output=True, text=True, timeout=120, cwd=b)
     assert r.returncode == 0, r.stdout + r.stderr
-    import torch
+    return b
 
-    if torch.cuda.is_available():  # the GPU-backed tests of the same CTest project
-        r = subprocess.run(["ctest", "--output-on-failure"], capture_output=True, text=True, timeout=600, cwd=b)
-        assert r.returncode == 0 and "100% tests passed" in r.stdout, r.stdout + r.stderr
+
+@pytest.mark.gpu
+def test_ctest_project_passes_on_the_gpu(built, tmp_path):
+    b = test_cmake_build_registers_the_reference_targets(built, tmp_path)
+    r = subprocess.run(["ctest", "--output-on-failure"], capture_output=True, text=True, timeout=600, cwd=b)
+    assert r.returncode == 0 and "100% tests passed" in r.stdout, r.stdout + r.stderr
 
 
 def test_executables_fail_loudly_without_gpu(built):
