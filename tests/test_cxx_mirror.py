@@ -34,7 +34,7 @@ def test_rotate_img_test_runs_without_a_gpu(built):
     assert out["exe"] == "RotateImgTest" and out["points"] == 289 and out["failures"] == 0
 
 
-def test_cmake_build_registers_the_reference_targets(built, tmp_path):
+def _cmake_project(built, tmp_path):
     # CMake >= 3.21 + CTest with the reference's target names (KeyPointDetection/CMakeLists.txt:7-13,
     # include/CMakeLists.txt:1-5, tests/CMakeLists.txt:1-5); the HIP library is taken prebuilt here
     from visualslam_amd import capi
@@ -55,9 +55,13 @@ def test_cmake_build_registers_the_reference_targets(built, tmp_path):
     return b
 
 
+def test_cmake_build_registers_the_reference_targets(built, tmp_path):
+    _cmake_project(built, tmp_path)
+
+
 @pytest.mark.gpu
 def test_ctest_project_passes_on_the_gpu(built, tmp_path):
-    b = test_cmake_build_registers_the_reference_targets(built, tmp_path)
+    b = _cmake_project(built, tmp_path)
     r = subprocess.run(["ctest", "--output-on-failure"], capture_output=True, text=True, timeout=600, cwd=b)
     assert r.returncode == 0 and "100% tests passed" in r.stdout, r.stdout + r.stderr
 
