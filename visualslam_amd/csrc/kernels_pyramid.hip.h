@@ -11,7 +11,7 @@
 //   pass 2 (horizontal) acc    = sum_k t[k]*h(y, x-r+k)     u16 x u16 taps -> v_dot2_u32_u16
 // (all quantised taps are <= 64 for sigma >= 1.6, h <= 65280, acc < 2^24).  No MFMA.
 //
-// Data layout in LDS (one 256-thread workgroup = one TW x TH output tile):
+// Data layout in LDS (one 256-thread workgroup = one TW x TH output tile, 128 x 64 or 256 x 32):
 //   rp  [(TH+2R)/4][RWP]  dwords: the base tile with halo R, BYTE-TRANSPOSED so that one dword
 //        holds 4 vertically adjacent pixels of one column -- the operand shape of a vertical
 //        dot4.  Filled once per tile (v_perm 4x4 transposes); image borders are resolved at
@@ -60,7 +60,7 @@ struct PyrCfg {
     static constexpr int delta(int l) { return (R - r(l)) & 3; }
     static constexpr int A(int l) { return (R - r(l)) & ~3; }
     static constexpr int ncg(int l) { return (TW + 2 * r(l) + delta(l) + 3) / 4; }   // h column groups of 4
-    static constexpr int m1(int l) { return ((delta(l) + 7 + n(l) - 1) >> 2) + 1; } // rp dwords per pass-1 item column (8 rows)
+    static constexpr int m1(int l) { return ((delta(l) + 3 + n(l) - 1) >> 2) + 1; } // rp dwords per pass-1 item column (4 rows)
     static constexpr int pmax(int l) { return (7 + delta(l) + 2 * r(l)) / 2; }      // last u16 pair a pass-2 item reads
     static constexpr int nb(int l) { return pmax(l) / 4 + 1; }                      // b128 reads per row
     static constexpr int hpp_l(int l) { return cmax(2 * ncg(l), TW / 2 - 4 + 4 * nb(l)); }
@@ -95,20 +95,22 @@ __device__ __forceinline__ void pyr_level(const PyrTaps<CFG>* __restrict__ taps,
     const uint32_t* __restrict__ t4 = &taps->t4[L][0][0] + z1;
     const uint4* __restrict__ rp4 = reinterpret_cast<const uint4*>(rp);
 
-    // ---- pass 1: vertical, item = 4 h-columns x 8 rows -------------------------------------
-    for (int it = tid; it < NCG * (TH / 8); it += 256) {
-        const int cg = it % NCG, ro = it / NCG;
-        uint32_t acc[8][4];
+    // ---- pass 1: vertical, item = 4 h-columns x 4 rows -------------------------------------
+    // (4-row items: the (TW + 2r)/4 x TH/4 items of a level fill 8.3 - 10 waves, so the partly
+    // filled last wave costs 0 - 8 % of the pass; with 8-row items it was 5 waves for 4.25 - 5)
+    for (int it = tid; it < NCG * (TH / 4); it += 256) {
+        const int cg = it % NCG, rq = it / NCG;
+        uint32_t acc[4][4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int c = 0; c < 4; ++c) acc[j][c] = 0;
-        const uint4* col = rp4 + (2 * ro + A / 4) * (RWP / 4) + cg + A / 4;
+        const uint4* col = rp4 + (rq + A / 4) * (RWP / 4) + cg + A / 4;
 #pragma unroll
         for (int m = 0; m < M; ++m) {
             const uint4 v = col[m * (RWP / 4)];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < 4; ++j) {
                 const int s = dl + j, o = s & 3, mm = m - (s >> 2);
                 if (mm >= 0 && mm <= ((o + n - 1) >> 2)) {
                     const uint32_t t = t4[o * CFG::T4M + mm];
@@ -120,11 +122,11 @@ __device__ __forceinline__ void pyr_level(const PyrTaps<CFG>* __restrict__ taps,
             }
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < 4; ++j) {
             uint2 w;
             w.x = __builtin_amdgcn_perm(acc[j][1], acc[j][0], 0x05040100);  // (acc0, acc1) as u16 pair: one v_perm, not shift + or
             w.y = __builtin_amdgcn_perm(acc[j][3], acc[j][2], 0x05040100);
-            *reinterpret_cast<uint2*>(hp + (8 * ro + j) * HPP + 2 * cg) = w;
+            *reinterpret_cast<uint2*>(hp + (4 * rq + j) * HPP + 2 * cg) = w;
         }
     }
     __syncthreads();
@@ -320,7 +322,12 @@ static void pyr_pack_taps(const uint16_t* const t[6], PyrTaps<CFG>& out) {
 
 // The reference's fixed pyramid (sigma0 = 1.6, Diff_of_Gauss.cpp:743): the zero-trimmed widths
 // of the SURVEY.md Appendix C kernels (11,13,17,21,25,31 / 21,25,31,39,49,63) for octaves 0, 1.
+// Two tile shapes per tap set: 256 x 32 halves the halo share of the vertical pass ((TW + 2r)/TW) and
+// is taken when it covers the octave with no more tile area than 128 x 64 (3840 x 2160: 15 x 68 tiles
+// either way); 1920 x 1080 is 7.5 tiles of 256 wide, so octave 1 of a 1080p frame stays at 128 x 64.
 using PyrCfgOct0 = PyrCfg<128, 64, 9, 13, 15, 19, 23, 29>;
 using PyrCfgOct1 = PyrCfg<128, 64, 19, 23, 29, 37, 45, 57>;
+using PyrCfgOct0W = PyrCfg<256, 32, 9, 13, 15, 19, 23, 29>;
+using PyrCfgOct1W = PyrCfg<256, 32, 19, 23, 29, 37, 45, 57>;
 
 }  // namespace vslam

@@ -498,9 +498,9 @@ static int enqueue_pyr_octave(vslam_ctx* c, double sigma0, int o, const OctPlan&
         void* d = nullptr;
         HIPCHK(c, hipMalloc(&d, sizeof(PyrTaps<CFG>)));
         HIPCHK(c, hipMemcpy(d, host.data(), sizeof(PyrTaps<CFG>), hipMemcpyHostToDevice));
-        TRY(raise_dyn_lds(c, reinterpret_cast<const void*>(&k_pyr_octave<CFG>)));
         it = c->tile_taps.emplace(key, d).first;
     }
+    TRY(raise_dyn_lds(c, reinterpret_cast<const void*>(&k_pyr_octave<CFG>)));  // once per kernel (both tile shapes share the taps)
     const PyrTaps<CFG>* taps = static_cast<const PyrTaps<CFG>*>(it->second);
     const dim3 grid((cols + CFG::TW - 1) / CFG::TW, (rows + CFG::TH - 1) / CFG::TH, nf);
     {
@@ -536,8 +536,14 @@ static int enqueue_dog(vslam_ctx* c, const vslam_params& p, const vslam_batch_la
         const bool fuse_next = has_next && pl.path != OctPath::Generic;
         uint8_t* nb = fuse_next ? s.bases + s.base_off[o + 1] : nullptr;
         const int nr = has_next ? L.rows[o + 1] : 0, nc = has_next ? L.cols[o + 1] : 0, np = has_next ? L.pitch[o + 1] : 0;
-        if (pl.path == OctPath::Tile0)
+        // tile shape: the wide tile when it needs no more tile area than the tall one
+        const bool wide = (long)((cols + 255) / 256) * ((rows + 31) / 32) <= (long)((cols + 127) / 128) * ((rows + 63) / 64);
+        if (pl.path == OctPath::Tile0 && wide)
+            TRY(enqueue_pyr_octave<PyrCfgOct0W>(c, p.sigma0, o, pl, base, s.bases_frame, oct, pframe, rows, cols, pitch, nf, nb, s.bases_frame, nr, nc, np));
+        else if (pl.path == OctPath::Tile0)
             TRY(enqueue_pyr_octave<PyrCfgOct0>(c, p.sigma0, o, pl, base, s.bases_frame, oct, pframe, rows, cols, pitch, nf, nb, s.bases_frame, nr, nc, np));
+        else if (pl.path == OctPath::Tile1 && wide)
+            TRY(enqueue_pyr_octave<PyrCfgOct1W>(c, p.sigma0, o, pl, base, s.bases_frame, oct, pframe, rows, cols, pitch, nf, nb, s.bases_frame, nr, nc, np));
         else if (pl.path == OctPath::Tile1)
             TRY(enqueue_pyr_octave<PyrCfgOct1>(c, p.sigma0, o, pl, base, s.bases_frame, oct, pframe, rows, cols, pitch, nf, nb, s.bases_frame, nr, nc, np));
         else if (pl.path == OctPath::Strip)
