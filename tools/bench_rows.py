@@ -1,5 +1,5 @@
 """Per-image latency of the SURVEY section 8f rows (host-buffer C ABI, PCIe copies included):
-pyramid build, initialKeypointDetection (+FeaturePointLocalization), filterKeypoints.
+pyramid build, initialKeypointDetection (+FeaturePointLocalization), filterKeypoints, SIFT.
 
     python tools/bench_rows.py [--rows 1080 --cols 1920 --reps 20] > profiles/rNN_rows.json
 """
@@ -40,9 +40,11 @@ def main():
             ms_kp, (kp, n) = timed(lambda: p.keypoints(o, 3, cap=1 << 18), a.reps)
             ms_cand, (_, cand, nc) = timed(lambda: p.extrema(o, 3, 8, cap=1 << 18), a.reps)
             ms_f, (fk, nf) = timed(lambda: p.filter_keypoints(o, kp, cap=1 << 18), a.reps)
+            ms_s, (desc, ok) = timed(lambda: p.sift_descriptors(o, fk), a.reps) if nf else (0.0, (None, []))
             rec["octaves"].append({"octave": o, "candidates_ge8": int(nc), "keypoints": int(n), "oriented": int(nf),
-                                   "extrema_ms": ms_cand, "keypoints_ms": ms_kp, "filter_keypoints_ms": ms_f})
-        rec["total_ms"] = ms_build + sum(r["keypoints_ms"] + r["filter_keypoints_ms"] for r in rec["octaves"])
+                                   "descriptors_defined": int(sum(ok)), "extrema_ms": ms_cand, "keypoints_ms": ms_kp,
+                                   "filter_keypoints_ms": ms_f, "sift_ms": ms_s})
+        rec["total_ms"] = ms_build + sum(r["keypoints_ms"] + r["filter_keypoints_ms"] + r["sift_ms"] for r in rec["octaves"])
         out["frames"][kind] = rec
         p.close()
     ctx.close()
