@@ -160,7 +160,7 @@ def main():
 
     shared = {}  # the big output buffers are shared by the modes (the pyramids alone are 31 GB)
 
-    def run_mode(localize, orient, steps, warmup, kname):
+    def run_mode(localize, orient, steps, warmup, kname, describe=0):
         """K timed steps of one list mode; returns per-mode results (times: max over ranks)."""
         p = capi.default_params(rows, cols, n_octaves=args.octaves, localize=1 if orient else localize, orient=orient)
         L = capi.batch_layout(p)
@@ -180,6 +180,11 @@ def main():
             out["oriented_points"] = torch.empty((n, p.oriented_cap, 6), dtype=torch.int32, device=dev)
             out["oriented_counts"] = torch.zeros(n, dtype=torch.int32, device=dev)
             out["oriented_survivors"] = torch.zeros(n, dtype=torch.int32, device=dev)
+        if describe:  # descriptors of a small per-frame budget: 128 floats per oriented point
+            p.oriented_cap = min(p.oriented_cap, 4096)
+            out["oriented_points"] = out["oriented_points"][:, : p.oriented_cap].contiguous()
+            out["descriptors"] = torch.empty((n, p.oriented_cap, 128), dtype=torch.float32, device=dev)
+            out["descriptor_defined"] = torch.zeros((n, p.oriented_cap), dtype=torch.uint8, device=dev)
         counts_local = torch.zeros(2, dtype=torch.int64, device=dev)
         counts_all = torch.zeros((world, 2), dtype=torch.int64, device=cdev)
 
@@ -223,12 +228,13 @@ def main():
     modes = None
     if args.modes and args.octaves > 0 and not (args.localize or args.orient):
         modes = {}
-        for name, (lz, orr) in (("localize", (1, 0)), ("orient", (1, 1))):
-            m = run_mode(lz, orr, max(2, args.steps // 2), 1, None)
+        for name, (lz, orr, de) in (("localize", (1, 0, 0)), ("orient", (1, 1, 0)), ("describe", (1, 1, 1))):
+            m = run_mode(lz, orr, max(2, args.steps // 2), 1, None, de)
             ms = max(2, args.steps // 2)
             modes[name] = {"frames_per_sec": n * world * ms / m["dt"], "ms_per_step": m["dt"] / ms * 1e3, "steps": ms,
                            "dog_points_per_step": m["dog"], "list_overflow": m["list_overflow"],
-                           **({"oriented_points_per_step": m["oriented"], "oriented_truncated": m["oriented_truncated"]} if orr else {})}
+                           **({"oriented_points_per_step": m["oriented"], "oriented_truncated": m["oriented_truncated"]} if orr else {}),
+                           **({"what": "the whole DoG executable: pyramid, initialKeypointDetection, filterKeypoints, SIFT descriptors"} if de else {})}
 
     if rank == 0:
         algo = kernel_algorithmic_bytes(L, rows, cols)

@@ -324,6 +324,11 @@ typedef struct {
     uint32_t* oriented_survivors; /* [n] optional: keypoints of the frame that pass the edge test (Diff_of_Gauss.cpp:336).
                                    * Only the first oriented_cap of them (list order) get their histogram evaluated, so
                                    * oriented_survivors[f] > oriented_cap flags a truncated frame */
+    float* descriptors;           /* [n][oriented_cap][128] optional: SIFT() descriptors (Diff_of_Gauss.cpp:561-693) of the
+                                   * oriented points, same order; needs the oriented outputs.  Row q of frame f is
+                                   * valid for q < min(oriented_counts[f], oriented_cap) */
+    uint8_t* descriptor_defined;  /* [n][oriented_cap] optional, with descriptors: 0 where the rotated window leaves the
+                                   * padded level (zero descriptor, see vslam_sift_descriptors) */
 } vslam_batch_out;
 
 void vslam_params_default(vslam_params* p, int rows, int cols);

@@ -47,6 +47,9 @@ def make(name):
         d[f"ext_pts_{o}"] = pts
         d[f"kp_pts_{o}"] = p.keypoints(o, 3)  # through FeaturePointLocalization (section 8f row 2)
         d[f"oriented_pts_{o}"] = p.filter_keypoints(o, d[f"kp_pts_{o}"])  # filterKeypoints (row 3)
+        desc, ok = p.sift_descriptors(o, d[f"oriented_pts_{o}"])            # SIFT descriptors (row 4)
+        d[f"sift_desc_{o}"] = np.nan_to_num(desc, nan=-1.0)                   # all-NaN rows (flat windows) stored as -1
+        d[f"sift_defined_{o}"] = ok
     return d
 
 

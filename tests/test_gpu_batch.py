@@ -41,6 +41,8 @@ def run_batch(ctx, torch, frames_np, with_nms2=True, **pkw):
         o["oriented_points"] = torch.zeros((n, p.oriented_cap, 6), dtype=torch.int32, device=dev)
         o["oriented_counts"] = torch.zeros(n, dtype=torch.int32, device=dev)
         o["oriented_survivors"] = torch.full((n,), -1, dtype=torch.int32, device=dev)
+        o["descriptors"] = torch.full((n, p.oriented_cap, 128), 7.0, dtype=torch.float32, device=dev)
+        o["descriptor_defined"] = torch.full((n, p.oriented_cap), 9, dtype=torch.uint8, device=dev)
     ctx.detect_batch(p, frames, **o)
     torch.cuda.synchronize()
     return p, L, {k: (v.cpu().numpy() if v is not None else None) for k, v in o.items()}
@@ -95,6 +97,16 @@ def check_frame(p, L, out, f, img, n_oct):
         mo = min(len(wo), p.oriented_cap)
         goo = out["oriented_points"][f][:mo].copy().view(capi.POINT_DTYPE).reshape(-1)
         assert goo.tobytes() == wo[:mo].tobytes()
+        # SIFT() on the oriented points, octave by octave, in the batched path
+        wd, wk = [], []
+        for o in range(n_oct):
+            d, k = want.sift_descriptors(o, wo[wo["octave"] == o])
+            wd.append(d)
+            wk.append(k)
+        wd, wk = np.concatenate(wd), np.concatenate(wk)
+        assert (out["descriptor_defined"][f][:mo] == wk[:mo]).all()
+        assert np.array_equal(out["descriptors"][f][:mo], wd[:mo], equal_nan=True)
+        assert (out["descriptors"][f][mo:] == 7.0).all() and (out["descriptor_defined"][f][mo:] == 9).all()  # rows beyond the list untouched
     want.close()
 
 

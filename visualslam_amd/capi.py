@@ -61,6 +61,7 @@ class BatchOut(C.Structure):
         ("pyramid", C.c_void_p), ("extrema_bits", C.c_void_p),
         ("dog_points", C.c_void_p), ("dog_counts", C.c_void_p),
         ("oriented_points", C.c_void_p), ("oriented_counts", C.c_void_p), ("oriented_survivors", C.c_void_p),
+        ("descriptors", C.c_void_p), ("descriptor_defined", C.c_void_p),
     ]
 
 
@@ -441,6 +442,7 @@ class Context:
             "dog_points": (i32, 24 * n * params.dog_cap), "dog_counts": (i32, 4 * n),
             "oriented_points": (i32, 24 * n * params.oriented_cap), "oriented_counts": (i32, 4 * n),
             "oriented_survivors": (i32, 4 * n),
+            "descriptors": (f32, 512 * n * params.oriented_cap), "descriptor_defined": (u8, n * params.oriented_cap),
         }
         bo = BatchOut()
         for k, t in outs.items():

@@ -36,23 +36,26 @@ struct SiftLevels {  // per Gaussian level of the octave (null / 0 when no keypo
     int kn[VSLAM_NUM_LEVELS];
 };
 
-// grid = (keypoints), block = 256.  cs[q] = (cos, sin) of keypoint q's angle.
-__global__ __launch_bounds__(256) void k_sift_descriptors(const vslam_point* __restrict__ kps, const float2* __restrict__ cs, int n, SiftLevels lv,
-                                                           int gpitch, int rows, int cols, float* __restrict__ desc,
-                                                           uint8_t* __restrict__ defined) {
-    __shared__ float mag[SIFT_WIN * SIFT_WIN];   // magROI, then reused as the row-filtered image
-    __shared__ float rowf[SIFT_WIN * SIFT_WIN];
-    __shared__ float mw[SIFT_WIN * SIFT_WIN];    // magWeighted
-    __shared__ uint8_t bin[SIFT_WIN * SIFT_WIN];
-    __shared__ float d[SIFT_DESC];
-    __shared__ int bad_s;
-    const int q = blockIdx.x, t = threadIdx.x;
-    const vslam_point kp = kps[q];
-    const int level = kp.level;
-    if (t == 0) bad_s = 0;
+// One keypoint by one 256-thread workgroup (all threads call this with the same arguments).
+// G = the keypoint's 8-bit Gaussian level, k / kn = the f32 taps of sigma = 1.5 * sigma(octave, level),
+// a = (cos, sin) of its angle.  Writes the 128 floats and the defined flag (0: the rotated window
+// leaves the padded level, descriptor zeroed).  Ends with the workgroup's shared arrays free again.
+struct SiftShared {
+    float mag[SIFT_WIN * SIFT_WIN];   // magROI
+    float rowf[SIFT_WIN * SIFT_WIN];  // row-filtered ROI
+    float mw[SIFT_WIN * SIFT_WIN];    // magWeighted
+    float d[SIFT_DESC];
+    uint8_t bin[SIFT_WIN * SIFT_WIN];
+    int bad;
+};
+
+__device__ __forceinline__ void sift_one_keypoint(SiftShared& sh, const vslam_point kp, const float2 a, const uint8_t* __restrict__ G,
+                                                  int gpitch, int rows, int cols, const float* __restrict__ k, int kn,
+                                                  float* __restrict__ desc, uint8_t* __restrict__ defined) {
+    const int t = threadIdx.x;
+    if (t == 0) sh.bad = 0;
     __syncthreads();
     const int i = t >> 4, j = t & 15;
-    const uint8_t* __restrict__ G = lv.gauss[level];
     const int pr = rows + 2 * SIFT_PAD, pc = cols + 2 * SIFT_PAD;
     float o = 0.0f;
     {
@@ -60,48 +63,47 @@ __global__ __launch_bounds__(256) void k_sift_descriptors(const vslam_point* __r
         const int e = t;                                            // rotatedPoints[i * imgROI.rows + j], :545
         const int iy = e / (SIFT_WIN + 1), jx = e - iy * (SIFT_WIN + 1);
         const int rx = jx - SIFT_WIN / 2, ry = iy - SIFT_WIN / 2;  // pt - center
-        const float2 a = cs[q];
         const float xr = (float)rx * a.x - (float)ry * a.y;        // rotation.cpp:22 (no FMA: -ffp-contract=off)
         const float yr = (float)rx * a.y + (float)ry * a.x;        // :23
         const int px = (int)xr + cx, py = (int)yr + cy;            // truncation; |xr|, |yr| < 16
         const long long lin = (long long)px * pc + py;             // at<>(x, y): x is the row (:549-554)
         if (lin < 0 || lin >= (long long)pr * pc) {
-            atomicOr(&bad_s, 1);
+            atomicOr(&sh.bad, 1);
         } else {
             const int prow = (int)(lin / pc), pcol = (int)(lin - (long long)prow * pc);
             const int r = clampi(prow - SIFT_PAD, 0, rows - 1), c = clampi(pcol - SIFT_PAD, 0, cols - 1);  // padOctave(20): replicate
             const float gx = (float)((int)G[(size_t)r * gpitch + reflect101(c + 1, cols)] - (int)G[(size_t)r * gpitch + reflect101(c - 1, cols)]);
             const float gy = (float)((int)G[(size_t)reflect101(r + 1, rows) * gpitch + c] - (int)G[(size_t)reflect101(r - 1, rows) * gpitch + c]);
             const float xx = gx * gx, yy = gy * gy;
-            mag[t] = (float)sqrt((double)(xx + yy));  // cv::magnitude, correctly rounded (kernels_aux.hip.h)
-            o = fast_atan2_deg(gy, gx);               // cv::phase(..., true)
+            sh.mag[t] = (float)sqrt((double)(xx + yy));  // cv::magnitude, correctly rounded (kernels_aux.hip.h)
+            o = fast_atan2_deg(gy, gx);                  // cv::phase(..., true)
         }
     }
     __syncthreads();
-    if (bad_s) {  // block-uniform
-        if (t < SIFT_DESC) desc[(size_t)q * SIFT_DESC + t] = 0.0f;
-        if (t == 0 && defined) defined[q] = 0;
+    if (sh.bad) {  // block-uniform
+        if (t < SIFT_DESC) desc[t] = 0.0f;
+        if (t == 0 && defined) *defined = 0;
+        __syncthreads();
         return;
     }
     {
         const float reductionCoeff = (float)8 / 360.0f;  // :114 with size = 8 (:631)
         const int index = (int)(o * reductionCoeff);     // :126
-        bin[t] = (uint8_t)min(max(index, 0), 7);
+        sh.bin[t] = (uint8_t)min(max(index, 0), 7);
     }
-    const int kn = lv.kn[level], R = kn >> 1;
-    const float* __restrict__ k = lv.kern[level];
+    const int R = kn >> 1;
     {   // row filter of ROI row i: s = k[0]*S[0]; s += k[m]*S[m], S = the row extended by reflect-101
-        const float* S = mag + i * SIFT_WIN;
+        const float* S = sh.mag + i * SIFT_WIN;
         float s0 = k[0] * S[reflect101(j - R, SIFT_WIN)];
         for (int m = 1; m < kn; ++m) s0 += k[m] * S[reflect101(j + m - R, SIFT_WIN)];
-        rowf[t] = s0;
+        sh.rowf[t] = s0;
     }
     __syncthreads();
     {   // symmetric column filter: s = k[R]*S(0); s += k[R+m]*(S(+m) + S(-m)), rows reflected likewise
-        float s0 = k[R] * rowf[i * SIFT_WIN + j];
+        float s0 = k[R] * sh.rowf[i * SIFT_WIN + j];
         for (int m = 1; m <= R; ++m)
-            s0 += k[R + m] * (rowf[reflect101(i + m, SIFT_WIN) * SIFT_WIN + j] + rowf[reflect101(i - m, SIFT_WIN) * SIFT_WIN + j]);
-        mw[t] = s0;
+            s0 += k[R + m] * (sh.rowf[reflect101(i + m, SIFT_WIN) * SIFT_WIN + j] + sh.rowf[reflect101(i - m, SIFT_WIN) * SIFT_WIN + j]);
+        sh.mw[t] = s0;
     }
     __syncthreads();
     if (t < SIFT_DESC) {  // thread = (sub-region, bin); regions row-major, columns advance first (:637-652)
@@ -110,28 +112,69 @@ __global__ __launch_bounds__(256) void k_sift_descriptors(const vslam_point* __r
         float h = 0.0f;
         for (int u = r0; u < r0 + 4; ++u)
             for (int v = c0; v < c0 + 4; ++v)
-                if (bin[u * SIFT_WIN + v] == b) h += mw[u * SIFT_WIN + v];
-        d[t] = h;
+                if (sh.bin[u * SIFT_WIN + v] == b) h += sh.mw[u * SIFT_WIN + v];
+        sh.d[t] = h;
     }
     __syncthreads();
     // *max_element (operator< scan: a NaN first element stays), c / max, min(c, 0.2f) as std::min,
     // again c / max (:659-675).  Every thread scans the 128 values itself: same result everywhere.
     float v = 0.0f;
     if (t < SIFT_DESC) {
-        float mx = d[0];
-        for (int b = 1; b < SIFT_DESC; ++b) mx = mx < d[b] ? d[b] : mx;
-        v = d[t] / mx;
+        float mx = sh.d[0];
+        for (int b = 1; b < SIFT_DESC; ++b) mx = mx < sh.d[b] ? sh.d[b] : mx;
+        v = sh.d[t] / mx;
         v = 0.2f < v ? 0.2f : v;
     }
     __syncthreads();
-    if (t < SIFT_DESC) d[t] = v;
+    if (t < SIFT_DESC) sh.d[t] = v;
     __syncthreads();
     if (t < SIFT_DESC) {
-        float mx = d[0];
-        for (int b = 1; b < SIFT_DESC; ++b) mx = mx < d[b] ? d[b] : mx;
-        desc[(size_t)q * SIFT_DESC + t] = v / mx;
+        float mx = sh.d[0];
+        for (int b = 1; b < SIFT_DESC; ++b) mx = mx < sh.d[b] ? sh.d[b] : mx;
+        desc[t] = v / mx;
     }
-    if (t == 0 && defined) defined[q] = 1;
+    if (t == 0 && defined) *defined = 1;
+    __syncthreads();
+}
+
+// Per-image entry point: grid = (keypoints), block = 256.  cs[q] = (cos, sin) of keypoint q's angle.
+__global__ __launch_bounds__(256) void k_sift_descriptors(const vslam_point* __restrict__ kps, const float2* __restrict__ cs, int n, SiftLevels lv,
+                                                           int gpitch, int rows, int cols, float* __restrict__ desc,
+                                                           uint8_t* __restrict__ defined) {
+    __shared__ SiftShared sh;
+    const int q = blockIdx.x;
+    const vslam_point kp = kps[q];
+    sift_one_keypoint(sh, kp, cs[q], lv.gauss[kp.level], gpitch, rows, cols, lv.kern[kp.level], lv.kn[kp.level],
+                      desc + (size_t)q * SIFT_DESC, defined ? defined + q : nullptr);
+}
+
+// Batched, device-resident form (params.describe): the oriented points of every frame of a batch
+// (filterKeypoints output of kernels_orient_batch.hip.h: angle = bin * 10), grid = (G, frames),
+// workgroups stride over the frame's list.  cs36[b] = (cos, sin) of b * 10 degrees from the host's
+// libm (the angles the pipeline produces); the blur taps are those of the orientation stage
+// (same sigma = 1.5 * sigma(octave, level), Diff_of_Gauss.cpp:346 and :616).
+struct SiftBatchGeom {
+    int rows[VSLAM_MAX_OCTAVES], cols[VSLAM_MAX_OCTAVES], pitch[VSLAM_MAX_OCTAVES];
+    unsigned long long oct_off[VSLAM_MAX_OCTAVES];
+    const float* kern[VSLAM_MAX_OCTAVES][VSLAM_NUM_LEVELS];
+    int kn[VSLAM_MAX_OCTAVES][VSLAM_NUM_LEVELS];
+    float2 cs36[36];
+};
+
+__global__ __launch_bounds__(256) void k_sift_descriptors_batch(const vslam_point* __restrict__ oriented, const unsigned int* __restrict__ counts,
+                                                                 unsigned int cap, const uint8_t* __restrict__ pyr, size_t pframe,
+                                                                 SiftBatchGeom g, float* __restrict__ desc, uint8_t* __restrict__ defined) {
+    __shared__ SiftShared sh;
+    const int f = blockIdx.y;
+    const unsigned int n = min(counts[f], cap);
+    for (unsigned int q = blockIdx.x; q < n; q += gridDim.x) {
+        const vslam_point kp = oriented[(size_t)f * cap + q];
+        const int o = kp.octave;
+        const uint8_t* G = pyr + f * pframe + g.oct_off[o] + (size_t)kp.level * g.rows[o] * g.pitch[o];
+        const unsigned int b = (unsigned int)kp.value / 10u;
+        sift_one_keypoint(sh, kp, g.cs36[b < 36u ? b : 0u], G, g.pitch[o], g.rows[o], g.cols[o], g.kern[o][kp.level], g.kn[o][kp.level],
+                          desc + ((size_t)f * cap + q) * SIFT_DESC, defined ? defined + (size_t)f * cap + q : nullptr);
+    }
 }
 
 }  // namespace vslam

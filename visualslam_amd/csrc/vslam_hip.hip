@@ -1449,6 +1449,27 @@ static int enqueue_orient_batch(vslam_ctx* c, const vslam_params& p, const vslam
     return VSLAM_OK;
 }
 
+// SIFT() for the oriented lists of nf frames (kernels_sift.hip.h), on the context's current stream,
+// behind the kernels that produced the lists.
+static int enqueue_sift_batch(vslam_ctx* c, const vslam_params& p, const vslam_batch_layout& L, int nf, const uint8_t* pyr, size_t pframe,
+                              const vslam_point* oriented, const unsigned int* ocounts, float* desc, uint8_t* defined) {
+    SiftBatchGeom g;
+    std::memset(&g, 0, sizeof(g));
+    for (int o = 0; o < L.n_octaves; ++o) {
+        g.rows[o] = L.rows[o];
+        g.cols[o] = L.cols[o];
+        g.pitch[o] = L.pitch[o];
+        g.oct_off[o] = L.octave_offset[o];
+        for (int l = 1; l <= 3; ++l)  // the levels initialKeypointDetection produces; same taps as the orientation blur
+            TRY(get_orient_taps(c, 1.5 * sigma_at(p.sigma0, o, l), &g.kern[o][l], &g.kn[o][l]));  // Diff_of_Gauss.cpp:616
+    }
+    for (int b = 0; b < 36; ++b) vslam_cos_sin_deg((float)(10 * b), &g.cs36[b].x, &g.cs36[b].y);  // host libm, like the reference
+    const int gwg = (int)std::min<long>(1024, std::max<long>(16, 8192 / nf));
+    LAUNCH(c, "k_sift_descriptors", k_sift_descriptors_batch, dim3(gwg, nf), dim3(256), oriented, ocounts, p.oriented_cap, pyr, pframe, g, desc,
+           defined);
+    return VSLAM_OK;
+}
+
 int vslam_detect_batch_dev(vslam_ctx* c, const vslam_params* pp, const uint8_t* d_frames, size_t frame_stride,
                            int n_frames, const vslam_batch_out* out) {
     TRY(bind_device(c));
@@ -1465,6 +1486,8 @@ int vslam_detect_batch_dev(vslam_ctx* c, const vslam_params* pp, const uint8_t* 
     ARGCHK(c, !orient || (p.localize && out->dog_points && out->dog_counts && out->oriented_points && out->oriented_counts &&
                           p.oriented_cap > 0 && p.dog_cap > 0 && p.extrema_window == 3),
            "detect_batch: orient needs localize = 1, windowSize 3, the DoG point list and the oriented outputs");
+    ARGCHK(c, !out->descriptors || orient, "detect_batch: descriptors need orient = 1");
+    ARGCHK(c, !out->descriptor_defined || out->descriptors, "detect_batch: descriptor_defined without descriptors");
     const size_t N = (size_t)p.rows * p.cols;
     // Whole-batch launches: every kernel sees all frames (grid.z = frames), so even the coarse
     // octaves fill the chip.  Scratch: octave bases (+ u16 row sums of the non-tiled octaves).
@@ -1540,6 +1563,11 @@ int vslam_detect_batch_dev(vslam_ctx* c, const vslam_params* pp, const uint8_t* 
                 if (out->oriented_survivors)
                     HIPCHK(c, hipMemcpyAsync(out->oriented_survivors + f0, os.scounts, sizeof(unsigned int) * (size_t)nf,
                                              hipMemcpyDeviceToDevice, c->stream));
+                if (out->descriptors)
+                    TRY(enqueue_sift_batch(c, p, L, nf, out->pyramid + (size_t)f0 * L.pyramid_frame_bytes, L.pyramid_frame_bytes,
+                                           out->oriented_points + (size_t)f0 * p.oriented_cap, out->oriented_counts + f0,
+                                           out->descriptors + (size_t)f0 * p.oriented_cap * 128,
+                                           out->descriptor_defined ? out->descriptor_defined + (size_t)f0 * p.oriented_cap : nullptr));
             }
         }
     }
