@@ -250,6 +250,8 @@ def test_golden_fixtures(ctx, name):
         assert nk == len(g[f"kp_pts_{o}"]) and same(kp, g[f"kp_pts_{o}"])
         fk, nf = p.filter_keypoints(o, kp)
         assert nf == len(g[f"oriented_pts_{o}"]) and same(fk, g[f"oriented_pts_{o}"])
+        desc, ok = p.sift_descriptors(o, fk)
+        assert (ok == g[f"sift_defined_{o}"]).all() and same(np.nan_to_num(desc, nan=-1.0), g[f"sift_desc_{o}"])
 
 
 def test_feature_point_localization_bit_exact(ctx):
