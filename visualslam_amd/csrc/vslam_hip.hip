@@ -517,9 +517,27 @@ static int enqueue_pyr_octave(vslam_ctx* c, double sigma0, int o, const OctPlan&
 static int enqueue_dog(vslam_ctx* c, const vslam_params& p, const vslam_batch_layout& L, const uint8_t* frames,
                        size_t fstep, size_t fframe, int nf, uint8_t* pyr, size_t pframe, DogScratch& s,
                        unsigned long long* bits, bool do_extrema, vslam_point* points, unsigned int* counts,
-                       hipStream_t side = nullptr) {
+                       hipStream_t side = nullptr, int* side_gate = nullptr) {
     // `side`: stream for the extrema scans and the list compaction (they only read what the
-    // octave kernels wrote); ordered after each octave by an event.  nullptr = same stream.
+    // octave kernels wrote); ordered after the octave kernels by events.  nullptr = same stream.
+    //
+    // Batches hold the side work back until the last LDS-tiled octave kernel has finished
+    // (*side_gate = that octave, -1 = no gate; the caller gates the Harris chain on the same event):
+    // those kernels are bound by VALU issue and lose exactly the issue slots the latency- and
+    // HBM-bound kernels take when they run beside them, while the coarse-octave strip kernels that
+    // follow run at low occupancy and overlap them for free.  Measured (256 x 1080p, same box):
+    // k_pyr_octave 7.46 -> 6.09 ms per launch, 13.36 -> 13.51 k frames/s.  Small batches keep the
+    // eager order: there the chain's latency matters, not the chip's issue slots.
+    int gate = -1;
+    if (side && nf >= 32)
+        for (int o = 0; o < L.n_octaves; ++o) {
+            const OctPath path = plan_octave(p.sigma0, o, L.rows[o], L.cols[o]).path;
+            if (path == OctPath::Tile0 || path == OctPath::Tile1) gate = o;
+        }
+    if (side_gate) *side_gate = gate;
+    // With filterKeypoints behind the lists (params.orient) the side chain is the longer one: holding
+    // the scans back would only lengthen its tail (10.55 -> 10.43 k frames/s); the Harris chain stays gated.
+    if (p.orient) gate = -1;
     ExtGeom g;
     if (p.localize) TRY(ensure_loc_lut(c));
     fill_geom(c, p, L, g);
@@ -559,11 +577,15 @@ static int enqueue_dog(vslam_ctx* c, const vslam_params& p, const vslam_batch_la
             LAUNCH(c, "k_resize_nearest_half_v4", k_resize_nearest_half_v4, dim3((L.cols[o + 1] / 4 + 256) / 256, L.rows[o + 1], nf),
                    dim3(256), oct + (size_t)3 * P, pframe, pitch, s.bases + s.base_off[o + 1], s.bases_frame, L.pitch[o + 1], rows,
                    L.rows[o + 1], L.cols[o + 1]);
+        if (side) HIPCHK(c, hipEventRecord(c->ev_oct[o], c->stream));
+        if (o < gate) continue;  // scan + compaction of this octave are enqueued behind octave `gate`
+        const int o_done = o;    // the octave whose kernels were enqueued last
+        for (int oo = (o_done == gate ? 0 : o_done); oo <= o_done; ++oo) {
+        const int o = oo;
         if (do_extrema && L.lat_rows[o] > 0 && L.lat_cols[o] > 0) {
             hipStream_t es = c->stream;
             if (side) {
-                HIPCHK(c, hipEventRecord(c->ev_oct[o], c->stream));
-                HIPCHK(c, hipStreamWaitEvent(side, c->ev_oct[o], 0));
+                HIPCHK(c, hipStreamWaitEvent(side, c->ev_oct[o_done], 0));
                 es = side;
             }
             if (p.extrema_window == 3) {
@@ -597,6 +619,7 @@ static int enqueue_dog(vslam_ctx* c, const vslam_params& p, const vslam_batch_la
                 LAUNCH(c, "k_points_localize_value", k_points_localize_value, dim3((unsigned)((oct_max + 255) / 256), nf), dim3(256), points,
                        s.pbegin, counts, p.dog_cap, pyr, pframe, g);
         }
+        }  // oo
     }
     return VSLAM_OK;
 }
@@ -1539,7 +1562,7 @@ int vslam_detect_batch_dev(vslam_ctx* c, const vslam_params* pp, const uint8_t* 
     for (int f0 = 0; f0 < n_frames; f0 += chunk) {
         const int nf = std::min(chunk, n_frames - f0);
         const uint8_t* fr = d_frames + (size_t)f0 * frame_stride;
-        if (harris) {
+        auto do_harris = [&]() -> int {
             StreamSwap sw(c, sh);
             float* resp = out->response ? out->response + (size_t)f0 * N : resp_ws;
             TRY(enqueue_harris(c, fr, frame_stride, p.rows, p.cols, nf, p.harris_k, resp,
@@ -1547,14 +1570,21 @@ int vslam_detect_batch_dev(vslam_ctx* c, const vslam_params* pp, const uint8_t* 
                                out->nms2 ? out->nms2 + (size_t)f0 * N : nullptr, want_kps ? hflags : nullptr,
                                want_kps ? out->harris_kps + (size_t)f0 * p.harris_cap : nullptr, p.harris_cap,
                                want_kps ? out->harris_counts + f0 : nullptr, hcws));
-        }
+            return VSLAM_OK;
+        };
+        if (harris && !(dog && use_aux)) TRY(do_harris());
         if (dog) {
+            int side_gate = -1;
             const bool ext = out->extrema_bits || (out->dog_points && out->dog_counts);
             TRY(enqueue_dog(c, p, L, fr, p.cols, frame_stride, nf, out->pyramid + (size_t)f0 * L.pyramid_frame_bytes,
                             L.pyramid_frame_bytes, s,
                             out->extrema_bits ? (unsigned long long*)out->extrema_bits + (size_t)f0 * L.bits_frame_words : nullptr,
                             ext, out->dog_points ? out->dog_points + (size_t)f0 * p.dog_cap : nullptr,
-                            out->dog_counts ? out->dog_counts + f0 : nullptr, sx));
+                            out->dog_counts ? out->dog_counts + f0 : nullptr, sx, &side_gate));
+            if (harris && use_aux) {  // the Harris chain shares the gate of the other side work (enqueue_dog)
+                if (side_gate >= 0) HIPCHK(c, hipStreamWaitEvent(sh, c->ev_oct[side_gate], 0));
+                TRY(do_harris());
+            }
             if (orient) {  // filterKeypoints behind the list, on the stream that produced it
                 StreamSwap sw(c, sx ? sx : c->stream);
                 TRY(enqueue_orient_batch(c, p, L, nf, out->pyramid + (size_t)f0 * L.pyramid_frame_bytes, L.pyramid_frame_bytes,
