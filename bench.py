@@ -219,9 +219,24 @@ def main():
         return {"p": p, "L": L, "dt": float(red.item()), "launches": launches, "kms": kms, "harris": totals[0], "dog": totals[1],
                 "list_overflow": bool(fl[0]), "oriented": fl[1], "oriented_truncated": bool(fl[2])}
 
+    def kernel_alone(kname, steps):
+        """The dominant kernel with nothing beside it: the same batch, pyramid output only (no Harris
+        chain, no extrema scan, no lists).  Not part of the timed region of `value`."""
+        p = capi.default_params(rows, cols, n_octaves=args.octaves)
+        ctx.detect_batch(p, frames, pyramid=shared["pyramid"])
+        fence()
+        ctx.kernel_timing_enable(kname)
+        for _ in range(steps):
+            ctx.detect_batch(p, frames, pyramid=shared["pyramid"])
+        fence()
+        launches, kms = ctx.kernel_timing_read()
+        ctx.kernel_timing_enable(None)
+        return launches, kms
+
     kname = args.kernel or "k_pyr_octave"
     main = run_mode(args.localize, args.orient, args.steps, args.warmup, kname)
     p, L, dt, launches, kms = main["p"], main["L"], main["dt"], main["launches"], main["kms"]
+    alone = kernel_alone(kname, 3) if (args.modes and kname == "k_pyr_octave" and args.octaves >= 2) else None
     # the list modes the reference's own functions produce (initialKeypointDetection appends the
     # FeaturePointLocalization survivors, Diff_of_Gauss.cpp:290; filterKeypoints the oriented points,
     # :787), measured in the same process on the same frames with fewer steps
@@ -265,6 +280,13 @@ def main():
                 "algorithmic_bytes_per_frame": algo.get(kname, 0),
                 "algorithmic_bytes_per_launch": algo.get(kname, 0) * n * args.steps / launches,
             }
+            if alone and alone[0] and alone[1] > 0:
+                # `achieved` / `frac` above are from the timed region, where octave 0's extrema scan runs
+                # beside octave 1's launch; this is the same kernel with the chip to itself
+                a_ms = alone[1] / alone[0]
+                a_ach = roof["algorithmic_bytes_per_launch"] / (a_ms * 1e-3) / 1e9
+                roof["alone"] = {"avg_launch_ms": a_ms, "achieved": a_ach, "frac": a_ach / HBM_PEAK_GBPS,
+                                 "what": "pyramid-only batches (no Harris chain, no extrema scan), 3 steps, outside the timed region"}
         # second roof of the same kernel: it is bound by VALU issue of the packed dot instructions,
         # not by HBM.  Algorithmic dot instructions per pixel = sum over levels of
         # n/4 (v_dot4_u32_u8, vertical) + n/2 (v_dot2_u32_u16, horizontal) with the zero-trimmed

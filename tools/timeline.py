@@ -1,11 +1,11 @@
-"""Print the kernel timeline of the last complete step in a rocprofv3 --kernel-trace CSV directory."""
-import csv, glob, sys
-f = glob.glob(sys.argv[1] + "/*kernel_trace.csv")[0]
-rows = [r for r in csv.DictReader(open(f)) if "vslam" in r["Kernel_Name"]]
-rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "k_resize_linear2x" in r["Kernel_Name"]]
-seg = rows[idx[-2]:idx[-1]]
-t0 = int(seg[0]["Start_Timestamp"])
-for r in seg:
-    print("%8.1f %8.1f  q%s %s" % ((int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3,
-                                  r.get("Queue_Id", "?"), r["Kernel_Name"][:80]))
+"""Print the kernel timeline of the last full batch in a rocprofv3 kernel trace (csv)."""
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r: int(r['Start_Timestamp']))
+idx = [i for i, r in enumerate(rows) if 'k_resize_linear2x_slide' in r['Kernel_Name']]
+i0, i1 = idx[-2], idx[-1]
+t0 = int(rows[i0]['Start_Timestamp'])
+for r in rows[i0:i1]:
+    if 'at::native' in r['Kernel_Name'] or 'rocclr' in r['Kernel_Name']:
+        continue
+    print(f"{(int(r['Start_Timestamp'])-t0)/1e6:8.3f} {(int(r['End_Timestamp'])-t0)/1e6:8.3f}  q{r['Queue_Id']:>2} {r['Kernel_Name'][:64]}")

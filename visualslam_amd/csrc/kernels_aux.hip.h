@@ -131,40 +131,51 @@ __global__ __launch_bounds__(256) void k_extrema_w3(const uint8_t* __restrict__ 
     }
     const int li = blockIdx.y, f = blockIdx.z;
     const int rows = g.rows[o], cols = g.cols[o], pitch = g.pitch[o];
-    const size_t P = (size_t)rows * pitch;
+    const uint32_t P = (uint32_t)rows * (uint32_t)pitch;  // 11 planes of an octave stay below 2^31 bytes
     const uint8_t* dog = pyr + f * pframe + g.oct_off[o] + (size_t)VSLAM_NUM_LEVELS * P;
     const int ya = max(3 * li - 1, 0), yb = 3 * li;  // padded rows i-1, i with i = 1 + 3li -> unpadded 3li-1, 3li
     const int yc = min(3 * li + 1, rows - 1);        // padded row i+1
     const int c0 = blockIdx.x * EXT_SPAN - 16;       // image column of staged byte 0
-    constexpr int C16 = EXT_PITCH / 16, NV = NROW * C16;  // 49 sixteen-byte pieces per staged row
+    // Staging: a wave takes whole staged rows (wave w: rows w, w+4, ...), lane = 16-byte piece, so
+    // the level / image row / row base are scalar and a piece costs one load and one LDS write.
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int cpiece = c0 + 16 * lane;
+    const bool piece_ok = lane < EXT_PITCH / 16 && cpiece >= 0 && cpiece < cols;
 #pragma unroll
-    for (int i = 0; i < (NV + 255) / 256; ++i) {
-        const int it = threadIdx.x + 256 * i;
-        if (it < NV) {
-            const int rl = it / C16, x16 = it - rl * C16;  // rl = level*2 + row
-            const int c = c0 + 16 * x16;
+    for (int i = 0; i < (NROW + 3) / 4; ++i) {
+        const int rl = wave + 4 * i;  // rl = level*2 + row
+        if (rl < NROW) {
             const int lev = rl < 10 ? (rl >> 1) : rl - 9, y = rl < 10 ? ((rl & 1) ? yb : ya) : yc;
-            if (c >= 0 && c < cols)
-                *reinterpret_cast<uint4*>(srow + rl * EXT_PITCH + 16 * x16) =
-                    *reinterpret_cast<const uint4*>(dog + (size_t)lev * P + (size_t)y * pitch + c);  // may end in the row padding
+            const uint8_t* rowp = dog + (ptrdiff_t)(int)((uint32_t)lev * P + (uint32_t)y * (uint32_t)pitch + (uint32_t)c0);  // scalar
+            if (piece_ok)
+                *reinterpret_cast<uint4*>(srow + rl * EXT_PITCH + 16 * lane) =
+                    *reinterpret_cast<const uint4*>(rowp + (uint32_t)(16 * lane));  // may end in the row padding
         }
     }
     if (blockIdx.x == 0 && threadIdx.x < 10)  // column -1 replicates column 0 (padOctave)
-        srow[threadIdx.x * EXT_PITCH + 15] = dog[(size_t)(threadIdx.x >> 1) * P + (size_t)((threadIdx.x & 1) ? yb : ya) * pitch];
+        srow[threadIdx.x * EXT_PITCH + 15] = dog[(threadIdx.x >> 1) * P + (uint32_t)((threadIdx.x & 1) ? yb : ya) * (uint32_t)pitch];
     __syncthreads();
     const int lc = g.lat_cols[o], wpr = g.wpr[o], lr = g.lat_rows[o];
     const int lj = blockIdx.x * 256 + threadIdx.x;
     bool cand[3] = {false, false, false}, listed[3] = {false, false, false};
-    if (lj < lc) {
-        const int xa = 3 * (int)threadIdx.x - 1 + 16;       // byte offset of column 3lj-1 in a staged row
-        const uint8_t* p0 = srow + (xa & ~3);               // enclosing dword pair
+    unsigned long long wcand[3], wlist[3];
+    // Every lane runs the window test (lanes past the last site read staged bytes that are there
+    // but mean nothing) and the ballots are masked by the lanes that own a site: the masks stay
+    // in scalar registers, built from the compares themselves.
+    const unsigned long long owns = __builtin_amdgcn_ballot_w64(lj < lc);
+    const int xa = 3 * (int)threadIdx.x - 1 + 16;       // byte offset of column 3lj-1 in a staged row
+    uint32_t self[5];
+    {
         const uint32_t s = xa & 3;
         const uint32_t sel = 0x0c000c00u | s | ((s + 1) << 16);  // (byte s, 0, byte s+1, 0)
-        uint32_t mn[5], mx[5], self[5];
+        uint32_t mn[5], mx[5];
 #pragma unroll
         for (int l = 0; l < 5; ++l) {
-            const uint32_t* q0 = reinterpret_cast<const uint32_t*>(p0 + (2 * l) * EXT_PITCH);  // 4-byte aligned: ds_read2_b32
-            const uint32_t* q1 = reinterpret_cast<const uint32_t*>(p0 + (2 * l + 1) * EXT_PITCH);
+            // one address per level: the level's second row is within ds_read2_b32's offset range of the first
+            uint32_t off = (uint32_t)(xa & ~3) + (uint32_t)(2 * l * EXT_PITCH);
+            if (l) asm volatile("" : "+v"(off));
+            const uint32_t* q0 = reinterpret_cast<const uint32_t*>(srow + off);  // 4-byte aligned: ds_read2_b32
+            const uint32_t* q1 = q0 + EXT_PITCH / 4;
             const uint32_t v0 = __builtin_amdgcn_perm(q0[1], q0[0], sel), v1 = __builtin_amdgcn_perm(q1[1], q1[0], sel);  // (a,b), (c,d)
             const uint32_t lo = pk_min_u16(v0, v1), hi = pk_max_u16(v0, v1);
             mn[l] = min(lo & 0xffffu, lo >> 16);
@@ -174,31 +185,32 @@ __global__ __launch_bounds__(256) void k_extrema_w3(const uint8_t* __restrict__ 
 #pragma unroll
         for (int L = 1; L <= 3; ++L) {
             const uint32_t lo = min(mn[L - 1], min(mn[L], mn[L + 1])), hi = max(mx[L - 1], max(mx[L], mx[L + 1]));
-            cand[L - 1] = self[L] == lo || self[L] == hi;
-            if (!LOC) listed[L - 1] = cand[L - 1] && (int)self[L] >= g.min_contrast;
+            wcand[L - 1] = (__builtin_amdgcn_ballot_w64(self[L] == lo) | __builtin_amdgcn_ballot_w64(self[L] == hi)) & owns;
+            if (LOC) cand[L - 1] = lj < lc && (self[L] == lo || self[L] == hi);
+            else wlist[L - 1] = wcand[L - 1] & __builtin_amdgcn_ballot_w64((int)self[L] >= g.min_contrast);
         }
-        if (LOC) {
-            const int xj = xa + 1;                                            // byte offset of column 3lj
-            const int xr = xj + ((3 * lj + 1 < cols) ? 1 : 0);                // padded (., j+1): replicate at the edge
+    }
+    if (LOC && lj < lc) {
+        const int xj = xa + 1;                                            // byte offset of column 3lj
+        const int xr = xj + ((3 * lj + 1 < cols) ? 1 : 0);                // padded (., j+1): replicate at the edge
 #pragma unroll
-            for (int L = 1; L <= 3; ++L) {
-                if (cand[L - 1]) {
-                    const uint8_t* r0 = srow + (2 * L) * EXT_PITCH;           // padded row i-1
-                    const uint8_t* r1 = r0 + EXT_PITCH;                       // padded row i
-                    const uint8_t* r2 = srow + (9 + L) * EXT_PITCH;           // padded row i+1
-                    const int d_x = (int)r1[xa] - (int)r1[xr];                // Diff_of_Gauss.cpp:226
-                    const int d_y = (int)r0[xj] - (int)r2[xj];                // :227
-                    const int d_s = (int)self[L - 1] - (int)self[L + 1];      // :228
-                    if (d_x == 0 || d_y == 0 || d_s == 0) {
-                        int nv;  // exactly singular: the test is value/255 > 0.03f
-                        listed[L - 1] = feature_point_localization(d_x, d_y, d_s, (int)self[L], nv);
-                    } else {
-                        // three non-zero differences: queue the site so that the workgroup evaluates
-                        // its queue on dense lanes afterwards
-                        const unsigned int q = atomicAdd(&qn, 1u);
-                        queue[q] = make_uint2((uint32_t)(d_x + 256) | ((uint32_t)(d_y + 256) << 10) | ((uint32_t)(d_s + 256) << 20),
-                                              self[L] | ((uint32_t)((L - 1) * 256 + threadIdx.x) << 8));
-                    }
+        for (int L = 1; L <= 3; ++L) {
+            if (cand[L - 1]) {
+                const uint8_t* r0 = srow + (2 * L) * EXT_PITCH;           // padded row i-1
+                const uint8_t* r1 = r0 + EXT_PITCH;                       // padded row i
+                const uint8_t* r2 = srow + (9 + L) * EXT_PITCH;           // padded row i+1
+                const int d_x = (int)r1[xa] - (int)r1[xr];                // Diff_of_Gauss.cpp:226
+                const int d_y = (int)r0[xj] - (int)r2[xj];                // :227
+                const int d_s = (int)self[L - 1] - (int)self[L + 1];      // :228
+                if (d_x == 0 || d_y == 0 || d_s == 0) {
+                    int nv;  // exactly singular: the test is value/255 > 0.03f
+                    listed[L - 1] = feature_point_localization(d_x, d_y, d_s, (int)self[L], nv);
+                } else {
+                    // three non-zero differences: queue the site so that the workgroup evaluates
+                    // its queue on dense lanes afterwards
+                    const unsigned int q = atomicAdd(&qn, 1u);
+                    queue[q] = make_uint2((uint32_t)(d_x + 256) | ((uint32_t)(d_y + 256) << 10) | ((uint32_t)(d_s + 256) << 20),
+                                          self[L] | ((uint32_t)((L - 1) * 256 + threadIdx.x) << 8));
                 }
             }
         }
@@ -218,13 +230,17 @@ __global__ __launch_bounds__(256) void k_extrema_w3(const uint8_t* __restrict__ 
 #pragma unroll
         for (int L = 0; L < 3; ++L) listed[L] = listed[L] || qkeep[L * 256 + threadIdx.x];
     }
+    const int word = blockIdx.x * 4 + wave;  // = lj >> 6, wave-uniform
+    if (word < wpr) {
+        const size_t w0 = f * bframe + g.bits_off[o] + (size_t)li * wpr + word;
 #pragma unroll
-    for (int L = 0; L < 3; ++L) {
-        const unsigned long long wc = __ballot(cand[L]), wl = __ballot(listed[L]);
-        if ((threadIdx.x & 63) == 0 && (lj >> 6) < wpr) {
-            const size_t w = f * bframe + g.bits_off[o] + ((size_t)L * lr + li) * wpr + (lj >> 6);
-            if (bits) bits[w] = wc;
-            lflags[w] = wl;
+        for (int L = 0; L < 3; ++L) {
+            const unsigned long long wc = wcand[L], wl = LOC ? __builtin_amdgcn_ballot_w64(listed[L]) : wlist[L];
+            if (lane == 0) {
+                const size_t w = w0 + (size_t)L * lr * wpr;
+                if (bits) bits[w] = wc;
+                lflags[w] = wl;
+            }
         }
     }
 }

@@ -521,13 +521,18 @@ static int enqueue_dog(vslam_ctx* c, const vslam_params& p, const vslam_batch_la
     // `side`: stream for the extrema scans and the list compaction (they only read what the
     // octave kernels wrote); ordered after the octave kernels by events.  nullptr = same stream.
     //
-    // Batches hold the side work back until the last LDS-tiled octave kernel has finished
-    // (*side_gate = that octave, -1 = no gate; the caller gates the Harris chain on the same event):
-    // those kernels are bound by VALU issue and lose exactly the issue slots the latency- and
-    // HBM-bound kernels take when they run beside them, while the coarse-octave strip kernels that
-    // follow run at low occupancy and overlap them for free.  Measured (256 x 1080p, same box):
-    // k_pyr_octave 7.46 -> 6.09 ms per launch, 13.36 -> 13.51 k frames/s.  Small batches keep the
-    // eager order: there the chain's latency matters, not the chip's issue slots.
+    // Where the side work runs decides how much of the VALU-issue-bound octave kernels it costs
+    // (*side_gate = the last LDS-tiled octave, -1 = none; 256 x 1080p, same box):
+    //  * the Harris chain (VALU-heavy) always waits for that octave's kernel - the caller gates it
+    //    on ev_oct[*side_gate] - and runs beside the coarse-octave strip kernels, which are short
+    //    of waves: k_pyr_octave 7.46 -> 6.06 ms per launch, +1.4 % frames/s;
+    //  * the plain extrema scan (HBM-heavy, ~90 VALU instructions per thread) starts as soon as its
+    //    octave is written, i.e. octave 0's scan runs beside octave 1's kernel: +2..3 % frames/s
+    //    over holding it back as well (the tail after the tiled octaves is as VALU-bound as they are,
+    //    so the scan's memory time is what gets hidden);
+    //  * the scan with FeaturePointLocalization inside (params.localize, ~8x the instructions) is
+    //    held back like the Harris chain: +0.5 % in the localize / orient / describe modes.
+    // Small batches keep the eager order: there the chain's latency matters, not the issue slots.
     int gate = -1;
     if (side && nf >= 32)
         for (int o = 0; o < L.n_octaves; ++o) {
@@ -535,9 +540,7 @@ static int enqueue_dog(vslam_ctx* c, const vslam_params& p, const vslam_batch_la
             if (path == OctPath::Tile0 || path == OctPath::Tile1) gate = o;
         }
     if (side_gate) *side_gate = gate;
-    // With filterKeypoints behind the lists (params.orient) the side chain is the longer one: holding
-    // the scans back would only lengthen its tail (10.55 -> 10.43 k frames/s); the Harris chain stays gated.
-    if (p.orient) gate = -1;
+    if (!p.localize) gate = -1;
     ExtGeom g;
     if (p.localize) TRY(ensure_loc_lut(c));
     fill_geom(c, p, L, g);
