@@ -122,13 +122,8 @@ __global__ __launch_bounds__(256) void k_extrema_w3(const uint8_t* __restrict__ 
                                                      unsigned long long* __restrict__ lflags, size_t bframe) {
     constexpr int NROW = LOC ? 13 : 10;
     __shared__ __attribute__((aligned(16))) uint8_t srow[NROW * EXT_PITCH + 16];  // [level 0..4][row 0..1], then [level 1..3] row 2
-    __shared__ uint2 queue[LOC ? 768 : 1];       // sites whose localization needs the full inverse
-    __shared__ uint8_t qkeep[LOC ? 768 : 1];     // their verdicts, by (level-1)*256 + thread
-    __shared__ unsigned int qn;
-    if (LOC) {
-        if (threadIdx.x == 0) qn = 0;
-        qkeep[threadIdx.x] = 0, qkeep[256 + threadIdx.x] = 0, qkeep[512 + threadIdx.x] = 0;
-    }
+    __shared__ uint2 queue[LOC ? 768 : 1];       // per wave: the sites whose localization needs the full inverse
+    __shared__ uint8_t qkeep[LOC ? 768 : 1];     // per wave: their verdicts, by (level-1)*64 + lane
     const int li = blockIdx.y, f = blockIdx.z;
     const int rows = g.rows[o], cols = g.cols[o], pitch = g.pitch[o];
     const uint32_t P = (uint32_t)rows * (uint32_t)pitch;  // 11 planes of an octave stay below 2^31 bytes
@@ -165,6 +160,7 @@ __global__ __launch_bounds__(256) void k_extrema_w3(const uint8_t* __restrict__ 
     const unsigned long long owns = __builtin_amdgcn_ballot_w64(lj < lc);
     const int xa = 3 * (int)threadIdx.x - 1 + 16;       // byte offset of column 3lj-1 in a staged row
     uint32_t self[5];
+    uint32_t up[5], left[5];  // LOC: padded (i-1, j) and (i, j-1) of each level, already in the window
     {
         const uint32_t s = xa & 3;
         const uint32_t sel = 0x0c000c00u | s | ((s + 1) << 16);  // (byte s, 0, byte s+1, 0)
@@ -181,6 +177,7 @@ __global__ __launch_bounds__(256) void k_extrema_w3(const uint8_t* __restrict__ 
             mn[l] = min(lo & 0xffffu, lo >> 16);
             mx[l] = max(hi & 0xffffu, hi >> 16);
             self[l] = v1 >> 16;  // (i, j) itself = d
+            if (LOC) up[l] = v0 >> 16, left[l] = v1 & 0xffffu;
         }
 #pragma unroll
         for (int L = 1; L <= 3; ++L) {
@@ -190,45 +187,60 @@ __global__ __launch_bounds__(256) void k_extrema_w3(const uint8_t* __restrict__ 
             else wlist[L - 1] = wcand[L - 1] & __builtin_amdgcn_ballot_w64((int)self[L] >= g.min_contrast);
         }
     }
-    if (LOC && lj < lc) {
+    if (LOC) {
+        // Candidates with three non-zero differences go through a queue OF THIS WAVE (slots from the
+        // ballot, no atomics, no workgroup barrier: LDS serves a wave's accesses in order) and are
+        // evaluated on dense lanes; a workgroup-wide queue made every workgroup wait twice for its
+        // slowest wave and for one wave's table loads - the scan was bound by that latency chain.
+        uint2* wq = queue + wave * 192;
+        uint8_t* wk = qkeep + wave * 192;
         const int xj = xa + 1;                                            // byte offset of column 3lj
         const int xr = xj + ((3 * lj + 1 < cols) ? 1 : 0);                // padded (., j+1): replicate at the edge
+        unsigned int nw = 0;                                              // wave-uniform queue length
+        bool queued[3];
 #pragma unroll
         for (int L = 1; L <= 3; ++L) {
+            bool nz = false;
+            uint32_t dpack = 0;
             if (cand[L - 1]) {
-                const uint8_t* r0 = srow + (2 * L) * EXT_PITCH;           // padded row i-1
-                const uint8_t* r1 = r0 + EXT_PITCH;                       // padded row i
+                const uint8_t* r1 = srow + (2 * L + 1) * EXT_PITCH;       // padded row i
                 const uint8_t* r2 = srow + (9 + L) * EXT_PITCH;           // padded row i+1
-                const int d_x = (int)r1[xa] - (int)r1[xr];                // Diff_of_Gauss.cpp:226
-                const int d_y = (int)r0[xj] - (int)r2[xj];                // :227
+                const int d_x = (int)left[L] - (int)r1[xr];               // Diff_of_Gauss.cpp:226
+                const int d_y = (int)up[L] - (int)r2[xj];                 // :227
                 const int d_s = (int)self[L - 1] - (int)self[L + 1];      // :228
-                if (d_x == 0 || d_y == 0 || d_s == 0) {
-                    int nv;  // exactly singular: the test is value/255 > 0.03f
-                    listed[L - 1] = feature_point_localization(d_x, d_y, d_s, (int)self[L], nv);
-                } else {
-                    // three non-zero differences: queue the site so that the workgroup evaluates
-                    // its queue on dense lanes afterwards
-                    const unsigned int q = atomicAdd(&qn, 1u);
-                    queue[q] = make_uint2((uint32_t)(d_x + 256) | ((uint32_t)(d_y + 256) << 10) | ((uint32_t)(d_s + 256) << 20),
-                                          self[L] | ((uint32_t)((L - 1) * 256 + threadIdx.x) << 8));
-                }
+                nz = d_x != 0 && d_y != 0 && d_s != 0;
+                // exactly singular otherwise: the quadratic term is +-0 and the test is
+                // value/255.0f > 0.03f, which holds from 8 on (8/255 = 0.03137, 7/255 = 0.02745; checked
+                // over 0..255 in tests/test_oracle_kat.py::test_feature_point_localization_oracle)
+                listed[L - 1] = !nz && self[L] >= 8u;
+                dpack = (uint32_t)(d_x + 256) | ((uint32_t)(d_y + 256) << 10) | ((uint32_t)(d_s + 256) << 20);
             }
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(nz);
+            if (nz) {
+                const unsigned int slot = nw + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                wq[slot] = make_uint2(dpack, self[L] | ((uint32_t)((L - 1) * 64 + lane) << 8));
+            }
+            queued[L - 1] = nz;
+            nw += (unsigned int)__builtin_popcountll(m);
         }
-    }
-    if (LOC) {
-        __syncthreads();
-        const unsigned int n = qn;
-        for (unsigned int q = threadIdx.x; q < n; q += 256) {
-            const uint2 e = queue[q];
-            int nv;
-            // table lookup for small differences (all of them on ordinary frames), closed form otherwise;
-            // dense lanes with independent loads, so the table's latency overlaps across the queue
-            qkeep[e.y >> 8] = feature_point_localization((int)(e.x & 1023u) - 256, (int)((e.x >> 10) & 1023u) - 256,
-                                                         (int)(e.x >> 20) - 256, (int)(e.y & 255u), nv, g.loc_lut);
-        }
-        __syncthreads();
+        if (nw) {  // wave-uniform
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (unsigned int q = lane; q < nw; q += 64) {
+                const uint2 e = wq[q];
+                int nv;
+                // table lookup for small differences (all of them on ordinary frames), closed form otherwise
+                wk[e.y >> 8] = feature_point_localization((int)(e.x & 1023u) - 256, (int)((e.x >> 10) & 1023u) - 256,
+                                                          (int)(e.x >> 20) - 256, (int)(e.y & 255u), nv, g.loc_lut);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-        for (int L = 0; L < 3; ++L) listed[L] = listed[L] || qkeep[L * 256 + threadIdx.x];
+            for (int L = 0; L < 3; ++L)
+                if (queued[L]) listed[L] = wk[L * 64 + lane] != 0;
+        }
     }
     const int word = blockIdx.x * 4 + wave;  // = lj >> 6, wave-uniform
     if (word < wpr) {

@@ -92,6 +92,9 @@ __device__ __forceinline__ void harris_strip_rows(const HarrisStripArgs& a, cons
     bool inter[4];  // NMS2 is evaluated for columns [2, cols-2)
 #pragma unroll
     for (int k = 0; k < 4; ++k) inter[k] = lane_out && x0 + k >= 2 && x0 + k < cols - 2;
+    unsigned long long inter_m[4];  // the same as wave masks: the keypoint words are built on the scalar unit
+#pragma unroll
+    for (int k = 0; k < 4; ++k) inter_m[k] = __builtin_amdgcn_ballot_w64(inter[k]);
 
     auto load_row = [&](int t) -> uint32_t {
         const uint8_t* row = src + (size_t)reflect101(t, rows) * cols;
@@ -159,6 +162,7 @@ __device__ __forceinline__ void harris_strip_rows(const HarrisStripArgs& a, cons
         if (b >= 0 && b < rows) {  // wave-uniform
             int V[3][4];
             if (b - 1 < 0 || b + 1 >= rows) {  // wave-uniform: first / last image row
+                asm volatile("");              // keeps this a branch: if-converted it is 24 selects on every row
                 const bool top_rep = b - 1 < 0, bot_rep = b + 1 >= rows;
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
@@ -229,6 +233,7 @@ __device__ __forceinline__ void harris_strip_rows(const HarrisStripArgs& a, cons
         for (int k = 0; k < 4; ++k) Cb[k] = __float_as_uint(__builtin_rintf(__uint_as_float(min(Rb[k], 0x437f0000u))));
         if (__builtin_amdgcn_ballot_w64(h4n[2] >= 0x4f000000u)) {
             // rare, wave-uniform: x86 cvRound wraps responses >= 2^31 to INT_MIN -> 0 in the view
+            asm volatile("");  // not to be if-converted
 #pragma unroll
             for (int k = 0; k < 4; ++k) Cb[k] = Rb[k] < 0x4f000000u ? Cb[k] : 0u;
         }
@@ -257,7 +262,7 @@ __device__ __forceinline__ void harris_strip_rows(const HarrisStripArgs& a, cons
                     const bool pass = inter[k] && Ry[k] >= w4;
                     n2[k] = pass ? w4 : 0u;
                     // cvt(w4) > 253 (Harris_corners.cpp:139): 253.5 <= w4 < 2^31 as one unsigned range test
-                    kpw[k] = __builtin_amdgcn_ballot_w64(pass && w4 - 0x437d8000u < 0x4f000000u - 0x437d8000u);
+                    kpw[k] = __builtin_amdgcn_ballot_w64(Ry[k] >= w4) & __builtin_amdgcn_ballot_w64(w4 - 0x437d8000u < 0x4f000000u - 0x437d8000u) & inter_m[k];
                 }
             }
             if (lane_out) {
