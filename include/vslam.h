@@ -198,6 +198,20 @@ int vslam_pyramid_get_gradients(const vslam_pyramid* pyr, int octave, int level,
 int vslam_dog_extrema(vslam_ctx* ctx, const vslam_pyramid* pyr, int octave, int window, int min_contrast,
                       uint64_t* bits, vslam_point* out, size_t cap, size_t* count);
 
+/* EXTENSION, not a reference function (note under the table): the dense
+ * 3x3x3 scale-space test the north star's wording names.  The rule of Diff_of_Gauss.cpp:282-287
+ * (candidate iff the value equals the minimum or the maximum of its window, ties included) and the
+ * replicate border of padOctave (:260), applied to EVERY pixel of DoG levels 1..3 with the full
+ * 3x3x3 neighbourhood (the reference tests a half-open 2x2x3 window on a stride-3 lattice:
+ * vslam_dog_extrema above is that, and is what parity is judged on).
+ *   bits (may be NULL): 3 levels x rows x words_per_row uint64 words, words_per_row = (cols+63)/64,
+ *     bit (x & 63) of word [((level-1)*rows + y)*words_per_row + x/64].
+ *   out/cap/count: candidates with value >= min_contrast in (level, y, x) order as
+ *     SLAM::point(y+1, x+1, value, 1, octave, level) - padded coordinates like :289;
+ *     *count = total (may exceed cap). */
+int vslam_dog_extrema_dense(vslam_ctx* ctx, const vslam_pyramid* pyr, int octave, int min_contrast, uint64_t* bits,
+                            vslam_point* out, size_t cap, size_t* count);
+
 /* The same function through its call to FeaturePointLocalization (Diff_of_Gauss.cpp:290,
  * :223-251): exactly the points the reference appends to `keypoints`, in its order, with the
  * value rewritten at :246.  The contrast test is evaluated for EVERY candidate with the

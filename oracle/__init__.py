@@ -100,6 +100,8 @@ def lib():
         L.vo_extrema_lattice.restype = None
         L.vo_dog_extrema.argtypes = [C.POINTER(_Pyr), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
         L.vo_dog_extrema.restype = C.c_size_t
+        L.vo_dog_extrema_dense.argtypes = [C.POINTER(_Pyr), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
+        L.vo_dog_extrema_dense.restype = C.c_size_t
         L.vo_feature_point_localization.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
         L.vo_dog_keypoints.argtypes = [C.POINTER(_Pyr), C.c_int, C.c_int, C.c_void_p, C.c_size_t]
         L.vo_dog_keypoints.restype = C.c_size_t
@@ -343,6 +345,16 @@ class Pyramid:
         pts = np.zeros(n, POINT_DTYPE)
         if n:
             lib().vo_dog_extrema(self._p, octave, window, min_contrast, None, pts.ctypes.data, n)
+        return mask, pts
+
+    def extrema_dense(self, octave: int, min_contrast: int = 8):
+        """Extension: dense 3x3x3 test; (mask[3, rows, cols] u8, points[POINT_DTYPE])."""
+        r, c = self.sizes[octave]
+        mask = np.zeros((3, r, c), np.uint8)
+        n = lib().vo_dog_extrema_dense(self._p, octave, min_contrast, mask.ctypes.data, None, 0)
+        pts = np.zeros(n, POINT_DTYPE)
+        if n:
+            lib().vo_dog_extrema_dense(self._p, octave, min_contrast, None, pts.ctypes.data, n)
         return mask, pts
 
     def keypoints(self, octave, window=3):

@@ -855,6 +855,44 @@ size_t vo_dog_extrema(const vo_pyramid* p, int octave, int window, int min_contr
     return n;
 }
 
+/* Extension, NOT a restatement of reference code (note under the table): the
+ * dense 3x3x3 scale-space test the north star's wording names.  Same rule as :282-287 (a site is a
+ * candidate iff its value equals the minimum or the maximum of its window, ties included), same
+ * replicate border as padOctave (:260), but on EVERY pixel of levels 1..3 with the full 3x3x3
+ * neighbourhood instead of the half-open 2x2x3 window on the stride-3 lattice.  Points carry padded
+ * coordinates (row+1, col+1, padding 1) like :289, in (level, row, col) order. */
+size_t vo_dog_extrema_dense(const vo_pyramid* p, int octave, int min_contrast, uint8_t* mask, vo_point* out, size_t cap) {
+    if (!p || octave < 0 || octave >= p->n_octaves) return 0;
+    int rows = p->rows[octave], cols = p->cols[octave];
+    size_t n = 0;
+    for (int level = 1; level < VO_NUM_DOGS - 1; level++)
+        for (int y = 0; y < rows; y++)
+            for (int x = 0; x < cols; x++) {
+                int v = p->dog[octave][level][(size_t)y * cols + x], mn = 256, mx = -1;
+                for (int l = level - 1; l <= level + 1; l++)
+                    for (int u = y - 1; u <= y + 1; u++)
+                        for (int w = x - 1; w <= x + 1; w++) {
+                            int t = p->dog[octave][l][(size_t)clampi(u, 0, rows - 1) * cols + clampi(w, 0, cols - 1)];
+                            if (t < mn) mn = t;
+                            if (t > mx) mx = t;
+                        }
+                int cand = (v == mn || v == mx);
+                if (mask) mask[((size_t)(level - 1) * rows + y) * cols + x] = (uint8_t)cand;
+                if (cand && v >= min_contrast) {
+                    if (out && n < cap) {
+                        out[n].row = y + 1;
+                        out[n].col = x + 1;
+                        out[n].value = v;
+                        out[n].padding = 1;
+                        out[n].octave = octave;
+                        out[n].level = level;
+                    }
+                    n++;
+                }
+            }
+    return n;
+}
+
 /* ------------------------------------------------------------------------- */
 /* CPU baseline driver                                                        */
 /* ------------------------------------------------------------------------- */

@@ -147,6 +147,11 @@ void vo_extrema_lattice(int rows, int cols, int window, int* lat_rows, int* lat_
 size_t vo_dog_extrema(const vo_pyramid* p, int octave, int window, int min_contrast, uint8_t* mask,
                       vo_point* out, size_t cap);
 
+/* Extension (not reference code): dense 3x3x3 test on every pixel of levels 1..3, replicate border,
+ * ties count; mask[(level-1)*rows*cols + y*cols + x]; points (row+1, col+1, value, 1, octave, level)
+ * with value >= min_contrast in (level, row, col) order. */
+size_t vo_dog_extrema_dense(const vo_pyramid* p, int octave, int min_contrast, uint8_t* mask, vo_point* out, size_t cap);
+
 /* Automatic kernel width for CV_32F input (cvRound(sigma*4*2+1)|1) and getGaussianKernel(n, sigma, CV_32F). */
 int vo_gauss_ksize_f32(double sigma);
 int vo_gauss_kernel_f32(int n, double sigma, float* k);

@@ -118,6 +118,7 @@ def test_cxx_results_match_oracle(built, tmp_path):
     assert [o["candidates"] for o in got["octaves"]] == want_oct
     assert [o["keypoints"] for o in got["octaves"]] == [len(pyr.keypoints(o, 3)) for o in range(4)]
     assert [o["oriented"] for o in got["octaves"]] == [len(pyr.filter_keypoints(o, pyr.keypoints(o, 3))) for o in range(4)]
+    assert [o["dense_3x3x3"] for o in got["octaves"]] == [len(pyr.extrema_dense(o, 8)[1]) for o in range(4)]
     assert got["per_point_mismatch"] == 0
 
 

@@ -39,11 +39,13 @@ def main():
         for o in range(a.octaves):
             ms_kp, (kp, n) = timed(lambda: p.keypoints(o, 3, cap=1 << 18), a.reps)
             ms_cand, (_, cand, nc) = timed(lambda: p.extrema(o, 3, 8, cap=1 << 18), a.reps)
+            ms_dense, (_, _, nd) = timed(lambda: p.extrema_dense(o, 8, cap=1 << 18), max(a.reps // 4, 2))  # extension: dense 3x3x3 test
             ms_f, (fk, nf) = timed(lambda: p.filter_keypoints(o, kp, cap=1 << 18), a.reps)
             ms_s, (desc, ok) = timed(lambda: p.sift_descriptors(o, fk), a.reps) if nf else (0.0, (None, []))
             rec["octaves"].append({"octave": o, "candidates_ge8": int(nc), "keypoints": int(n), "oriented": int(nf),
                                    "descriptors_defined": int(sum(ok)), "extrema_ms": ms_cand, "keypoints_ms": ms_kp,
-                                   "filter_keypoints_ms": ms_f, "sift_ms": ms_s})
+                                   "filter_keypoints_ms": ms_f, "sift_ms": ms_s,
+                                   "dense_3x3x3_ge8": int(nd), "dense_3x3x3_ms": ms_dense})
         rec["total_ms"] = ms_build + sum(r["keypoints_ms"] + r["filter_keypoints_ms"] + r["sift_ms"] for r in rec["octaves"])
         out["frames"][kind] = rec
         p.close()

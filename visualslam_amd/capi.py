@@ -107,6 +107,7 @@ SIGNATURES = {
     "vslam_pyramid_get_dog": (_I, [_P, _I, _I, _P, _Z]),
     "vslam_pyramid_get_gradients": (_I, [_P, _I, _I, _P, _P, _P, _P, _Z]),
     "vslam_dog_extrema": (_I, [_P, _P, _I, _I, _I, _P, _P, _Z, C.POINTER(_Z)]),
+    "vslam_dog_extrema_dense": (_I, [_P, _P, _I, _I, _P, _P, _Z, C.POINTER(_Z)]),
     "vslam_dog_keypoints": (_I, [_P, _P, _I, _I, _P, _Z, C.POINTER(_Z)]),
     "vslam_localize_points": (_I, [_P, _P, _Z, _P, _P]),
     "vslam_filter_keypoints": (_I, [_P, _P, _I, _P, _Z, _P, _Z, C.POINTER(_Z)]),
@@ -511,6 +512,17 @@ class Pyramid:
         n = C.c_size_t()
         self.ctx._chk(lib().vslam_dog_extrema(self.ctx._h, self._h, octave, window, min_contrast, bits.ctypes.data, pts.ctypes.data, cap, C.byref(n)), "vslam_dog_extrema")
         mask = np.unpackbits(bits.view(np.uint8), axis=-1, bitorder="little")[..., :lc] if lc else np.zeros((3, lr, 0), np.uint8)
+        return mask, pts[: min(n.value, cap)], n.value
+
+    def extrema_dense(self, octave: int, min_contrast: int = 8, cap: int = 1 << 22):
+        """Extension: dense 3x3x3 test on every pixel; (mask[3, rows, cols] u8, points, total count)."""
+        r, c = self.sizes[octave] if 0 <= octave < self.n_octaves else (0, 0)
+        wpr = (c + 63) // 64
+        bits = np.zeros((3, r, max(wpr, 1)), np.uint64)
+        pts = np.zeros(cap, POINT_DTYPE)
+        n = C.c_size_t()
+        self.ctx._chk(lib().vslam_dog_extrema_dense(self.ctx._h, self._h, octave, min_contrast, bits.ctypes.data, pts.ctypes.data, cap, C.byref(n)), "vslam_dog_extrema_dense")
+        mask = np.unpackbits(bits.view(np.uint8), axis=-1, bitorder="little")[..., :c] if c else np.zeros((3, r, 0), np.uint8)
         return mask, pts[: min(n.value, cap)], n.value
 
     def keypoints(self, octave: int, window: int = 3, cap: int = 1 << 22):

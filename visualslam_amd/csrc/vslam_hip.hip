@@ -22,6 +22,7 @@
 #include "kernels_orient_batch.hip.h"
 #include "kernels_compact.hip.h"
 #include "kernels_sift.hip.h"
+#include "kernels_extrema_dense.hip.h"
 #include "vslam_internal.h"
 
 using namespace vslam;
@@ -91,7 +92,7 @@ static int fail(vslam_ctx* c, int code, const std::string& msg) {
 static const char* const kKernelNames =
     "k_resize_linear2x\nk_blur_h_generic\nk_blur_v_generic\n"
     "k_dog5\nk_resize_nearest_half\nk_extrema\nk_pyr_octave\n"
-    "k_gauss_v_strip\nk_gauss_h_strip\nk_resize_linear2x_slide\nk_resize_nearest_half_v4\nk_extrema_w3\nk_localize_points\nk_points_localize_value\nk_orient_keypoints\nk_edge_response_windows\nk_level_gradients\nk_pack_rows\nk_edge_flags\nk_orient_survivors\n"
+    "k_gauss_v_strip\nk_gauss_h_strip\nk_resize_linear2x_slide\nk_resize_nearest_half_v4\nk_extrema_w3\nk_extrema_dense\nk_localize_points\nk_points_localize_value\nk_orient_keypoints\nk_edge_response_windows\nk_level_gradients\nk_pack_rows\nk_edge_flags\nk_orient_survivors\n"
     "k_harris_strip\nk_flag_count\nk_chunk_scan\nk_flag_scatter\nk_level_gradients\nk_sift_descriptors";
 
 static std::pair<hipEvent_t, hipEvent_t>* timing_slot(vslam_ctx* c);
@@ -1179,6 +1180,47 @@ static int dog_points_host(vslam_ctx* c, const vslam_pyramid* py, int octave, in
 int vslam_dog_extrema(vslam_ctx* c, const vslam_pyramid* py, int octave, int window, int min_contrast, uint64_t* bits,
                       vslam_point* out, size_t cap, size_t* count) {
     return dog_points_host(c, py, octave, window, min_contrast, 0, bits, out, cap, count);
+}
+
+int vslam_dog_extrema_dense(vslam_ctx* c, const vslam_pyramid* py, int octave, int min_contrast, uint64_t* bits,
+                            vslam_point* out, size_t cap, size_t* count) {
+    TRY(bind_device(c));
+    ARGCHK(c, py && py->ctx == c && count && (out || cap == 0), "dense extrema: bad arguments");
+    if (octave < 0 || octave >= py->layout.n_octaves) return fail(c, VSLAM_ERR_RANGE, "octave out of range");
+    ARGCHK(c, min_contrast >= 0 && min_contrast <= 65535, "dense extrema: min_contrast out of range");
+    const vslam_batch_layout& L = py->layout;
+    DenseGeom g;
+    g.rows = L.rows[octave], g.cols = L.cols[octave], g.pitch = L.pitch[octave];
+    g.wpr = (g.cols + 63) / 64;
+    g.min_contrast = min_contrast;
+    g.P = (unsigned int)((size_t)g.rows * g.pitch);
+    g.dog_off = (unsigned int)(L.octave_offset[octave] + (size_t)VSLAM_NUM_LEVELS * g.P);
+    const size_t words = (size_t)3 * g.rows * g.wpr;
+    const unsigned int ocap = (unsigned int)std::min<size_t>(cap, 0x7fffffff);
+    TRY(ws_reserve(c, 2 * ws_need(words * 8) + ws_need(sizeof(vslam_point) * (size_t)ocap) + 256 + ws_need(4 * compaction_ws_elems(words, 1))));
+    unsigned long long* d_bits = ws_take<unsigned long long>(c, words);
+    unsigned long long* d_lf = ws_take<unsigned long long>(c, words);
+    vslam_point* d_pts = ws_take<vslam_point>(c, ocap);
+    unsigned int* d_n = ws_take<unsigned int>(c, 1);
+    unsigned int* d_cws = ws_take<unsigned int>(c, compaction_ws_elems(words, 1));
+    HIPCHK(c, hipMemsetAsync(d_n, 0, 4, c->stream));
+    // a lane walks g.seg rows: long segments amortise the two halo rows, short ones give a single image
+    // enough waves to hide the loads (about 8 per SIMD)
+    const long waves_per_rowseg = 4L * (((g.cols + 3) / 4 + 255) / 256);
+    const long segs_wanted = std::max<long>(1, 8192 / waves_per_rowseg);
+    g.seg = (int)std::min<long>(XD_SEG_MAX, std::max<long>(4, (g.rows + segs_wanted - 1) / segs_wanted));
+    LAUNCH(c, "k_extrema_dense", k_extrema_dense, dim3(((g.cols + 3) / 4 + 255) / 256, (g.rows + g.seg - 1) / g.seg, 1), dim3(256),
+           py->d_block, L.pyramid_frame_bytes, g, bits ? d_bits : nullptr, d_lf, words);
+    DenseDogEntries ent{d_lf, words, py->d_block, L.pyramid_frame_bytes, g, octave, d_pts};
+    TRY(enqueue_compaction(c, ent, words, 1, d_cws, ocap, d_n, 0));
+    unsigned int n = 0;
+    HIPCHK(c, hipMemcpyAsync(&n, d_n, 4, hipMemcpyDeviceToHost, c->stream));
+    if (bits) HIPCHK(c, hipMemcpyAsync(bits, d_bits, words * 8, hipMemcpyDeviceToHost, c->stream));
+    TRY(vslam_ctx_sync(c));
+    *count = n;
+    const size_t m = std::min<size_t>(n, ocap);
+    if (m) HIPCHK(c, hipMemcpy(out, d_pts, m * sizeof(vslam_point), hipMemcpyDeviceToHost));
+    return VSLAM_OK;
 }
 
 int vslam_dog_keypoints(vslam_ctx* c, const vslam_pyramid* py, int octave, int window, vslam_point* out, size_t cap,

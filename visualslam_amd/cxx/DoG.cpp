@@ -31,8 +31,10 @@ int main(int argc, char** argv) {
             SIFT(reducedKeypoints, featureDescriptors_vec, pyramid, octave, &defined);  // :791
             for (unsigned char d : defined) undefined += d == 0;
             scaleSpaceCandidates(candidates, pyramid, octave, windowSize);
-            std::printf("%s{\"octave\": %d, \"candidates\": %zu, \"keypoints\": %zu, \"oriented\": %zu}", octave ? ", " : "", octave,
-                        candidates.size(), keypoints.size(), reducedKeypoints.size());
+            std::vector<SLAM::point> dense;  // extension: the dense 3x3x3 test (no reference counterpart)
+            scaleSpaceExtremaDense(dense, pyramid, octave);
+            std::printf("%s{\"octave\": %d, \"candidates\": %zu, \"keypoints\": %zu, \"oriented\": %zu, \"dense_3x3x3\": %zu}", octave ? ", " : "",
+                        octave, candidates.size(), keypoints.size(), reducedKeypoints.size(), dense.size());
             if (!keypoints.empty()) {  // the per-point entry point agrees with the fused edge test on the first keypoint
                 const SLAM::point& k0 = keypoints.front();
                 const float r0 = computeEdgeResponse(k0, pyramid.octaveGradX(octave).at(k0.level), pyramid.octaveGradY(octave).at(k0.level));

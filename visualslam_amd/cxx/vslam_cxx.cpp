@@ -285,6 +285,12 @@ void scaleSpaceCandidates(std::vector<SLAM::point>& candidates, GaussPyramid& py
     });
 }
 
+void scaleSpaceExtremaDense(std::vector<SLAM::point>& candidates, GaussPyramid& pyramid, int octave, int minContrast) {
+    append_points(candidates, [&](vslam_ctx* c, vslam_point* out, size_t cap, size_t* n) {
+        return vslam_dog_extrema_dense(c, pyramid.handle(), octave, minContrast, nullptr, out, cap, n);
+    });
+}
+
 bool FeaturePointLocalization(std::vector<cv::Mat>& dogs_padded, std::vector<SLAM::point>& keypoints, int level, SLAM::point& point) {
     vslam_ctx* c = default_context();
     if (level < 1 || level + 1 >= (int)dogs_padded.size()) throw vslam::Error(VSLAM_ERR_RANGE, "FeaturePointLocalization: level out of range");

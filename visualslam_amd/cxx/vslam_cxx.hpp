@@ -143,6 +143,10 @@ void initialKeypointDetection(std::vector<SLAM::point>& keypoints, GaussPyramid&
 // 8 = the contrast test for the degenerate, exactly-singular cases).
 void scaleSpaceCandidates(std::vector<SLAM::point>& candidates, GaussPyramid& pyramid, int octave, int windowSize,
                           int minContrast = 8);
+// EXTENSION (no reference counterpart; SURVEY.md section 8a, note): the dense 3x3x3 scale-space test on
+// every pixel of levels 1..3 - rule of :282-287, replicate border of :260, points in (level, row, col)
+// order with padded coordinates like :289 (vslam_dog_extrema_dense).
+void scaleSpaceExtremaDense(std::vector<SLAM::point>& candidates, GaussPyramid& pyramid, int octave, int minContrast = 8);
 // bool FeaturePointLocalization(...), Diff_of_Gauss.cpp:223-251: reads the three finite
 // differences from the padded DoG stack (:226-228) on the host, evaluates the contrast test on
 // the GPU (vslam_localize_points), updates point.value and appends the point when kept.
