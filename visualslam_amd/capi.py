@@ -411,6 +411,10 @@ class Context:
     # ---- device-resident batch (torch CUDA tensors)
     def detect_batch(self, params: Params, frames, **outs):
         """frames: uint8 CUDA tensor [n, rows, cols]; outs: CUDA tensors by BatchOut field name."""
+        n, bo, fstride = self._batch_args(params, frames, outs)
+        self._chk(lib().vslam_detect_batch_dev(self._h, C.byref(params), frames.data_ptr(), fstride, n, C.byref(bo)), "vslam_detect_batch_dev")
+
+    def _batch_args(self, params: Params, frames, outs):
         import torch
 
         n = frames.shape[0]
@@ -452,7 +456,7 @@ class Context:
                     raise ValueError(f"detect_batch: unknown output {k!r}")
                 need(k, t, *spec[k])
                 setattr(bo, k, t.data_ptr())
-        self._chk(lib().vslam_detect_batch_dev(self._h, C.byref(params), frames.data_ptr(), frames.stride(0), n, C.byref(bo)), "vslam_detect_batch_dev")
+        return n, bo, (frames.stride(0) if n > 1 else N)  # a size-1 dimension may carry any stride
 
     def kernel_timing_enable(self, name: str | None):
         self._chk(lib().vslam_kernel_timing_enable(self._h, name.encode() if name else None), "vslam_kernel_timing_enable")
