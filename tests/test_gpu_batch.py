@@ -134,6 +134,21 @@ def test_batch_larger_than_one_chunk(env):
     assert out["dog_counts"][256] != out["dog_counts"][0] or out["harris_counts"][256] != out["harris_counts"][0]
 
 
+@pytest.mark.parametrize("mode", ["candidates", "localized", "oriented"])
+def test_batch_of_40_frames_takes_the_gated_launch_order(env, mode):
+    # from 32 frames on the side streams are ordered differently (vslam_hip.hip, enqueue_dog): the Harris
+    # chain and the localizing scan wait for the last LDS-tiled octave kernel, the plain scan does not.
+    # Same results, every list mode, frames with different content
+    ctx, torch = env
+    frames = synth.frames_np(40, 96, 160, stream_id=21)
+    frames[5] = synth.frame_np(96, 160, kind="noise")
+    frames[39] = synth.frame_np(96, 160, frame=3, stream_id=2, kind="noise")
+    kw = dict(localize=int(mode != "candidates"), orient=int(mode == "oriented"))
+    p, L, out = run_batch(ctx, torch, frames, n_octaves=3, harris_cap=4096, dog_cap=8192, **kw)
+    for f in (0, 5, 17, 38, 39):
+        check_frame(p, L, out, f, frames[f], 3)
+
+
 def test_batch_ragged_size_and_small_caps(env):
     ctx, torch = env
     frames = synth.frames_np(2, 75, 131, stream_id=9)
