@@ -122,6 +122,18 @@ struct DogEntries {  // entry = one 64-site word of the (octave, level, lattice 
         pt.row = in.i;
         pt.col = j;
         pt.value = pyr[f * pframe + in.row_off + (j - g.pad)];
+        if (g.localize) {
+            // the list holds FeaturePointLocalization's survivors: the record carries the value that
+            // function stores at Diff_of_Gauss.cpp:246, formed here while the record is written (it was a
+            // pass of its own over the list, a millisecond on the side chain of a 256-frame batch)
+            const int o = in.octave;
+            const size_t P = (size_t)g.rows[o] * g.pitch[o];
+            const uint8_t* dog = pyr + f * pframe + g.oct_off[o] + (size_t)VSLAM_NUM_LEVELS * P;
+            int d_x, d_y, d_s, nv;
+            dog_differences(dog, P, g.rows[o], g.cols[o], g.pitch[o], g.pad, in.level, in.i, j, d_x, d_y, d_s);
+            feature_point_localization(d_x, d_y, d_s, pt.value, nv, g.loc_lut);
+            pt.value = nv;
+        }
         pt.padding = g.pad;
         pt.octave = in.octave;
         pt.level = in.level;
@@ -210,26 +222,6 @@ struct OrientBatchEntries {  // entry = one survivor of a frame: 36-bit mask of 
         out[slot] = pt;
     }
 };
-
-// localize mode: rewrite the value of the points one octave has just appended the way
-// FeaturePointLocalization does at Diff_of_Gauss.cpp:246.  One thread per list record (dense,
-// unlike the per-word emit loop); records [begins[f], min(counts[f], cap)) of frame f, begins ==
-// nullptr meaning 0.  grid = (ceil(most records an octave can add / 256), frames).
-__global__ __launch_bounds__(256) void k_points_localize_value(vslam_point* __restrict__ pts, const unsigned int* __restrict__ begins,
-                                                               const unsigned int* __restrict__ counts, unsigned int cap,
-                                                               const uint8_t* __restrict__ pyr, size_t pframe, ExtGeom g) {
-    const int f = blockIdx.y;
-    const unsigned int i = (begins ? begins[f] : 0u) + blockIdx.x * 256 + threadIdx.x;
-    if (i >= min(counts[f], cap)) return;
-    vslam_point& pt = pts[(size_t)f * cap + i];
-    const int o = pt.octave;
-    const size_t P = (size_t)g.rows[o] * g.pitch[o];
-    const uint8_t* dog = pyr + f * pframe + g.oct_off[o] + (size_t)VSLAM_NUM_LEVELS * P;
-    int d_x, d_y, d_s, nv;
-    dog_differences(dog, P, g.rows[o], g.cols[o], g.pitch[o], g.pad, pt.level, pt.row, pt.col, d_x, d_y, d_s);
-    feature_point_localization(d_x, d_y, d_s, pt.value, nv, g.loc_lut);
-    pt.value = nv;
-}
 
 // Block-wide exclusive scan for 256 threads; `total` = block sum.
 __device__ __forceinline__ unsigned int block_excl_scan_256(unsigned int v, unsigned int* wsum, unsigned int& total) {

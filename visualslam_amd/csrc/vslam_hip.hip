@@ -92,7 +92,7 @@ static int fail(vslam_ctx* c, int code, const std::string& msg) {
 static const char* const kKernelNames =
     "k_resize_linear2x\nk_blur_h_generic\nk_blur_v_generic\n"
     "k_dog5\nk_resize_nearest_half\nk_extrema\nk_pyr_octave\n"
-    "k_gauss_v_strip\nk_gauss_h_strip\nk_resize_linear2x_slide\nk_resize_nearest_half_v4\nk_extrema_w3\nk_extrema_dense\nk_localize_points\nk_points_localize_value\nk_orient_keypoints\nk_edge_response_windows\nk_level_gradients\nk_pack_rows\nk_edge_flags\nk_orient_survivors\n"
+    "k_gauss_v_strip\nk_gauss_h_strip\nk_resize_linear2x_slide\nk_resize_nearest_half_v4\nk_extrema_w3\nk_extrema_dense\nk_localize_points\nk_orient_keypoints\nk_edge_response_windows\nk_level_gradients\nk_pack_rows\nk_edge_flags\nk_orient_survivors\n"
     "k_harris_strip\nk_flag_count\nk_chunk_scan\nk_flag_scatter\nk_level_gradients\nk_sift_descriptors";
 
 static std::pair<hipEvent_t, hipEvent_t>* timing_slot(vslam_ctx* c);
@@ -610,20 +610,7 @@ static int enqueue_dog(vslam_ctx* c, const vslam_params& p, const vslam_batch_la
         if (do_extrema && points && counts) {
             StreamSwap sw(c, side ? side : c->stream);
             DogEntries ent{s.lflags, L.bits_frame_words, pyr, pframe, g, o, o + 1, points};
-            // localize mode: the records this octave appends get their values rewritten right away
-            // (a dense pass over [count before, count after)), beside the next octave's kernels
-            const size_t oct_max = std::min<size_t>((size_t)3 * L.lat_rows[o] * L.lat_cols[o], p.dog_cap);
-            const bool rewrite = p.localize && p.dog_cap && oct_max;
-            if (rewrite) {
-                if (o > 0)
-                    HIPCHK(c, hipMemcpyAsync(s.pbegin, counts, sizeof(unsigned int) * (size_t)nf, hipMemcpyDeviceToDevice, c->stream));
-                else
-                    HIPCHK(c, hipMemsetAsync(s.pbegin, 0, sizeof(unsigned int) * (size_t)nf, c->stream));
-            }
             TRY(enqueue_compaction(c, ent, (size_t)3 * L.lat_rows[o] * L.lat_words[o], nf, s.cws, p.dog_cap, counts, o > 0 ? 1 : 0));
-            if (rewrite)
-                LAUNCH(c, "k_points_localize_value", k_points_localize_value, dim3((unsigned)((oct_max + 255) / 256), nf), dim3(256), points,
-                       s.pbegin, counts, p.dog_cap, pyr, pframe, g);
         }
         }  // oo
     }
@@ -1162,9 +1149,6 @@ static int dog_points_host(vslam_ctx* c, const vslam_pyramid* py, int octave, in
         }
         DogEntries ent{d_lf, words, py->d_block, L.pyramid_frame_bytes, g, octave, octave + 1, d_pts};
         TRY(enqueue_compaction(c, ent, ow, 1, d_cws, p.dog_cap, d_n, 0));
-        if (localize && p.dog_cap)
-            LAUNCH(c, "k_points_localize_value", k_points_localize_value, dim3((p.dog_cap + 255) / 256, 1), dim3(256), d_pts,
-                   (const unsigned int*)nullptr, d_n, p.dog_cap, py->d_block, L.pyramid_frame_bytes, g);
     }
     unsigned int n = 0;
     HIPCHK(c, hipMemcpyAsync(&n, d_n, 4, hipMemcpyDeviceToHost, c->stream));
