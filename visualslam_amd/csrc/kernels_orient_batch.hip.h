@@ -32,14 +32,21 @@ struct OrientBatchGeom {
     int kn[VSLAM_MAX_OCTAVES][VSLAM_NUM_LEVELS];
 };
 
-// grid = (ceil(cap/256), frames): flags[f][i/64] bit i%64 = record i of frame f passes the edge test
-__global__ __launch_bounds__(256) void k_edge_flags(const vslam_point* __restrict__ pts, const unsigned int* __restrict__ counts,
-                                                     unsigned int cap, const uint8_t* __restrict__ pyr, size_t pframe,
-                                                     OrientBatchGeom g, unsigned long long* __restrict__ flags, size_t fwords) {
+// grid = (ceil(cap/256), frames): flags[f][i/64] bit i%64 = record i of frame f passes the edge test.
+// Records [begins[f], ends[f]) of frame f (begins == nullptr: from 0).  The list is in octave order and
+// complete octave by octave, so the records of octave 0 (four fifths of a 1080p frame's list) are
+// tested as soon as they exist, beside the coarse octaves' kernels, and the rest when the list is
+// complete: the first launch writes every word (zeros past its range), the second leaves the words
+// below its range alone and ORs into the one the two ranges share.
+__global__ __launch_bounds__(256) void k_edge_flags(const vslam_point* __restrict__ pts, const unsigned int* __restrict__ begins,
+                                                     const unsigned int* __restrict__ ends, unsigned int cap,
+                                                     const uint8_t* __restrict__ pyr, size_t pframe, OrientBatchGeom g,
+                                                     unsigned long long* __restrict__ flags, size_t fwords) {
     const int f = blockIdx.y;
     const unsigned int i = blockIdx.x * 256 + threadIdx.x;
+    const unsigned int begin = begins ? min(begins[f], cap) : 0u, end = min(ends[f], cap);
     bool keep = false;
-    if (i < min(counts[f], cap)) {
+    if (i >= begin && i < end) {
         const vslam_point kp = pts[(size_t)f * cap + i];
         const int o = kp.octave;
         const uint8_t* G = pyr + f * pframe + g.oct_off[o] + (size_t)kp.level * g.rows[o] * g.pitch[o];
@@ -47,7 +54,17 @@ __global__ __launch_bounds__(256) void k_edge_flags(const vslam_point* __restric
         keep = edge_response_u8(G, g.pitch[o], g.rows[o], g.cols[o], kp.row, kp.col, kp.padding) < threshold;  // :335
     }
     const unsigned long long w = __ballot(keep);
-    if ((threadIdx.x & 63) == 0 && (i >> 6) < fwords) flags[(size_t)f * fwords + (i >> 6)] = w;
+    const unsigned int word = i >> 6;
+    if ((threadIdx.x & 63) == 0 && word < fwords) {
+        unsigned long long* dst = flags + (size_t)f * fwords + word;
+        if ((word + 1) * 64u <= begin) {
+            // below this launch's range: the earlier launch's word
+        } else if (word * 64u < begin) {
+            if (w) atomicOr(dst, w);  // the word the two ranges share
+        } else {
+            *dst = w;
+        }
+    }
 }
 
 // cv::magnitude / cv::phase of the level's Sobel gradients at one pixel (processGradients,

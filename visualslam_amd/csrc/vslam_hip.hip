@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <string>
 #include <set>
@@ -44,6 +45,7 @@ struct vslam_ctx {
     // run beside the VALU-bound pyramid kernels; forked from / joined to `stream` by events
     hipStream_t aux[2] = {nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr}, ev_oct[VSLAM_MAX_OCTAVES] = {};
+    hipEvent_t ev_list0 = nullptr, ev_edge = nullptr;  // octave 0's part of the DoG list is written / its edge test is done
     // recycled pyramid blocks: a GaussPyramid per image would otherwise pay hipMalloc + hipFree of
     // >100 MB each time (milliseconds, more than the kernels)
     std::vector<std::pair<size_t, void*>> block_cache;
@@ -146,6 +148,8 @@ static int ensure_aux(vslam_ctx* c) {
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
     }
     for (auto& e : c->ev_oct) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_list0, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_edge, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     return VSLAM_OK;
 }
@@ -515,12 +519,25 @@ static int enqueue_pyr_octave(vslam_ctx* c, double sigma0, int o, const OctPlan&
     return VSLAM_OK;
 }
 
+// The octave whose kernels the held-back side work of a batch waits for (enqueue_dog): the last
+// LDS-tiled one for batches of 32 frames or more, -1 (no gate) otherwise.
+static int dog_side_gate(const vslam_params& p, const vslam_batch_layout& L, int nf) {
+    int gate = -1;
+    if (nf >= 32)
+        for (int o = 0; o < L.n_octaves; ++o) {
+            const OctPath path = plan_octave(p.sigma0, o, L.rows[o], L.cols[o]).path;
+            if (path == OctPath::Tile0 || path == OctPath::Tile1) gate = o;
+        }
+    return gate;
+}
+
 // createPyramid (GaussPyramid.cpp:106-131) + initialKeypointDetection (Diff_of_Gauss.cpp:254)
 // for nf frames; pyr/bits/points are per-frame blocks with the given strides.
 static int enqueue_dog(vslam_ctx* c, const vslam_params& p, const vslam_batch_layout& L, const uint8_t* frames,
                        size_t fstep, size_t fframe, int nf, uint8_t* pyr, size_t pframe, DogScratch& s,
                        unsigned long long* bits, bool do_extrema, vslam_point* points, unsigned int* counts,
-                       hipStream_t side = nullptr, int* side_gate = nullptr) {
+                       hipStream_t side = nullptr, int* side_gate = nullptr,
+                       const std::function<int(int)>& after_list = nullptr, const std::function<int(int)>& after_octave = nullptr) {
     // `side`: stream for the extrema scans and the list compaction (they only read what the
     // octave kernels wrote); ordered after the octave kernels by events.  nullptr = same stream.
     //
@@ -536,12 +553,7 @@ static int enqueue_dog(vslam_ctx* c, const vslam_params& p, const vslam_batch_la
     //  * the scan with FeaturePointLocalization inside (params.localize, ~8x the instructions) is
     //    held back like the Harris chain: +0.5 % in the localize / orient / describe modes.
     // Small batches keep the eager order: there the chain's latency matters, not the issue slots.
-    int gate = -1;
-    if (side && nf >= 32)
-        for (int o = 0; o < L.n_octaves; ++o) {
-            const OctPath path = plan_octave(p.sigma0, o, L.rows[o], L.cols[o]).path;
-            if (path == OctPath::Tile0 || path == OctPath::Tile1) gate = o;
-        }
+    int gate = side ? dog_side_gate(p, L, nf) : -1;
     if (side_gate) *side_gate = gate;
     if (!p.localize) gate = -1;
     ExtGeom g;
@@ -584,6 +596,7 @@ static int enqueue_dog(vslam_ctx* c, const vslam_params& p, const vslam_batch_la
                    dim3(256), oct + (size_t)3 * P, pframe, pitch, s.bases + s.base_off[o + 1], s.bases_frame, L.pitch[o + 1], rows,
                    L.rows[o + 1], L.cols[o + 1]);
         if (side) HIPCHK(c, hipEventRecord(c->ev_oct[o], c->stream));
+        if (after_octave) TRY(after_octave(o));  // octave o's kernels are enqueued and ev_oct[o] marks their end
         if (o < gate) continue;  // scan + compaction of this octave are enqueued behind octave `gate`
         const int o_done = o;    // the octave whose kernels were enqueued last
         for (int oo = (o_done == gate ? 0 : o_done); oo <= o_done; ++oo) {
@@ -611,6 +624,7 @@ static int enqueue_dog(vslam_ctx* c, const vslam_params& p, const vslam_batch_la
             StreamSwap sw(c, side ? side : c->stream);
             DogEntries ent{s.lflags, L.bits_frame_words, pyr, pframe, g, o, o + 1, points};
             TRY(enqueue_compaction(c, ent, (size_t)3 * L.lat_rows[o] * L.lat_words[o], nf, s.cws, p.dog_cap, counts, o > 0 ? 1 : 0));
+            if (after_list) TRY(after_list(o));  // on the stream the list is written on, behind octave o's records
         }
         }  // oo
     }
@@ -1427,11 +1441,14 @@ struct OrientScratch {
     unsigned int* scounts = nullptr;      // [nf]
     unsigned long long* masks = nullptr;  // [nf][scap] histogram-peak masks
     unsigned int* cws = nullptr;          // compaction scratch
+    unsigned int* obegin = nullptr;       // [nf] list length after octave 0 (the early edge-test launch covers [0, obegin))
+    bool early_done = false;              // the early launch has been enqueued for this chunk
+    bool early_forked = false;            // ... on another stream: ev_edge marks its end
     size_t fwords = 0;
 };
 static size_t orient_scratch_bytes(const vslam_params& p, int nf) {
     const size_t fwords = ((size_t)p.dog_cap + 63) / 64, scap = p.oriented_cap;
-    return ws_need((size_t)nf * fwords * 8) + ws_need((size_t)nf * scap * 4) + ws_need((size_t)nf * 4) + ws_need((size_t)nf * scap * 8) +
+    return ws_need((size_t)nf * fwords * 8) + ws_need((size_t)nf * scap * 4) + 2 * ws_need((size_t)nf * 4) + ws_need((size_t)nf * scap * 8) +
            ws_need(4 * compaction_ws_elems(std::max(fwords, scap), nf));
 }
 static int orient_scratch_take(vslam_ctx* c, const vslam_params& p, int nf, OrientScratch& s) {
@@ -1440,23 +1457,29 @@ static int orient_scratch_take(vslam_ctx* c, const vslam_params& p, int nf, Orie
     s.flags = ws_take<unsigned long long>(c, (size_t)nf * s.fwords);
     s.surv = ws_take<unsigned int>(c, (size_t)nf * scap);
     s.scounts = ws_take<unsigned int>(c, nf);
+    s.obegin = ws_take<unsigned int>(c, nf);
+    s.early_done = false;
     s.masks = ws_take<unsigned long long>(c, (size_t)nf * scap);
     s.cws = ws_take<unsigned int>(c, compaction_ws_elems(std::max(s.fwords, scap), nf));
-    if (!s.flags || !s.surv || !s.scounts || !s.masks || !s.cws) return fail(c, VSLAM_ERR_NOMEM, "workspace sizing error (orient)");
+    if (!s.flags || !s.surv || !s.scounts || !s.obegin || !s.masks || !s.cws) return fail(c, VSLAM_ERR_NOMEM, "workspace sizing error (orient)");
     return VSLAM_OK;
 }
 
-// filterKeypoints for the keypoint lists of nf frames (kernels_orient_batch.hip.h), on the
-// context's current stream; the lists must be complete on that stream.
-static int enqueue_orient_batch(vslam_ctx* c, const vslam_params& p, const vslam_batch_layout& L, int nf, const uint8_t* pyr,
-                                size_t pframe, const vslam_point* points, const unsigned int* counts, OrientScratch& s,
-                                vslam_point* oriented, unsigned int* oriented_counts) {
+// Geometry / blur taps of the batched filterKeypoints and the LDS budgets of its two launches.
+struct OrientPlan {
     OrientBatchGeom g;
+    int need_lo = 0, need_hi = 0;  // LDS floats for the octaves whose magnitude region fits beside 3-4 other workgroups / at all
+    int split = 0;                 // first octave handled by the big-LDS launch
+};
+static int make_orient_plan(vslam_ctx* c, const vslam_params& p, const vslam_batch_layout& L, OrientPlan& pl) {
+    OrientBatchGeom& g = pl.g;
     std::memset(&g, 0, sizeof(g));
     g.n_oct = L.n_octaves;
-    int need_lo = 0, need_hi = 0;  // LDS floats for the octaves whose magnitude region fits beside 3-4 other workgroups / at all
+    int& need_lo = pl.need_lo;
+    int& need_hi = pl.need_hi;
     constexpr int kSmallLds = 10 * 1024 + 512, kBigLds = 36 * 1024;  // floats: 42 KB, 144 KB
-    int split = L.n_octaves;       // first octave handled by the big-LDS launch
+    int& split = pl.split;
+    split = L.n_octaves;
     for (int o = 0; o < L.n_octaves; ++o) {
         g.rows[o] = L.rows[o];
         g.cols[o] = L.cols[o];
@@ -1478,10 +1501,44 @@ static int enqueue_orient_batch(vslam_ctx* c, const vslam_params& p, const vslam
             need_hi = std::max(need_hi, std::min(std::max(worst, strip), std::max(kBigLds, strip)));
         }
     }
+    return VSLAM_OK;
+}
+
+// The edge test (Diff_of_Gauss.cpp:331-335) for the records octave 0 has appended.  Called on the stream
+// the list is written on, right behind that octave's compaction (`counts` is then the list length after
+// octave 0); the kernel itself goes to `other` (the Harris chain's stream, idle by then) so that it runs
+// beside the next octaves' scans instead of between them.
+static int enqueue_edge_flags_early(vslam_ctx* c, const vslam_params& p, const OrientPlan& pl, int nf, const uint8_t* pyr, size_t pframe,
+                                    const vslam_point* points, const unsigned int* counts, OrientScratch& s, hipStream_t other) {
+    HIPCHK(c, hipMemcpyAsync(s.obegin, counts, sizeof(unsigned int) * (size_t)nf, hipMemcpyDeviceToDevice, c->stream));
+    const bool fork = other && other != c->stream;
+    if (fork) {
+        HIPCHK(c, hipEventRecord(c->ev_list0, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(other, c->ev_list0, 0));
+    }
+    {
+        StreamSwap sw(c, fork ? other : c->stream);
+        LAUNCH(c, "k_edge_flags", k_edge_flags, dim3((unsigned)((s.fwords * 64 + 255) / 256), nf), dim3(256), points, (const unsigned int*)nullptr,
+               (const unsigned int*)s.obegin, p.dog_cap, pyr, pframe, pl.g, s.flags, s.fwords);
+        if (fork) HIPCHK(c, hipEventRecord(c->ev_edge, c->stream));
+    }
+    s.early_done = true;
+    s.early_forked = fork;
+    return VSLAM_OK;
+}
+
+// filterKeypoints for the keypoint lists of nf frames (kernels_orient_batch.hip.h), on the
+// context's current stream; the lists must be complete on that stream.
+static int enqueue_orient_batch(vslam_ctx* c, const vslam_params& p, const vslam_batch_layout& L, const OrientPlan& pl, int nf, const uint8_t* pyr,
+                                size_t pframe, const vslam_point* points, const unsigned int* counts, OrientScratch& s,
+                                vslam_point* oriented, unsigned int* oriented_counts) {
+    const OrientBatchGeom& g = pl.g;
+    const int need_lo = pl.need_lo, need_hi = pl.need_hi, split = pl.split;
     const size_t scap = p.oriented_cap;
     const size_t fw = s.fwords;
-    LAUNCH(c, "k_edge_flags", k_edge_flags, dim3((unsigned)((fw * 64 + 255) / 256), nf), dim3(256), points, counts, p.dog_cap, pyr, pframe, g,
-           s.flags, fw);
+    if (s.early_done && s.early_forked) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_edge, 0));  // the two launches share a flag word
+    LAUNCH(c, "k_edge_flags", k_edge_flags, dim3((unsigned)((fw * 64 + 255) / 256), nf), dim3(256), points,
+           (const unsigned int*)(s.early_done ? s.obegin : nullptr), counts, p.dog_cap, pyr, pframe, g, s.flags, fw);
     SurvivorEntries se{s.flags, fw, s.surv};
     TRY(enqueue_compaction(c, se, fw, nf, s.cws, (unsigned int)scap, s.scounts, 0));
     TRY(raise_dyn_lds(c, reinterpret_cast<const void*>(&k_orient_survivors)));
@@ -1557,6 +1614,8 @@ int vslam_detect_batch_dev(vslam_ctx* c, const vslam_params* pp, const uint8_t* 
     if (dog) TRY(dog_scratch_take(c, L, p.sigma0, chunk, s));
     OrientScratch os;
     if (orient) TRY(orient_scratch_take(c, p, chunk, os));
+    OrientPlan opl;
+    if (orient) TRY(make_orient_plan(c, p, L, opl));
     float* resp_ws = (harris && !out->response) ? ws_take<float>(c, (size_t)chunk * N) : nullptr;
     unsigned long long* hflags = harris ? ws_take<unsigned long long>(c, (size_t)chunk * harris_flag_words(p.rows, p.cols)) : nullptr;
     unsigned int* hcws = harris ? ws_take<unsigned int>(c, compaction_ws_elems(harris_flag_words(p.rows, p.cols), chunk)) : nullptr;
@@ -1603,22 +1662,38 @@ int vslam_detect_batch_dev(vslam_ctx* c, const vslam_params* pp, const uint8_t* 
                                want_kps ? out->harris_counts + f0 : nullptr, hcws));
             return VSLAM_OK;
         };
-        if (harris && !(dog && use_aux)) TRY(do_harris());
+        // The Harris chain: without the DoG path or the side streams it is simply enqueued here.  With
+        // them it goes to its own stream - at once for small batches, behind the last LDS-tiled octave
+        // kernel for large ones (enqueue_dog explains the gate) - and is enqueued from inside enqueue_dog,
+        // right after that octave's event, so that nothing enqueued on its stream later can get in front of it.
+        const int harris_gate = (dog && use_aux) ? dog_side_gate(p, L, nf) : -1;
+        if (harris && harris_gate < 0) TRY(do_harris());
         if (dog) {
             int side_gate = -1;
             const bool ext = out->extrema_bits || (out->dog_points && out->dog_counts);
+            os.early_done = os.early_forked = false;
+            // filterKeypoints' edge test for octave 0's records as soon as that octave's part of the list exists
+            const std::function<int(int)> after_list = [&](int o) -> int {
+                if (orient && o == 0 && L.n_octaves > 1)
+                    return enqueue_edge_flags_early(c, p, opl, nf, out->pyramid + (size_t)f0 * L.pyramid_frame_bytes, L.pyramid_frame_bytes,
+                                                    out->dog_points + (size_t)f0 * p.dog_cap, out->dog_counts + f0, os, use_aux ? sh : nullptr);
+                return VSLAM_OK;
+            };
+            const std::function<int(int)> after_octave = [&](int o) -> int {
+                if (harris && o == harris_gate) {
+                    HIPCHK(c, hipStreamWaitEvent(sh, c->ev_oct[o], 0));
+                    return do_harris();
+                }
+                return VSLAM_OK;
+            };
             TRY(enqueue_dog(c, p, L, fr, p.cols, frame_stride, nf, out->pyramid + (size_t)f0 * L.pyramid_frame_bytes,
                             L.pyramid_frame_bytes, s,
                             out->extrema_bits ? (unsigned long long*)out->extrema_bits + (size_t)f0 * L.bits_frame_words : nullptr,
                             ext, out->dog_points ? out->dog_points + (size_t)f0 * p.dog_cap : nullptr,
-                            out->dog_counts ? out->dog_counts + f0 : nullptr, sx, &side_gate));
-            if (harris && use_aux) {  // the Harris chain shares the gate of the other side work (enqueue_dog)
-                if (side_gate >= 0) HIPCHK(c, hipStreamWaitEvent(sh, c->ev_oct[side_gate], 0));
-                TRY(do_harris());
-            }
+                            out->dog_counts ? out->dog_counts + f0 : nullptr, sx, &side_gate, after_list, after_octave));
             if (orient) {  // filterKeypoints behind the list, on the stream that produced it
                 StreamSwap sw(c, sx ? sx : c->stream);
-                TRY(enqueue_orient_batch(c, p, L, nf, out->pyramid + (size_t)f0 * L.pyramid_frame_bytes, L.pyramid_frame_bytes,
+                TRY(enqueue_orient_batch(c, p, L, opl, nf, out->pyramid + (size_t)f0 * L.pyramid_frame_bytes, L.pyramid_frame_bytes,
                                          out->dog_points + (size_t)f0 * p.dog_cap, out->dog_counts + f0, os,
                                          out->oriented_points + (size_t)f0 * p.oriented_cap, out->oriented_counts + f0));
                 if (out->oriented_survivors)
