@@ -45,6 +45,7 @@ struct vslam_ctx {
     // run beside the VALU-bound pyramid kernels; forked from / joined to `stream` by events
     hipStream_t aux[2] = {nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr}, ev_oct[VSLAM_MAX_OCTAVES] = {};
+    hipEvent_t ev_up2 = nullptr;  // the second half of a batch has been upsampled (enqueue_dog)
     hipEvent_t ev_list0 = nullptr, ev_edge = nullptr;  // octave 0's part of the DoG list is written / its edge test is done
     // recycled pyramid blocks: a GaussPyramid per image would otherwise pay hipMalloc + hipFree of
     // >100 MB each time (milliseconds, more than the kernels)
@@ -148,6 +149,7 @@ static int ensure_aux(vslam_ctx* c) {
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
     }
     for (auto& e : c->ev_oct) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_up2, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_list0, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_edge, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
@@ -559,8 +561,19 @@ static int enqueue_dog(vslam_ctx* c, const vslam_params& p, const vslam_batch_la
     ExtGeom g;
     if (p.localize) TRY(ensure_loc_lut(c));
     fill_geom(c, p, L, g);
-    LAUNCH(c, "k_resize_linear2x_slide", k_resize_linear2x_slide, dim3(((p.cols + 3) / 4 + 255) / 256, (p.rows + 15) / 16, nf), dim3(256),
+    // Large batches go through the upsample and octave 0 in two halves: the second half is upsampled
+    // on the side stream (idle until octave 0 is done) while the first half's octave-0 kernel runs, so
+    // only half of the bandwidth-bound upsample is exposed in front of the VALU-bound octave kernels.
+    const int nf_a = (side && nf >= 64) ? nf / 2 : nf;
+    LAUNCH(c, "k_resize_linear2x_slide", k_resize_linear2x_slide, dim3(((p.cols + 3) / 4 + 255) / 256, (p.rows + 15) / 16, nf_a), dim3(256),
            frames, fstep, fframe, s.bases + s.base_off[0], s.bases_frame, L.pitch[0], p.rows, p.cols, 16);
+    if (nf_a < nf) {
+        StreamSwap sw(c, side);
+        LAUNCH(c, "k_resize_linear2x_slide", k_resize_linear2x_slide, dim3(((p.cols + 3) / 4 + 255) / 256, (p.rows + 15) / 16, nf - nf_a), dim3(256),
+               frames + (size_t)nf_a * fframe, fstep, fframe, s.bases + s.base_off[0] + (size_t)nf_a * s.bases_frame, s.bases_frame, L.pitch[0],
+               p.rows, p.cols, 16);
+        HIPCHK(c, hipEventRecord(c->ev_up2, c->stream));
+    }
     for (int o = 0; o < L.n_octaves; ++o) {
         const int rows = L.rows[o], cols = L.cols[o], pitch = L.pitch[o];
         const size_t P = (size_t)rows * pitch;
@@ -574,14 +587,27 @@ static int enqueue_dog(vslam_ctx* c, const vslam_params& p, const vslam_batch_la
         const int nr = has_next ? L.rows[o + 1] : 0, nc = has_next ? L.cols[o + 1] : 0, np = has_next ? L.pitch[o + 1] : 0;
         // tile shape: the wide tile when it needs no more tile area than the tall one
         const bool wide = (long)((cols + 255) / 256) * ((rows + 31) / 32) <= (long)((cols + 127) / 128) * ((rows + 63) / 64);
-        if (pl.path == OctPath::Tile0 && wide)
-            TRY(enqueue_pyr_octave<PyrCfgOct0W>(c, p.sigma0, o, pl, base, s.bases_frame, oct, pframe, rows, cols, pitch, nf, nb, s.bases_frame, nr, nc, np));
-        else if (pl.path == OctPath::Tile0)
-            TRY(enqueue_pyr_octave<PyrCfgOct0>(c, p.sigma0, o, pl, base, s.bases_frame, oct, pframe, rows, cols, pitch, nf, nb, s.bases_frame, nr, nc, np));
-        else if (pl.path == OctPath::Tile1 && wide)
-            TRY(enqueue_pyr_octave<PyrCfgOct1W>(c, p.sigma0, o, pl, base, s.bases_frame, oct, pframe, rows, cols, pitch, nf, nb, s.bases_frame, nr, nc, np));
-        else if (pl.path == OctPath::Tile1)
-            TRY(enqueue_pyr_octave<PyrCfgOct1>(c, p.sigma0, o, pl, base, s.bases_frame, oct, pframe, rows, cols, pitch, nf, nb, s.bases_frame, nr, nc, np));
+        // frames [f_lo, f_lo + n) of this octave through the LDS-tiled kernel
+        auto tiled = [&](int f_lo, int n) -> int {
+            const uint8_t* b = base + (size_t)f_lo * s.bases_frame;
+            uint8_t* oc = oct + (size_t)f_lo * pframe;
+            uint8_t* nbh = nb ? nb + (size_t)f_lo * s.bases_frame : nullptr;
+            if (pl.path == OctPath::Tile0 && wide)
+                return enqueue_pyr_octave<PyrCfgOct0W>(c, p.sigma0, o, pl, b, s.bases_frame, oc, pframe, rows, cols, pitch, n, nbh, s.bases_frame, nr, nc, np);
+            if (pl.path == OctPath::Tile0)
+                return enqueue_pyr_octave<PyrCfgOct0>(c, p.sigma0, o, pl, b, s.bases_frame, oc, pframe, rows, cols, pitch, n, nbh, s.bases_frame, nr, nc, np);
+            if (wide)
+                return enqueue_pyr_octave<PyrCfgOct1W>(c, p.sigma0, o, pl, b, s.bases_frame, oc, pframe, rows, cols, pitch, n, nbh, s.bases_frame, nr, nc, np);
+            return enqueue_pyr_octave<PyrCfgOct1>(c, p.sigma0, o, pl, b, s.bases_frame, oc, pframe, rows, cols, pitch, n, nbh, s.bases_frame, nr, nc, np);
+        };
+        const bool is_tiled = pl.path == OctPath::Tile0 || pl.path == OctPath::Tile1;
+        if (o == 0 && nf_a < nf && !is_tiled) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_up2, 0));  // octave 0 needs every base
+        if (is_tiled && o == 0 && nf_a < nf) {
+            TRY(tiled(0, nf_a));
+            HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_up2, 0));
+            TRY(tiled(nf_a, nf - nf_a));
+        } else if (is_tiled)
+            TRY(tiled(0, nf));
         else if (pl.path == OctPath::Strip)
             TRY(enqueue_strip_octave(c, p.sigma0, o, pl, base, s.bases_frame, oct, pframe, s.h, rows, cols, pitch, nf, nb, s.bases_frame, nr, nc, np));
         else {
