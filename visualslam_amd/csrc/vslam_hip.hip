@@ -772,6 +772,8 @@ int vslam_ctx_destroy(vslam_ctx* c) {
         if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
     }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    for (hipEvent_t e : {c->ev_up2, c->ev_list0, c->ev_edge})
+        if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ev_oct)
         if (e) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
