@@ -45,7 +45,17 @@ def gauss_trimmed_width(capi, sigma):
     return int(nz[-1] - nz[0] + 1)
 
 
-def cpu_baseline(rows, cols, n_oct, sample_frames):
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return None
+
+
+def cpu_baseline(rows, cols, n_oct, sample_frames, gpu_keypoints=None):
     """Time the CPU oracle on a bounded sample of the same workload: 1 thread (the reference is
     single-threaded: the reported baseline) and all host CPUs of this box's share with OpenMP over
     frames inside the oracle (SURVEY 8d ii)."""
@@ -78,6 +88,12 @@ def cpu_baseline(rows, cols, n_oct, sample_frames):
         "sample": f"{sample_frames} synthetic {cols}x{rows} frames, Harris+NMS+DoG pyramid+extrema, oracle/vslam_oracle.c -O2, 1 thread",
         "keypoints_per_sec": kp / dt,
         "host_cpus": os.cpu_count(),
+        "cpu_model": cpu_model(),
+        # the same frames give the same keypoint counts on both paths (Harris list + DoG list
+        # with value >= 8 of the sample's frames, which are the first frames of rank 0's batch)
+        "keypoints": int(kp),
+        "keypoints_gpu_same_frames": gpu_keypoints,
+        "keypoints_equal_gpu": (int(kp) == int(gpu_keypoints)) if gpu_keypoints is not None else None,
     }
 
 
@@ -236,6 +252,11 @@ def main():
     kname = args.kernel or "k_pyr_octave"
     main = run_mode(args.localize, args.orient, args.steps, args.warmup, kname)
     p, L, dt, launches, kms = main["p"], main["L"], main["dt"], main["launches"], main["kms"]
+    # keypoints of the first frames of this rank's batch, for the CPU baseline's count check
+    cs = min(args.cpu_sample, n)
+    gpu_kp_sample = None
+    if cs > 0 and not (args.localize or args.orient) and args.octaves > 0:
+        gpu_kp_sample = int(shared["harris_counts"][:cs].sum().item() + shared["dog_counts"][:cs].sum().item())
     alone = kernel_alone(kname, 3) if (args.modes and kname == "k_pyr_octave" and args.octaves >= 2) else None
     # the list modes the reference's own functions produce (initialKeypointDetection appends the
     # FeaturePointLocalization survivors, Diff_of_Gauss.cpp:290; filterKeypoints the oriented points,
@@ -331,7 +352,7 @@ def main():
             },
             "roofline": roof,
             "roofline_valu": valu,
-            "cpu_baseline": cpu_baseline(rows, cols, args.octaves, args.cpu_sample) if (world == 1 and args.cpu_sample > 0) else None,
+            "cpu_baseline": cpu_baseline(rows, cols, args.octaves, cs, gpu_kp_sample) if (world == 1 and args.cpu_sample > 0) else None,
         }
         print(json.dumps(line))
     ctx.close()
