@@ -538,16 +538,16 @@ static int dog_side_gate(const vslam_params& p, const vslam_batch_layout& L, int
 static int enqueue_dog(vslam_ctx* c, const vslam_params& p, const vslam_batch_layout& L, const uint8_t* frames,
                        size_t fstep, size_t fframe, int nf, uint8_t* pyr, size_t pframe, DogScratch& s,
                        unsigned long long* bits, bool do_extrema, vslam_point* points, unsigned int* counts,
-                       hipStream_t side = nullptr, int* side_gate = nullptr,
-                       const std::function<int(int)>& after_list = nullptr, const std::function<int(int)>& after_octave = nullptr) {
+                       hipStream_t side = nullptr, const std::function<int(int)>& after_list = nullptr,
+                       const std::function<int(int)>& after_octave = nullptr) {
     // `side`: stream for the extrema scans and the list compaction (they only read what the
     // octave kernels wrote); ordered after the octave kernels by events.  nullptr = same stream.
     //
     // Where the side work runs decides how much of the VALU-issue-bound octave kernels it costs
-    // (*side_gate = the last LDS-tiled octave, -1 = none; 256 x 1080p, same box):
-    //  * the Harris chain (VALU-heavy) always waits for that octave's kernel - the caller gates it
-    //    on ev_oct[*side_gate] - and runs beside the coarse-octave strip kernels, which are short
-    //    of waves: k_pyr_octave 7.46 -> 6.06 ms per launch, +1.4 % frames/s;
+    // (gate = dog_side_gate(): the last LDS-tiled octave, -1 = none; 256 x 1080p, same box):
+    //  * the Harris chain (VALU-heavy) always waits for that octave's kernel - the caller enqueues it
+    //    from after_octave(gate), behind ev_oct[gate] - and runs beside the coarse-octave strip
+    //    kernels, which are short of waves: k_pyr_octave 7.46 -> 6.06 ms per launch, +1.4 % frames/s;
     //  * the plain extrema scan (HBM-heavy, ~90 VALU instructions per thread) starts as soon as its
     //    octave is written, i.e. octave 0's scan runs beside octave 1's kernel: +2..3 % frames/s
     //    over holding it back as well (the tail after the tiled octaves is as VALU-bound as they are,
@@ -555,9 +555,7 @@ static int enqueue_dog(vslam_ctx* c, const vslam_params& p, const vslam_batch_la
     //  * the scan with FeaturePointLocalization inside (params.localize, ~8x the instructions) is
     //    held back like the Harris chain: +0.5 % in the localize / orient / describe modes.
     // Small batches keep the eager order: there the chain's latency matters, not the issue slots.
-    int gate = side ? dog_side_gate(p, L, nf) : -1;
-    if (side_gate) *side_gate = gate;
-    if (!p.localize) gate = -1;
+    const int gate = (side && p.localize) ? dog_side_gate(p, L, nf) : -1;
     ExtGeom g;
     if (p.localize) TRY(ensure_loc_lut(c));
     fill_geom(c, p, L, g);
@@ -1697,7 +1695,6 @@ int vslam_detect_batch_dev(vslam_ctx* c, const vslam_params* pp, const uint8_t* 
         const int harris_gate = (dog && use_aux) ? dog_side_gate(p, L, nf) : -1;
         if (harris && harris_gate < 0) TRY(do_harris());
         if (dog) {
-            int side_gate = -1;
             const bool ext = out->extrema_bits || (out->dog_points && out->dog_counts);
             os.early_done = os.early_forked = false;
             // filterKeypoints' edge test for octave 0's records as soon as that octave's part of the list exists
@@ -1718,7 +1715,7 @@ int vslam_detect_batch_dev(vslam_ctx* c, const vslam_params* pp, const uint8_t* 
                             L.pyramid_frame_bytes, s,
                             out->extrema_bits ? (unsigned long long*)out->extrema_bits + (size_t)f0 * L.bits_frame_words : nullptr,
                             ext, out->dog_points ? out->dog_points + (size_t)f0 * p.dog_cap : nullptr,
-                            out->dog_counts ? out->dog_counts + f0 : nullptr, sx, &side_gate, after_list, after_octave));
+                            out->dog_counts ? out->dog_counts + f0 : nullptr, sx, after_list, after_octave));
             if (orient) {  // filterKeypoints behind the list, on the stream that produced it
                 StreamSwap sw(c, sx ? sx : c->stream);
                 TRY(enqueue_orient_batch(c, p, L, opl, nf, out->pyramid + (size_t)f0 * L.pyramid_frame_bytes, L.pyramid_frame_bytes,
