@@ -21,6 +21,11 @@ namespace vslam {
 constexpr int STRIP_W = 64;        // columns per vertical-pass workgroup
 constexpr int STRIP_MAXM = 64;     // tap dword groups per level: ceil((245+3)/4) = 62
 constexpr int STRIP_MAXTP = 272;   // padded u16 tap-pair table: 8 + (245+1) + 16, multiple of 8
+// The row sums the vertical pass hands to the horizontal pass carry +128 each: the taps of a level sum
+// to exactly 256 (strip_pack_taps checks it), so sum tx * (h + 128) = sum tx * h + 32768 - the rounding
+// constant of SURVEY A2-iv arrives with the data and the horizontal accumulators start from the first
+// product instead of from a constant.  h <= 255 * 256 = 65280, so h + 128 still fits 16 bits.
+constexpr uint32_t STRIP_HBIAS = 128;
 
 // Device-resident tap tables of one octave (6 levels).
 struct StripTaps {
@@ -68,6 +73,8 @@ __global__ __launch_bounds__(256) void k_gauss_v_strip(const uint8_t* __restrict
 
     // gridDim.y splits the six levels over workgroups (each re-stages the strip): a single frame
     // has only cols/64 strips, far too few workgroups for 256 CUs
+    uint32_t hbias = STRIP_HBIAS;
+    asm volatile("" : "+v"(hbias));  // one VGPR for the whole kernel (not an inline constant; the taps occupy the scalar operand)
     for (int l = blockIdx.y; l < VSLAM_NUM_LEVELS; l += gridDim.y) {
         const int n = taps->n[l], r = n >> 1;
         const int M = (n + 3 + 3) >> 2;            // dwords covering bytes [0, 3 + n)
@@ -80,13 +87,21 @@ __global__ __launch_bounds__(256) void k_gauss_v_strip(const uint8_t* __restrict
             const int cg = it & 15, q = it >> 4;
             const int ty0 = ty_start + 4 * q;
             uint32_t acc[4][4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) acc[j][c] = 0;
             const uint4* col = reinterpret_cast<const uint4*>(rp + ((ty0 - r + RM) >> 2) * STRIP_W + 4 * cg);
+            {   // first tap group: starts the accumulators at STRIP_HBIAS (see k_gauss_h_strip), no zeroing pass
+                const uint4 v = col[0];
+                const uint4 t = tab[0];
+                const uint32_t tt[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[j][0] = udot4(v.x, tt[j], hbias);
+                    acc[j][1] = udot4(v.y, tt[j], hbias);
+                    acc[j][2] = udot4(v.z, tt[j], hbias);
+                    acc[j][3] = udot4(v.w, tt[j], hbias);
+                }
+            }
 #pragma unroll 2
-            for (int m = 0; m < M; ++m) {
+            for (int m = 1; m < M; ++m) {
                 const uint4 v = col[m * (STRIP_W / 4)];
                 const uint4 t = tab[m];  // wave-uniform: scalar load
                 const uint32_t tt[4] = {t.x, t.y, t.z, t.w};
@@ -117,11 +132,10 @@ __global__ __launch_bounds__(256) void k_gauss_v_strip(const uint8_t* __restrict
 template <int DL, int RI>
 __device__ __forceinline__ void h_item_level(const uint32_t* __restrict__ hrow, int pw, int tx0, int nb,
                                              const uint32_t* __restrict__ tp, uint32_t (&acc)[RI][8]) {
-#pragma unroll
-    for (int jr = 0; jr < RI; ++jr)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[jr][j] = 32768u;
-    for (int b = 0; b < nb; ++b) {
+    // one block of 8 input columns (4 pairs) against the 8 outputs; FIRST: the accumulators start here
+    // (the rounding constant is in the data: STRIP_HBIAS), so there is no initialisation pass
+    auto block = [&](int b, auto first) {
+        constexpr bool FIRST = decltype(first)::value;
         // tap pairs e in [8b-8, 8b+8): 16 wave-uniform dwords
         uint32_t T[16];
 #pragma unroll
@@ -137,10 +151,12 @@ __device__ __forceinline__ void h_item_level(const uint32_t* __restrict__ hrow, 
                 for (int j = 0; j < 8; ++j) {
                     // e = 2(4b+pp) - j - DL + 1 ; table index = e + 8 - 8b
                     const int ti = 2 * pp - j - DL + 1 + 8;
-                    acc[jr][j] = udot2(vv[pp], T[ti], acc[jr][j]);
+                    acc[jr][j] = udot2(vv[pp], T[ti], (FIRST && pp == 0) ? 0u : acc[jr][j]);
                 }
         }
-    }
+    };
+    block(0, std::true_type{});
+    for (int b = 1; b < nb; ++b) block(b, std::false_type{});
 }
 
 // grid = (1, ceil(rows/SH), frames); dynamic LDS = SH * pw * 4 bytes, pw = (cols + 2*(rmax+1) + 8)/2
@@ -242,8 +258,12 @@ static bool strip_pack_taps(const uint16_t* const t[6], const int n[6], StripTap
     for (int l = 0; l < VSLAM_NUM_LEVELS; ++l) {
         if (n[l] > 245 || (n[l] & 1) == 0) return false;
         out.n[l] = n[l];
-        for (int k = 0; k < n[l]; ++k)
+        unsigned sum = 0;
+        for (int k = 0; k < n[l]; ++k) {
             if (t[l][k] > 255) return false;
+            sum += t[l][k];
+        }
+        if (sum != 256) return false;  // STRIP_HBIAS relies on it
         for (int m = 0; m < STRIP_MAXM; ++m)
             for (int j = 0; j < 4; ++j) {
                 uint32_t w = 0;
