@@ -149,6 +149,20 @@ def test_batch_of_40_frames_takes_the_gated_launch_order(env, mode):
         check_frame(p, L, out, f, frames[f], 3)
 
 
+@pytest.mark.parametrize("mode", ["candidates", "localized", "oriented"])
+def test_batch_of_70_frames_goes_through_octave_0_in_two_halves(env, mode):
+    # from 64 frames on the upsample and octave 0 run as two half-batches (the second half upsampled on
+    # the side stream, enqueue_dog); frames on both sides of the seam, first and last, every list mode
+    ctx, torch = env
+    frames = synth.frames_np(70, 72, 104, stream_id=23)
+    frames[34] = synth.frame_np(72, 104, kind="noise")
+    frames[35] = synth.frame_np(72, 104, frame=9, stream_id=4, kind="noise")
+    kw = dict(localize=int(mode != "candidates"), orient=int(mode == "oriented"))
+    p, L, out = run_batch(ctx, torch, frames, n_octaves=3, harris_cap=4096, dog_cap=8192, **kw)
+    for f in (0, 33, 34, 35, 36, 69):
+        check_frame(p, L, out, f, frames[f], 3)
+
+
 def test_batch_ragged_size_and_small_caps(env):
     ctx, torch = env
     frames = synth.frames_np(2, 75, 131, stream_id=9)
