@@ -35,3 +35,31 @@ def test_bench_two_ranks_share_one_gpu():
     d1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][0])
     assert d["keypoints_per_step"]["harris"] > d1["keypoints_per_step"]["harris"]
     assert d["keypoints_per_step"]["dog"] > d1["keypoints_per_step"]["dog"]
+
+
+@pytest.mark.gpu
+def test_bench_one_rank_goes_through_rccl():
+    # the driver launches N ranks with torch.distributed.run over RCCL; with one rank on the one GPU of
+    # the test box the same code path runs: init_process_group("nccl"), the barrier / max-over-ranks
+    # timing, the all-gather of the counts on device tensors and the flag reductions
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("VSLAM_BENCH_BACKEND", None)
+    env.pop("VSLAM_BENCH_SHARE_GPU", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--frames", "8", "--rows", "240", "--cols", "320",
+           "--steps", "2", "--warmup", "1", "--cpu-sample", "0"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0
+    assert d["distributed"] == {"initialized": True, "world_size": 1, "backend": "nccl", "ranks_gathered": 1}
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--frames", "8", "--rows", "240", "--cols", "320", "--steps", "2",
+                          "--warmup", "1", "--cpu-sample", "0", "--modes", "0"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    d1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][0])
+    assert d["keypoints_per_step"] == d1["keypoints_per_step"]  # the gathered counts are the rank's own
