@@ -120,13 +120,15 @@ def test_batch_small_frames_all_outputs(env):
         check_frame(p, L, out, f, frames[f], 3)
 
 
-def test_batch_larger_than_one_chunk(env):
-    # more frames than one whole-batch launch takes (256): the second chunk reuses the scratch and
-    # the auxiliary streams of the first; frames on both sides of the seam against the oracle
+@pytest.mark.parametrize("mode", ["candidates", "localized", "oriented"])
+def test_batch_larger_than_one_chunk(env, mode):
+    # more frames than one whole-batch launch takes (256): the second chunk reuses the scratch, the
+    # events and the auxiliary streams of the first; frames on both sides of the seam against the oracle
     ctx, torch = env
     frames = synth.frames_np(300, 40, 56, stream_id=13)
     frames[256] = synth.frame_np(40, 56, kind="noise")
-    p, L, out = run_batch(ctx, torch, frames, n_octaves=2, harris_cap=1024, dog_cap=2048)
+    kw = dict(localize=int(mode != "candidates"), orient=int(mode == "oriented"))
+    p, L, out = run_batch(ctx, torch, frames, n_octaves=2, harris_cap=1024, dog_cap=2048, **kw)
     for f in (0, 1, 254, 255, 256, 257, 299):
         check_frame(p, L, out, f, frames[f], 2)
     # every frame of the first chunk also appears, identically, nowhere else: spot-check that no
