@@ -83,7 +83,15 @@ __global__ __launch_bounds__(256) void k_gauss_v_strip(const uint8_t* __restrict
         const int nq = (rows - ty_start + 3) >> 2;
         const uint4* tab = reinterpret_cast<const uint4*>(&taps->v4[l][0][0]);
         uint16_t* hl = h + blockIdx.z * hframe + (size_t)l * P;
-        for (int it = tid; it < nq * (STRIP_W / 4); it += 256) {
+        // the partial last round of items rotates over the waves with the level (as in k_pyr_octave: it
+        // would otherwise always load the SIMDs that hold waves 0 and 1)
+        const int n_items = nq * (STRIP_W / 4), full = n_items & ~255;
+        for (int base_it = 0; base_it < n_items; base_it += 256) {
+            int it = base_it + tid;
+            if (base_it == full) {
+                it = full + ((tid - 64 * (l & 3)) & 255);
+                if (it >= n_items) break;
+            }
             const int cg = it & 15, q = it >> 4;
             const int ty0 = ty_start + 4 * q;
             uint32_t acc[4][4];
