@@ -85,7 +85,7 @@ __device__ __forceinline__ void pyr_level(const PyrTaps<CFG>* __restrict__ taps,
                                           uint32_t* __restrict__ hp, uint8_t* __restrict__ out, size_t P, int cols,
                                           int pitch, int rows, int tile_x0, int tile_y0, uint32_t (&prev_e)[4][2],
                                           uint32_t (&prev_o)[4][2], uint8_t* __restrict__ next_base, int nrows,
-                                          int ncols, int npitch) {
+                                          int ncols, int npitch, const uint32_t (&row_off)[4]) {
     constexpr int n = CFG::n(L), dl = CFG::delta(L), A = CFG::A(L);
     constexpr int NCG = CFG::ncg(L), M = CFG::m1(L), NB = CFG::nb(L);
     constexpr int RWP = CFG::RWP, HPP = CFG::HPP, TH = CFG::TH;
@@ -202,7 +202,7 @@ __device__ __forceinline__ void pyr_level(const PyrTaps<CFG>* __restrict__ taps,
             // 32-bit offset inside a wave-uniform plane pointer (a frame's octave block is far below
             // 4 GB): scalar base + VGPR offset addressing, no 64-bit address arithmetic per store.
             // The last 8-column group may end in the row padding.
-            const uint32_t off = (uint32_t)y * (uint32_t)pitch + (uint32_t)x;
+            const uint32_t off = row_off[jr];  // y * pitch + x: the same for every level, formed once per thread (k_pyr_octave)
             uint8_t* gp = out + (size_t)L * P;
             *reinterpret_cast<uint2*>(gp + off) = make_uint2(g[0], g[1]);
             if (L > 0) {
@@ -301,12 +301,21 @@ __global__ __launch_bounds__(256) void k_pyr_octave(const uint8_t* __restrict__ 
 
     uint8_t* nb = next_base ? next_base + fz * nframe : nullptr;
     uint32_t prev_e[4][2], prev_o[4][2];
-    pyr_level<CFG, 0>(taps, rp, hp, out, P, cols, pitch, rows, tile_x0, tile_y0, prev_e, prev_o, nb, nrows, ncols, npitch);
-    pyr_level<CFG, 1>(taps, rp, hp, out, P, cols, pitch, rows, tile_x0, tile_y0, prev_e, prev_o, nb, nrows, ncols, npitch);
-    pyr_level<CFG, 2>(taps, rp, hp, out, P, cols, pitch, rows, tile_x0, tile_y0, prev_e, prev_o, nb, nrows, ncols, npitch);
-    pyr_level<CFG, 3>(taps, rp, hp, out, P, cols, pitch, rows, tile_x0, tile_y0, prev_e, prev_o, nb, nrows, ncols, npitch);
-    pyr_level<CFG, 4>(taps, rp, hp, out, P, cols, pitch, rows, tile_x0, tile_y0, prev_e, prev_o, nb, nrows, ncols, npitch);
-    pyr_level<CFG, 5>(taps, rp, hp, out, P, cols, pitch, rows, tile_x0, tile_y0, prev_e, prev_o, nb, nrows, ncols, npitch);
+    // byte offsets of this thread's four output rows inside a plane (pass 2 / epilogue mapping of pyr_level):
+    // 32-bit multiplies are quarter rate, and the offsets do not depend on the level
+    uint32_t row_off[4];
+    {
+        const int xg = tid & (CFG::TW / 8 - 1), rg = tid / (CFG::TW / 8);
+#pragma unroll
+        for (int jr = 0; jr < 4; ++jr)
+            row_off[jr] = (uint32_t)(tile_y0 + 4 * rg + jr) * (uint32_t)pitch + (uint32_t)(tile_x0 + 8 * xg);
+    }
+    pyr_level<CFG, 0>(taps, rp, hp, out, P, cols, pitch, rows, tile_x0, tile_y0, prev_e, prev_o, nb, nrows, ncols, npitch, row_off);
+    pyr_level<CFG, 1>(taps, rp, hp, out, P, cols, pitch, rows, tile_x0, tile_y0, prev_e, prev_o, nb, nrows, ncols, npitch, row_off);
+    pyr_level<CFG, 2>(taps, rp, hp, out, P, cols, pitch, rows, tile_x0, tile_y0, prev_e, prev_o, nb, nrows, ncols, npitch, row_off);
+    pyr_level<CFG, 3>(taps, rp, hp, out, P, cols, pitch, rows, tile_x0, tile_y0, prev_e, prev_o, nb, nrows, ncols, npitch, row_off);
+    pyr_level<CFG, 4>(taps, rp, hp, out, P, cols, pitch, rows, tile_x0, tile_y0, prev_e, prev_o, nb, nrows, ncols, npitch, row_off);
+    pyr_level<CFG, 5>(taps, rp, hp, out, P, cols, pitch, rows, tile_x0, tile_y0, prev_e, prev_o, nb, nrows, ncols, npitch, row_off);
 }
 
 // Host side: pack quantised taps into the operand shapes described at the top.
