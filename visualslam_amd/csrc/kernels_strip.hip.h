@@ -123,11 +123,12 @@ __global__ __launch_bounds__(256) void k_gauss_v_strip(const uint8_t* __restrict
             }
             const int gx = x0 + 4 * cg;
             if (gx < cols) {
+                const int off0 = ty0 * pitch + gx;  // one multiply per item (quarter rate), rows by addition; a level's scratch is far below 2^31 elements
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int y = ty0 + j;
                     if (y >= 0 && y < rows)
-                        *reinterpret_cast<uint2*>(hl + (size_t)y * pitch + gx) =
+                        *reinterpret_cast<uint2*>(hl + (off0 + j * pitch)) =
                             make_uint2(__builtin_amdgcn_perm(acc[j][1], acc[j][0], 0x05040100), __builtin_amdgcn_perm(acc[j][3], acc[j][2], 0x05040100));
                 }
             }
@@ -186,6 +187,16 @@ __global__ __launch_bounds__(256) void k_gauss_h_strip(const uint16_t* __restric
     uint8_t* out = oct_out + blockIdx.z * pframe;
     const int ncg = (cols + 7) >> 3, items = ncg * (SH / RI);
     uint32_t prev_e[2][RI][2], prev_o[2][RI][2];
+    // this thread's (at most two) items and the plane offset of each item's first row: the same for every
+    // level, so the division and the multiply (quarter rate) are done once
+    int item_cg[2], item_rg[2];
+    uint32_t item_off[2];
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii) {
+        const int it = tid + ii * 256;
+        item_cg[ii] = it % ncg, item_rg[ii] = it / ncg;
+        item_off[ii] = (uint32_t)(y0 + RI * item_rg[ii]) * (uint32_t)pitch + (uint32_t)(8 * item_cg[ii]);
+    }
 
     for (int l = 0; l < VSLAM_NUM_LEVELS; ++l) {
         const int n = taps->n[l], r = n >> 1, dl = r & 1, PL = r + dl;
@@ -221,7 +232,7 @@ __global__ __launch_bounds__(256) void k_gauss_h_strip(const uint16_t* __restric
         for (int ii = 0; ii < 2; ++ii) {
             const int it = tid + ii * 256;
             if (it < items) {
-                const int cg = it % ncg, rg = it / ncg;
+                const int cg = item_cg[ii], rg = item_rg[ii];
                 uint32_t acc[RI][8];
                 if (dl)
                     h_item_level<1, RI>(hp + (RI * rg) * pw, pw, 8 * cg, nb, tp, acc);
@@ -242,7 +253,7 @@ __global__ __launch_bounds__(256) void k_gauss_h_strip(const uint16_t* __restric
                         prev_o[ii][jr][hw] = o;
                     }
                     if (y < rows) {
-                        const uint32_t off = (uint32_t)y * (uint32_t)pitch + (uint32_t)x;  // 32-bit offset in a uniform plane pointer
+                        const uint32_t off = item_off[ii] + (uint32_t)(jr * pitch);  // 32-bit offset in a uniform plane pointer
                         uint8_t* gp = out + (size_t)l * P;
                         *reinterpret_cast<uint2*>(gp + off) = make_uint2(g[0], g[1]);
                         if (l > 0) {
