@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void k_gauss_h_strip(const uint16_t* __restric
         const uint16_t* hl = h + blockIdx.z * hframe + (size_t)l * P;
         // ---- stage SH rows, reflect-101 extended, as u16 pairs -------------------------------
         __syncthreads();  // previous level's reads are done
-        for (int jr = tid >> 6; jr < SH; jr += 4) {  // one wave per row
+        for (int jr = __builtin_amdgcn_readfirstlane(tid >> 6); jr < SH; jr += 4) {  // one wave per row: the row address is scalar
             const uint16_t* row = hl + (size_t)min(y0 + jr, rows - 1) * pitch;
             uint32_t* dstp = hp + jr * pw + (PL >> 1);  // pair index of image column 0
             // interior: 16-byte coalesced loads (8 columns), LDS side is only 4-byte aligned.  The
