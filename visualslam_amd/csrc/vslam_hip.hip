@@ -143,9 +143,12 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 static int ensure_aux(vslam_ctx* c) {
     if (c->ev_fork) return VSLAM_OK;
     int prio_lo = 0, prio_hi = 0;
-    HIPCHK(c, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));  // numerically: lowest priority, highest priority
+    if (hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess) prio_lo = 0;  // numerically: lowest priority, highest priority
     for (int i = 0; i < 2; ++i) {
-        HIPCHK(c, hipStreamCreateWithPriority(&c->aux[i], hipStreamNonBlocking, prio_lo));
+        if (hipStreamCreateWithPriority(&c->aux[i], hipStreamNonBlocking, prio_lo) != hipSuccess) {
+            (void)hipGetLastError();  // priorities are a speed matter only
+            HIPCHK(c, hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking));
+        }
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
     }
     for (auto& e : c->ev_oct) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
