@@ -98,9 +98,15 @@ __device__ __forceinline__ void harris_strip_rows(const HarrisStripArgs& a, cons
 
     auto load_row = [&](int t) -> uint32_t {
         const uint8_t* row = src + (size_t)reflect101(t, rows) * cols;
-        if (!EDGE || (ANYW ? lane_full : lane_in)) {  // interior strips: every lane lies inside the image
+        if (!EDGE) {  // interior strips: every lane lies inside the image; scalar row offset + 32-bit lane offset
+            uint32_t w;   // (a frame is far below 4 GB: no 64-bit address arithmetic per row)
+            const uint32_t roff = __builtin_amdgcn_readfirstlane((uint32_t)reflect101(t, rows) * (uint32_t)cols);  // scalar multiply
+            __builtin_memcpy(&w, src + roff + (uint32_t)x0, 4);  // dword aligned when !ANYW
+            return w;
+        }
+        if (ANYW ? lane_full : lane_in) {
             uint32_t w;
-            __builtin_memcpy(&w, row + x0, 4);  // dword aligned when !ANYW
+            __builtin_memcpy(&w, row + x0, 4);
             return w;
         }
         return (uint32_t)row[reflect101(x0, cols)] | ((uint32_t)row[reflect101(x0 + 1, cols)] << 8) |
@@ -266,7 +272,8 @@ __device__ __forceinline__ void harris_strip_rows(const HarrisStripArgs& a, cons
                 }
             }
             if (lane_out) {
-                const size_t off = blockIdx.z * N + (size_t)y * cols + x0;
+                // row start on the scalar unit (a full 32-bit multiply is quarter rate on the vector unit; rows * cols < 2^32)
+                const size_t off = blockIdx.z * N + __builtin_amdgcn_readfirstlane((uint32_t)y * (uint32_t)cols) + x0;
                 const float4 rv = make_float4(__uint_as_float(Ry[0]), __uint_as_float(Ry[1]), __uint_as_float(Ry[2]), __uint_as_float(Ry[3]));
                 const float4 nv = make_float4(__uint_as_float(n2[0]), __uint_as_float(n2[1]), __uint_as_float(n2[2]), __uint_as_float(n2[3]));
                 if (!ANYW) {

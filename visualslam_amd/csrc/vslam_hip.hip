@@ -668,6 +668,7 @@ static int enqueue_harris(vslam_ctx* c, const uint8_t* frames, size_t fframe, in
                           float* resp, uint8_t* mask, float* nms2, unsigned long long* hflags, vslam_kp* kps,
                           unsigned int cap, unsigned int* counts, unsigned int* chunk_ws) {
     const size_t N = (size_t)rows * cols;
+    if (N >= ((size_t)1 << 31)) return fail(c, VSLAM_ERR_UNSUPPORTED, "Harris: images of 2^31 pixels or more are not supported (32-bit row offsets)");
     const bool aligned = cols % 4 == 0 && fframe % 4 == 0;
     HarrisStripArgs a;
     a.img = frames;
