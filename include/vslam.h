@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VSLAM_VERSION 100 /* 0.1.0 */
+#define VSLAM_VERSION 200 /* 0.2.0: vslam_batch_out carries buffer sizes (round 3) */
 
 enum {
     VSLAM_OK = 0,
@@ -271,7 +271,11 @@ int vslam_rotated_window_points(int cx, int cy, int window, float theta_deg, int
  * DEFINED (always the case for square and portrait octaves away from the last rows), otherwise the
  * reference reads foreign memory: defined[k] = 0 and a zero descriptor.  defined may be NULL, in
  * which case any undefined keypoint makes the call return VSLAM_ERR_RANGE (after filling desc).
- * A flat window gives the reference's all-NaN descriptor (0 / 0 at :661). */
+ * A flat window gives the reference's all-NaN descriptor (0 / 0 at :661).
+ * Histogram bins: the reference indexes histo.at((int)(orientation * 8/360.f)) (:126), which throws for
+ * an orientation of exactly 360.0; the kernels clamp the bin to 0..7 instead.  The gradients here come
+ * from integer Sobel differences, for which cv::phase never returns 360.0, so the two agree on every
+ * input this entry point can be given; the clamp only keeps an impossible value from indexing outside LDS. */
 int vslam_sift_descriptors(vslam_ctx* ctx, const vslam_pyramid* pyr, int octave, const vslam_point* oriented, size_t n,
                            float* desc, uint8_t* defined);
 /* featureDescriptors.dat, Diff_of_Gauss.cpp:837-863: int32 {n, 128, 24} (24 = sizeof(std::vector<float>)
@@ -297,6 +301,12 @@ typedef struct {
     uint32_t dog_cap;    /* per-frame capacity of the DoG point list */
     uint32_t oriented_cap; /* per-frame capacity of the oriented keypoint list (and of the
                             * edge-test survivors it is made from) */
+    int extrema_dense;   /* EXTENSION (0 = the reference's lattice test, the default and the parity path): 1 runs the
+                          * dense 3x3x3 scale-space test of vslam_dog_extrema_dense on every pixel of DoG levels 1..3
+                          * of every frame instead.  extrema_bits then holds, per octave, 3 levels x rows x
+                          * ceil(cols/64) words (layout.lat_rows / lat_cols / lat_words report rows / cols / words per
+                          * row) and dog_points the candidates with value >= min_contrast in (octave, level, y, x)
+                          * order.  Needs extrema_window = 3, localize = 0, orient = 0. */
 } vslam_params;
 
 /* Byte layout of the per-frame output blocks, so that a caller can allocate them. */
@@ -319,35 +329,62 @@ typedef struct {
     size_t algorithmic_bytes_harris, algorithmic_bytes_dog;
 } vslam_batch_layout;
 
-/* Device pointers; any may be NULL to skip that output (it is then neither computed
- * for its own sake nor written). */
+/* Device pointers; any may be NULL to skip that output (it is then neither computed for its own sake
+ * nor written).  Every pointer travels with the size of the buffer behind it: `x_bytes` is the number of
+ * bytes the caller allocated at `x`.  vslam_detect_batch_dev checks each non-NULL buffer against what
+ * n_frames frames need (vslam_batch_out_required fills in exactly those numbers) and returns
+ * VSLAM_ERR_INVALID - before anything is launched - if one is too small or struct_size is not
+ * sizeof(vslam_batch_out); a kernel never writes past a size stated here. */
 typedef struct {
+    size_t struct_size;      /* = sizeof(vslam_batch_out) */
     float* response;         /* [n][rows][cols]  HarrisCorner output */
+    size_t response_bytes;
     uint8_t* nms_mask;       /* [n][rows][cols]  NonMaximumSuppression(8-bit view, 3) */
+    size_t nms_mask_bytes;
     float* nms2;             /* [n][rows][cols]  NMS2(response, 5) map (optional) */
+    size_t nms2_bytes;
     vslam_kp* harris_kps;    /* [n][harris_cap] */
+    size_t harris_kps_bytes;
     uint32_t* harris_counts; /* [n] totals (may exceed cap) */
+    size_t harris_counts_bytes;
     uint8_t* pyramid;        /* [n][pyramid_frame_bytes], 16-byte aligned, planes pitched (layout.pitch) */
+    size_t pyramid_bytes;
     uint64_t* extrema_bits;  /* [n][bits_frame_words] */
+    size_t extrema_bits_bytes;
     vslam_point* dog_points; /* [n][dog_cap], order (octave, level, i, j) */
+    size_t dog_points_bytes;
     uint32_t* dog_counts;    /* [n] totals (may exceed cap) */
+    size_t dog_counts_bytes;
     vslam_point* oriented_points; /* [n][oriented_cap] filterKeypoints output: {row, col, angle, 0, octave, level},
                                    * order (octave, keypoint, histogram bin); params.orient = 1 */
+    size_t oriented_points_bytes;
     uint32_t* oriented_counts;    /* [n] oriented points of the EVALUATED survivors (may exceed cap): the true total
                                    * iff oriented_survivors[f] <= oriented_cap */
+    size_t oriented_counts_bytes;
     uint32_t* oriented_survivors; /* [n] optional: keypoints of the frame that pass the edge test (Diff_of_Gauss.cpp:336).
                                    * Only the first oriented_cap of them (list order) get their histogram evaluated, so
                                    * oriented_survivors[f] > oriented_cap flags a truncated frame */
+    size_t oriented_survivors_bytes;
     float* descriptors;           /* [n][oriented_cap][128] optional: SIFT() descriptors (Diff_of_Gauss.cpp:561-693) of the
                                    * oriented points, same order; needs the oriented outputs.  Row q of frame f is
                                    * valid for q < min(oriented_counts[f], oriented_cap) */
+    size_t descriptors_bytes;
     uint8_t* descriptor_defined;  /* [n][oriented_cap] optional, with descriptors: 0 where the rotated window leaves the
                                    * padded level (zero descriptor, see vslam_sift_descriptors) */
+    size_t descriptor_defined_bytes;
 } vslam_batch_out;
 
+/* Defaults of the reference's literals; the three list capacities scale with the frame area
+ * (harris_cap = dog_cap = rows*cols/8, oriented_cap = rows*cols/32, each rounded up to a multiple
+ * of 4096 and not below 65536 / 65536 / 16384: 262144 / 262144 / 65536 at 1920x1080, 1040384 / 1040384 /
+ * 262144 at 3840x2160). */
 void vslam_params_default(vslam_params* p, int rows, int cols);
 /* Pure host computation (no GPU needed). */
 int vslam_batch_layout_query(const vslam_params* p, vslam_batch_layout* out);
+/* Bytes each output buffer needs for n_frames frames under *p: sets struct_size and every x_bytes field
+ * of *sizes (also for outputs the parameters do not produce - a buffer is only needed where its pointer
+ * will be non-NULL); the pointers are left as they are.  Pure host computation. */
+int vslam_batch_out_required(const vslam_params* p, int n_frames, vslam_batch_out* sizes);
 /* Harris + DoG over n frames already resident in HBM (frame f at d_frames +
  * f*frame_stride, dense rows).  Asynchronous on the context stream.  This is the fused
  * path of BASELINE config 4: every frame is read from HBM once per path and every
@@ -355,6 +392,17 @@ int vslam_batch_layout_query(const vslam_params* p, vslam_batch_layout* out);
  * ranks with no data-path collective. */
 int vslam_detect_batch_dev(vslam_ctx* ctx, const vslam_params* p, const uint8_t* d_frames, size_t frame_stride,
                            int n_frames, const vslam_batch_out* out);
+
+/* Packs the first min(counts[f], cap) records of every frame's list ([n_frames][cap] records of
+ * record_bytes each: harris_kps, dog_points or oriented_points of vslam_detect_batch_dev) back to back
+ * into `packed`, frame after frame, and writes offsets[f] = sum over g < f of min(counts[g], cap) for
+ * f = 0..n_frames (offsets[n_frames] = total records): a host-fed caller then downloads
+ * offsets[n_frames] * record_bytes bytes instead of n_frames * cap records of mostly padding.  All
+ * pointers are DEVICE pointers; asynchronous on the context stream, behind the call that wrote the lists.
+ * Records that do not fit packed_bytes are not written (offsets still give their positions, so
+ * offsets[n_frames] * record_bytes > packed_bytes tells the caller).  record_bytes: a multiple of 4. */
+int vslam_pack_lists_dev(vslam_ctx* ctx, const void* lists, size_t record_bytes, uint32_t cap, const uint32_t* counts,
+                         int n_frames, void* packed, size_t packed_bytes, uint64_t* offsets);
 
 /* Timing hook for bench.py: when enabled, the context brackets every launch of the
  * named kernel with HIP events on its stream; vslam_kernel_timing_read synchronises and

@@ -32,7 +32,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/vslam.h but not exported"
     assert set(names) == set(capi.SIGNATURES), "capi.SIGNATURES out of sync with include/vslam.h"
-    assert lib.vslam_version() == 100
+    assert lib.vslam_version() == 200
     assert b"k_harris_strip" in lib.vslam_kernel_names()
 
 
@@ -99,3 +99,46 @@ def test_null_arguments_are_rejected_without_touching_the_gpu(lib):
     assert lib.vslam_pyramid_destroy(None) == -1
     assert lib.vslam_batch_layout_query(None, None) == -1
     assert lib.vslam_last_error(None) == b"null context"
+
+
+def test_default_list_capacities_follow_the_frame_area(lib):
+    # the fixed 2^18 default overflowed at 3840x2160
+    caps = lambda r, c: (lambda p: (p.harris_cap, p.dog_cap, p.oriented_cap))(capi.default_params(r, c))
+    assert caps(1080, 1920) == (262144, 262144, 65536)
+    assert caps(2160, 3840) == (1040384, 1040384, 262144)
+    assert caps(96, 160) == (65536, 65536, 16384)  # floors: an all-noise small frame still fits
+    assert capi.default_params(1080, 1920).extrema_dense == 0
+
+
+def test_batch_out_required_sizes(lib):
+    p = capi.default_params(1080, 1920)
+    L = capi.batch_layout(p)
+    n = 256
+    z = capi.batch_out_required(p, n)
+    N = 1080 * 1920
+    assert z.struct_size == C.sizeof(capi.BatchOut)
+    assert (z.response_bytes, z.nms_mask_bytes, z.nms2_bytes) == (4 * n * N, n * N, 4 * n * N)
+    assert (z.harris_kps_bytes, z.harris_counts_bytes) == (12 * n * p.harris_cap, 4 * n)
+    assert (z.pyramid_bytes, z.extrema_bits_bytes) == (n * L.pyramid_frame_bytes, 8 * n * L.bits_frame_words)
+    assert (z.dog_points_bytes, z.dog_counts_bytes) == (24 * n * p.dog_cap, 4 * n)
+    assert (z.oriented_points_bytes, z.oriented_counts_bytes, z.oriented_survivors_bytes) == (24 * n * p.oriented_cap, 4 * n, 4 * n)
+    assert (z.descriptors_bytes, z.descriptor_defined_bytes) == (512 * n * p.oriented_cap, n * p.oriented_cap)
+    with pytest.raises(capi.VslamError):
+        capi.batch_out_required(p, 0)
+    # the header's struct: one size_t, then (pointer, size_t) per output, in the header's order
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "vslam.h")).read(), flags=re.S)
+    body = text[text.index("size_t struct_size;"): text.index("} vslam_batch_out;")]
+    fields = re.findall(r"\b(\w+);", body)
+    want = ["struct_size"] + [f for n_ in capi.BATCH_OUT_FIELDS for f in (n_, n_ + "_bytes")]
+    assert fields == want
+
+
+def test_dense_mode_layout(lib):
+    # extension: the dense 3x3x3 scan's bitmask has one site per pixel of levels 1..3
+    p = capi.default_params(1080, 1920, extrema_dense=1)
+    L = capi.batch_layout(p)
+    assert [(L.lat_rows[o], L.lat_cols[o], L.lat_words[o]) for o in range(4)] == [(2160, 3840, 60), (1080, 1920, 30), (540, 960, 15), (270, 480, 8)]
+    assert L.bits_frame_words == 3 * (2160 * 60 + 1080 * 30 + 540 * 15 + 270 * 8)
+    for bad in (dict(localize=1), dict(extrema_window=5), dict(localize=1, orient=1)):
+        with pytest.raises(capi.VslamError):
+            capi.batch_layout(capi.default_params(64, 64, extrema_dense=1, **bad))

@@ -136,6 +136,60 @@ def test_batch_larger_than_one_chunk(env, mode):
     assert out["dog_counts"][256] != out["dog_counts"][0] or out["harris_counts"][256] != out["harris_counts"][0]
 
 
+@pytest.mark.parametrize("lists", [False, True])
+def test_two_full_chunks_of_256_frames(env, lists):
+    # with two chunks of >= 64 frames the second chunk's half-batch upsample runs on a
+    # side stream and overwrites the octave bases of frames [128, 256) of the FIRST chunk; in a pyramid-only
+    # call nothing but the ev_chunk wait orders it behind the first chunk's octave-0 kernel.  Every frame
+    # is different (its own seed; noise frames at the seams), so a pyramid built from the wrong chunk's
+    # base cannot pass.  Pyramid-only and list mode; second halves of both chunks against the oracle, and
+    # every pyramid of a second run of the same batch equal to the first (a race is not repeatable).
+    ctx, torch = env
+    rows, cols, n, n_oct = 136, 248, 512, 3
+    frames_np = np.stack([synth.frame_np(rows, cols, frame=f, stream_id=31 + (f >> 8), kind="noise" if f % 64 == 0 else "checker")
+                          for f in range(n)])
+    dev = "cuda:0"
+    frames = torch.from_numpy(frames_np).to(dev)
+    p = capi.default_params(rows, cols, n_octaves=n_oct, harris_cap=4096, dog_cap=16384)
+    L = capi.batch_layout(p)
+    runs = []
+    for rep in range(2):
+        o = dict(pyramid=torch.zeros((n, L.pyramid_frame_bytes), dtype=torch.uint8, device=dev))
+        if lists:
+            o.update(extrema_bits=torch.zeros((n, L.bits_frame_words), dtype=torch.int64, device=dev),
+                     dog_points=torch.zeros((n, p.dog_cap, 6), dtype=torch.int32, device=dev),
+                     dog_counts=torch.zeros(n, dtype=torch.int32, device=dev),
+                     response=torch.empty((n, rows, cols), dtype=torch.float32, device=dev),
+                     harris_kps=torch.zeros((n, p.harris_cap, 3), dtype=torch.int32, device=dev),
+                     harris_counts=torch.zeros(n, dtype=torch.int32, device=dev))
+        ctx.detect_batch(p, frames, **o)
+        torch.cuda.synchronize()
+        runs.append(o)
+    assert torch.equal(runs[0]["pyramid"], runs[1]["pyramid"])
+    o = runs[0]
+    for f in (0, 127, 128, 129, 191, 254, 255, 256, 383, 384, 385, 448, 511):
+        want = oracle.Pyramid(frames_np[f], n_oct, p.sigma0)
+        blk = o["pyramid"][f].cpu().numpy()
+        pts = []
+        for oc in range(n_oct):
+            r, c = want.sizes[oc]
+            pitch, off = L.pitch[oc], L.octave_offset[oc]
+            P = r * pitch
+            for l in range(6):
+                assert (blk[off + l * P: off + (l + 1) * P].reshape(r, pitch)[:, :c] == want.gauss(oc, l)).all(), (f, "gauss", oc, l)
+            for l in range(5):
+                assert (blk[off + (6 + l) * P: off + (7 + l) * P].reshape(r, pitch)[:, :c] == want.dog(oc, l)).all(), (f, "dog", oc, l)
+            pts.append(want.extrema(oc, 3, 8)[1])
+        want.close()
+        if lists:
+            allp = np.concatenate(pts)
+            assert int(o["dog_counts"][f]) == len(allp), f
+            assert o["dog_points"][f][: len(allp)].cpu().numpy().view(capi.POINT_DTYPE).reshape(-1).tobytes() == allp.tobytes(), f
+            kps = oracle.harris_keypoints(oracle.nms2(oracle.harris_response(frames_np[f]), 5)[0])
+            assert int(o["harris_counts"][f]) == len(kps), f
+            assert o["harris_kps"][f][: len(kps)].cpu().numpy().view(capi.KP_DTYPE).reshape(-1).tobytes() == kps.tobytes(), f
+
+
 @pytest.mark.parametrize("mode", ["candidates", "localized", "oriented"])
 def test_batch_of_40_frames_takes_the_gated_launch_order(env, mode):
     # from 32 frames on the side streams are ordered differently (vslam_hip.hip, enqueue_dog): the Harris
@@ -306,6 +360,76 @@ def test_batch_argument_errors(env):
     bad = capi.default_params(32, 32, extrema_window=4)
     with pytest.raises(capi.VslamError):
         ctx.detect_batch(bad, frames, pyramid=torch.zeros(1 << 20, dtype=torch.uint8, device="cuda:0"))
+
+
+def test_undersized_buffers_are_refused_before_any_launch(env):
+    # vslam_batch_out carries the size of every buffer; a buffer smaller than n_frames
+    # frames need is VSLAM_ERR_INVALID (-1) and nothing is written
+    ctx, torch = env
+    rows, cols, n = 64, 96, 3
+    frames = torch.from_numpy(synth.frames_np(n, rows, cols)).to("cuda:0")
+    p = capi.default_params(rows, cols, n_octaves=2)
+    L = capi.batch_layout(p)
+    z = capi.batch_out_required(p, n)
+    dev = "cuda:0"
+    good = dict(response=torch.zeros((n, rows, cols), dtype=torch.float32, device=dev),
+                harris_kps=torch.zeros((n, p.harris_cap, 3), dtype=torch.int32, device=dev),
+                harris_counts=torch.zeros(n, dtype=torch.int32, device=dev),
+                pyramid=torch.zeros(z.pyramid_bytes, dtype=torch.uint8, device=dev),
+                extrema_bits=torch.zeros((n, L.bits_frame_words), dtype=torch.int64, device=dev),
+                dog_points=torch.zeros((n, p.dog_cap, 6), dtype=torch.int32, device=dev),
+                dog_counts=torch.zeros(n, dtype=torch.int32, device=dev))
+    for k in good:
+        bad = dict(good)
+        flat = good[k].reshape(-1)
+        bad[k] = flat[: flat.numel() - 1].clone()  # one element short
+        with pytest.raises(capi.VslamError) as e:
+            ctx.detect_batch(p, frames, **bad)
+        assert e.value.status == -1 and k in str(e.value), (k, str(e.value))
+    torch.cuda.synchronize()
+    assert all(not bool(t.any()) for t in good.values())  # the refused calls launched nothing
+    ctx.detect_batch(p, frames, **good)  # exactly the required sizes pass
+    torch.cuda.synchronize()
+    assert bool(good["pyramid"].any())
+    # a struct without sizes (struct_size unset) is refused as well
+    import ctypes as C
+    bo = capi.BatchOut()
+    bo.pyramid = good["pyramid"].data_ptr()
+    rc = capi.lib().vslam_detect_batch_dev(ctx._h, C.byref(p), frames.data_ptr(), rows * cols, n, C.byref(bo))
+    assert rc == -1 and b"struct_size" in capi.lib().vslam_last_error(ctx._h)
+
+
+@pytest.mark.parametrize("n,cap", [(1, 64), (5, 4096), (300, 700), (513, 96)])
+def test_pack_lists(env, n, cap):
+    # vslam_pack_lists_dev: the lists of a batch back to back (what a host-fed caller downloads), 12- and
+    # 24-byte records, counts above the capacity clipped, a packed buffer that is too small never overrun
+    ctx, torch = env
+    dev = "cuda:0"
+    rng = np.random.default_rng(n * 1000 + cap)
+    for k in (3, 6):
+        lists = torch.from_numpy(rng.integers(-2**31, 2**31 - 1, size=(n, cap, k), dtype=np.int64).astype(np.int32)).to(dev)
+        counts_np = rng.integers(0, cap + cap // 4 + 2, size=n).astype(np.int32)  # some exceed cap
+        counts_np[rng.integers(0, n)] = 0
+        counts = torch.from_numpy(counts_np).to(dev)
+        m = np.minimum(counts_np, cap).astype(np.int64)
+        total = int(m.sum())
+        packed = torch.full((total * k + 5,), 77, dtype=torch.int32, device=dev)
+        offsets = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+        ctx.pack_lists(lists, counts, packed, offsets)
+        torch.cuda.synchronize()
+        off = offsets.cpu().numpy()
+        assert (off == np.concatenate([[0], np.cumsum(m)])).all()
+        want = np.concatenate([lists[f, : m[f]].cpu().numpy().reshape(-1) for f in range(n)]) if total else np.zeros(0, np.int32)
+        got = packed.cpu().numpy()
+        assert (got[: total * k] == want).all() and (got[total * k:] == 77).all()
+        if total > 3:  # too small a destination: filled up to its end, nothing beyond, offsets unchanged
+            small = torch.full((total * k - 2 * k + 1 + 4,), 77, dtype=torch.int32, device=dev)
+            view = small[: total * k - 2 * k + 1]
+            ctx.pack_lists(lists, counts, view, offsets)
+            torch.cuda.synchronize()
+            g2 = small.cpu().numpy()
+            assert (g2[: view.numel()] == want[: view.numel()]).all() and (g2[view.numel():] == 77).all()
+            assert int(offsets[-1]) == total
 
 
 def test_fast_paths_are_the_ones_that_run(env):

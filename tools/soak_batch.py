@@ -1,6 +1,6 @@
 """One-off randomized parity soak of the batched path (not part of the test suite)."""
-import sys, time
-sys.path.insert(0, "/root/repo")
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from tests.test_gpu_batch import run_batch, check_frame
 from visualslam_amd import capi, synth

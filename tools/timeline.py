@@ -1,4 +1,7 @@
-"""Print the kernel timeline of the last full batch in a rocprofv3 kernel trace (csv)."""
+"""Print the kernel timeline of the last full batch in a rocprofv3 kernel trace.
+
+    python tools/timeline.py <..._kernel_trace.csv>     (the CSV file itself, not its directory)
+"""
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))

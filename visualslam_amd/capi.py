@@ -38,7 +38,7 @@ class Params(C.Structure):
         ("rows", C.c_int), ("cols", C.c_int), ("n_octaves", C.c_int), ("sigma0", C.c_double),
         ("harris_k", C.c_float), ("do_harris", C.c_int), ("extrema_window", C.c_int),
         ("min_contrast", C.c_int), ("localize", C.c_int), ("orient", C.c_int), ("harris_cap", C.c_uint32), ("dog_cap", C.c_uint32),
-        ("oriented_cap", C.c_uint32),
+        ("oriented_cap", C.c_uint32), ("extrema_dense", C.c_int),
     ]
 
 
@@ -54,15 +54,13 @@ class BatchLayout(C.Structure):
     ]
 
 
+BATCH_OUT_FIELDS = ("response", "nms_mask", "nms2", "harris_kps", "harris_counts", "pyramid", "extrema_bits", "dog_points", "dog_counts",
+                    "oriented_points", "oriented_counts", "oriented_survivors", "descriptors", "descriptor_defined")
+
+
 class BatchOut(C.Structure):
-    _fields_ = [
-        ("response", C.c_void_p), ("nms_mask", C.c_void_p), ("nms2", C.c_void_p),
-        ("harris_kps", C.c_void_p), ("harris_counts", C.c_void_p),
-        ("pyramid", C.c_void_p), ("extrema_bits", C.c_void_p),
-        ("dog_points", C.c_void_p), ("dog_counts", C.c_void_p),
-        ("oriented_points", C.c_void_p), ("oriented_counts", C.c_void_p), ("oriented_survivors", C.c_void_p),
-        ("descriptors", C.c_void_p), ("descriptor_defined", C.c_void_p),
-    ]
+    """vslam_batch_out: struct_size, then (pointer, bytes behind it) per output."""
+    _fields_ = [("struct_size", C.c_size_t)] + [f for n in BATCH_OUT_FIELDS for f in ((n, C.c_void_p), (n + "_bytes", C.c_size_t))]
 
 
 class PyramidInfo(C.Structure):
@@ -119,7 +117,9 @@ SIGNATURES = {
     "vslam_structure_matrix_windows": (_I, [_P, _P, _P, _I, _Z, _P]),
     "vslam_params_default": (None, [C.POINTER(Params), _I, _I]),
     "vslam_batch_layout_query": (_I, [C.POINTER(Params), C.POINTER(BatchLayout)]),
+    "vslam_batch_out_required": (_I, [C.POINTER(Params), _I, C.POINTER(BatchOut)]),
     "vslam_detect_batch_dev": (_I, [_P, C.POINTER(Params), _P, _Z, _I, C.POINTER(BatchOut)]),
+    "vslam_pack_lists_dev": (_I, [_P, _P, _Z, C.c_uint32, _P, _I, _P, _Z, _P]),
     "vslam_kernel_timing_enable": (_I, [_P, C.c_char_p]),
     "vslam_kernel_timing_read": (_I, [_P, C.POINTER(_I), C.POINTER(_D)]),
     "vslam_kernel_names": (C.c_char_p, []),
@@ -240,6 +240,15 @@ def batch_layout(p: Params) -> BatchLayout:
     if rc:
         raise VslamError(rc, "vslam_batch_layout_query")
     return L
+
+
+def batch_out_required(p: Params, n_frames: int) -> BatchOut:
+    """Bytes every output buffer needs for n_frames frames (the x_bytes fields; pointers stay NULL)."""
+    z = BatchOut()
+    rc = lib().vslam_batch_out_required(C.byref(p), int(n_frames), C.byref(z))
+    if rc:
+        raise VslamError(rc, "vslam_batch_out_required")
+    return z
 
 
 def _u8(a):
@@ -421,17 +430,15 @@ class Context:
         L = batch_layout(params)  # raises on bad parameters before anything is checked against them
         N = params.rows * params.cols
 
-        def need(name, t, dtype, numel):
-            # the C ABI carries no buffer sizes: an undersized or mis-typed tensor would be a silent
-            # out-of-bounds device write, so it is refused here
+        def need(name, t, dtype):
+            # sizes are checked by the library itself (vslam_batch_out carries them); placement, dtype and
+            # contiguity are properties of the tensor that only this wrapper can see
             if not (t.is_cuda and t.device.index == self.device):
                 raise ValueError(f"detect_batch: {name} is not on cuda:{self.device}")
             if t.dtype not in dtype:
                 raise ValueError(f"detect_batch: {name} has dtype {t.dtype}, expected one of {dtype}")
             if not t.is_contiguous():
                 raise ValueError(f"detect_batch: {name} is not contiguous")
-            if t.numel() * t.element_size() < numel:
-                raise ValueError(f"detect_batch: {name} holds {t.numel() * t.element_size()} bytes, needs {numel}")
 
         if frames.dim() != 3 or tuple(frames.shape[1:]) != (params.rows, params.cols) or frames.stride(2) != 1 or frames.stride(1) != params.cols:
             raise ValueError("detect_batch: frames must be [n, rows, cols] uint8 with dense rows")
@@ -441,22 +448,31 @@ class Context:
             raise ValueError("detect_batch: frames overlap")
         i32, u8, f32, i64 = (torch.int32,), (torch.uint8,), (torch.float32,), (torch.int64, torch.uint64)
         spec = {
-            "response": (f32, 4 * n * N), "nms_mask": (u8, n * N), "nms2": (f32, 4 * n * N),
-            "harris_kps": (i32 + f32, 12 * n * params.harris_cap), "harris_counts": (i32, 4 * n),
-            "pyramid": (u8, n * L.pyramid_frame_bytes), "extrema_bits": (i64, 8 * n * L.bits_frame_words),
-            "dog_points": (i32, 24 * n * params.dog_cap), "dog_counts": (i32, 4 * n),
-            "oriented_points": (i32, 24 * n * params.oriented_cap), "oriented_counts": (i32, 4 * n),
-            "oriented_survivors": (i32, 4 * n),
-            "descriptors": (f32, 512 * n * params.oriented_cap), "descriptor_defined": (u8, n * params.oriented_cap),
+            "response": f32, "nms_mask": u8, "nms2": f32, "harris_kps": i32 + f32, "harris_counts": i32,
+            "pyramid": u8, "extrema_bits": i64, "dog_points": i32, "dog_counts": i32,
+            "oriented_points": i32, "oriented_counts": i32, "oriented_survivors": i32,
+            "descriptors": f32, "descriptor_defined": u8,
         }
         bo = BatchOut()
+        bo.struct_size = C.sizeof(BatchOut)
         for k, t in outs.items():
             if t is not None:
                 if k not in spec:
                     raise ValueError(f"detect_batch: unknown output {k!r}")
-                need(k, t, *spec[k])
+                need(k, t, spec[k])
                 setattr(bo, k, t.data_ptr())
+                setattr(bo, k + "_bytes", t.numel() * t.element_size())
         return n, bo, (frames.stride(0) if n > 1 else N)  # a size-1 dimension may carry any stride
+
+    def pack_lists(self, lists, counts, packed, offsets):
+        """vslam_pack_lists_dev: lists [n, cap, k] (int32 / float32 records), counts [n] int32 -> packed (flat,
+        any capacity), offsets [n + 1] int64.  CUDA tensors; asynchronous on the context stream."""
+        n, cap = lists.shape[0], lists.shape[1]
+        rb = lists[0, 0].numel() * lists.element_size()
+        if not (lists.is_contiguous() and packed.is_contiguous() and counts.numel() >= n and offsets.numel() >= n + 1 and offsets.element_size() == 8):
+            raise ValueError("pack_lists: bad tensors")
+        self._chk(lib().vslam_pack_lists_dev(self._h, lists.data_ptr(), rb, cap, counts.data_ptr(), n, packed.data_ptr(),
+                                             packed.numel() * packed.element_size(), offsets.data_ptr()), "vslam_pack_lists_dev")
 
     def kernel_timing_enable(self, name: str | None):
         self._chk(lib().vslam_kernel_timing_enable(self._h, name.encode() if name else None), "vslam_kernel_timing_enable")

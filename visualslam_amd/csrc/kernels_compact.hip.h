@@ -312,4 +312,43 @@ __global__ __launch_bounds__(256) void k_flag_scatter(const E ent, const unsigne
     }
 }
 
+// ---- packing the per-frame lists back to back (vslam_pack_lists_dev) ---------------------------------
+// one block: offsets[f] = sum over g < f of min(counts[g], cap), f = 0..n (64-bit: n * cap may exceed 2^32)
+__global__ __launch_bounds__(256) void k_pack_offsets(const unsigned int* __restrict__ counts, unsigned int cap, int n,
+                                                       unsigned long long* __restrict__ offsets) {
+    __shared__ unsigned long long sc[256];
+    const int t = threadIdx.x;
+    unsigned long long running = 0;
+    for (int base = 0; base < n; base += 256) {
+        const int i = base + t;
+        const unsigned long long v = i < n ? (unsigned long long)min(counts[i], cap) : 0ull;
+        sc[t] = v;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {  // Hillis-Steele inclusive scan
+            const unsigned long long a = t >= off ? sc[t - off] : 0ull;
+            __syncthreads();
+            sc[t] += a;
+            __syncthreads();
+        }
+        if (i < n) offsets[i] = running + sc[t] - v;
+        running += sc[255];
+        __syncthreads();
+    }
+    if (t == 0) offsets[n] = running;
+}
+
+// grid = (blocks per frame, 1, frames): dword-wise copy of frame f's first min(counts[f], cap) records to
+// packed + offsets[f] records; consecutive threads move consecutive dwords on both sides.
+__global__ __launch_bounds__(256) void k_pack_copy(const unsigned int* __restrict__ lists, unsigned int rec_dw, unsigned int cap,
+                                                    const unsigned int* __restrict__ counts,
+                                                    const unsigned long long* __restrict__ offsets,
+                                                    unsigned int* __restrict__ packed, unsigned long long packed_dw) {
+    const int f = blockIdx.z;
+    const unsigned long long ndw = (unsigned long long)min(counts[f], cap) * rec_dw;
+    const unsigned int* src = lists + (size_t)f * cap * rec_dw;
+    const unsigned long long d0 = offsets[f] * rec_dw;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < ndw; i += (unsigned long long)gridDim.x * 256)
+        if (d0 + i < packed_dw) packed[d0 + i] = src[i];
+}
+
 }  // namespace vslam

@@ -43,9 +43,13 @@ struct vslam_ctx {
     std::map<std::pair<uint64_t, int>, void*> tile_taps;        // (sigma0 bits, octave) -> PyrTaps<CFG>
     // auxiliary streams of the batched path: the HBM-bound chains (Harris; extrema + compaction)
     // run beside the VALU-bound pyramid kernels; forked from / joined to `stream` by events
-    hipStream_t aux[2] = {nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr}, ev_oct[VSLAM_MAX_OCTAVES] = {};
+    // aux[2] carries only the second-half upsample of a large batch (enqueue_dog): it must not queue behind
+    // the previous chunk's list chain on aux[1]
+    static constexpr int kAux = 3;
+    hipStream_t aux[kAux] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[kAux] = {nullptr, nullptr, nullptr}, ev_oct[VSLAM_MAX_OCTAVES] = {};
     hipEvent_t ev_up2 = nullptr;  // the second half of a batch has been upsampled (enqueue_dog)
+    hipEvent_t ev_chunk = nullptr;  // the main-stream kernels of a chunk (the readers of the octave bases) are enqueued up to here
     hipEvent_t ev_list0 = nullptr, ev_edge = nullptr;  // octave 0's part of the DoG list is written / its edge test is done
     // recycled pyramid blocks: a GaussPyramid per image would otherwise pay hipMalloc + hipFree of
     // >100 MB each time (milliseconds, more than the kernels)
@@ -96,7 +100,7 @@ static const char* const kKernelNames =
     "k_resize_linear2x\nk_blur_h_generic\nk_blur_v_generic\n"
     "k_dog5\nk_resize_nearest_half\nk_extrema\nk_pyr_octave\n"
     "k_gauss_v_strip\nk_gauss_h_strip\nk_resize_linear2x_slide\nk_resize_nearest_half_v4\nk_extrema_w3\nk_extrema_dense\nk_localize_points\nk_orient_keypoints\nk_edge_response_windows\nk_level_gradients\nk_pack_rows\nk_edge_flags\nk_orient_survivors\n"
-    "k_harris_strip\nk_flag_count\nk_chunk_scan\nk_flag_scatter\nk_level_gradients\nk_sift_descriptors";
+    "k_harris_strip\nk_flag_count\nk_chunk_scan\nk_flag_scatter\nk_level_gradients\nk_sift_descriptors\nk_pack_offsets\nk_pack_copy";
 
 static std::pair<hipEvent_t, hipEvent_t>* timing_slot(vslam_ctx* c);
 
@@ -143,8 +147,11 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 static int ensure_aux(vslam_ctx* c) {
     if (c->ev_fork) return VSLAM_OK;
     int prio_lo = 0, prio_hi = 0;
-    if (hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess) prio_lo = 0;  // numerically: lowest priority, highest priority
-    for (int i = 0; i < 2; ++i) {
+    if (hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess) {  // numerically: lowest priority, highest priority
+        (void)hipGetLastError();  // priorities are a speed matter only: do not leave the error for the next launch check
+        prio_lo = 0;
+    }
+    for (int i = 0; i < vslam_ctx::kAux; ++i) {
         if (hipStreamCreateWithPriority(&c->aux[i], hipStreamNonBlocking, prio_lo) != hipSuccess) {
             (void)hipGetLastError();  // priorities are a speed matter only
             HIPCHK(c, hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking));
@@ -153,6 +160,7 @@ static int ensure_aux(vslam_ctx* c) {
     }
     for (auto& e : c->ev_oct) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_up2, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_chunk, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_list0, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_edge, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
@@ -209,7 +217,7 @@ static int ws_reserve(vslam_ctx* c, size_t bytes) {
     c->ws_off = 0;
     if (bytes <= c->ws_cap) return VSLAM_OK;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < vslam_ctx::kAux; ++i)
         if (c->aux[i]) HIPCHK(c, hipStreamSynchronize(c->aux[i]));
     if (c->ws) (void)hipFree(c->ws);
     c->ws = nullptr;
@@ -536,13 +544,29 @@ static int dog_side_gate(const vslam_params& p, const vslam_batch_layout& L, int
     return gate;
 }
 
+// Geometry of the dense 3x3x3 scan (kernels_extrema_dense.hip.h) for octave o of nf frames.
+static DenseGeom dense_geom(const vslam_batch_layout& L, int o, int min_contrast, int nf) {
+    DenseGeom g;
+    g.rows = L.rows[o], g.cols = L.cols[o], g.pitch = L.pitch[o];
+    g.wpr = (g.cols + 63) / 64;
+    g.min_contrast = min_contrast;
+    g.P = (unsigned int)((size_t)g.rows * g.pitch);
+    g.dog_off = (unsigned int)(L.octave_offset[o] + (size_t)VSLAM_NUM_LEVELS * g.P);
+    // a lane walks g.seg rows: long segments amortise the two halo rows, short ones give a small launch
+    // enough waves to hide the loads (about 8 per SIMD)
+    const long waves_per_rowseg = 4L * (((g.cols + 3) / 4 + 255) / 256) * nf;
+    const long segs_wanted = std::max<long>(1, 8192 / waves_per_rowseg);
+    g.seg = (int)std::min<long>(XD_SEG_MAX, std::max<long>(4, (g.rows + segs_wanted - 1) / segs_wanted));
+    return g;
+}
+
 // createPyramid (GaussPyramid.cpp:106-131) + initialKeypointDetection (Diff_of_Gauss.cpp:254)
 // for nf frames; pyr/bits/points are per-frame blocks with the given strides.
 static int enqueue_dog(vslam_ctx* c, const vslam_params& p, const vslam_batch_layout& L, const uint8_t* frames,
                        size_t fstep, size_t fframe, int nf, uint8_t* pyr, size_t pframe, DogScratch& s,
                        unsigned long long* bits, bool do_extrema, vslam_point* points, unsigned int* counts,
                        hipStream_t side = nullptr, const std::function<int(int)>& after_list = nullptr,
-                       const std::function<int(int)>& after_octave = nullptr) {
+                       const std::function<int(int)>& after_octave = nullptr, hipStream_t up = nullptr, bool later_chunk = false) {
     // `side`: stream for the extrema scans and the list compaction (they only read what the
     // octave kernels wrote); ordered after the octave kernels by events.  nullptr = same stream.
     //
@@ -565,11 +589,16 @@ static int enqueue_dog(vslam_ctx* c, const vslam_params& p, const vslam_batch_la
     // Large batches go through the upsample and octave 0 in two halves: the second half is upsampled
     // on the side stream (idle until octave 0 is done) while the first half's octave-0 kernel runs, so
     // only half of the bandwidth-bound upsample is exposed in front of the VALU-bound octave kernels.
-    const int nf_a = (side && nf >= 64) ? nf / 2 : nf;
+    // The second half goes to a stream of its own (`up`): on `side` it would queue behind the previous
+    // chunk's whole list chain.  It overwrites bases the previous chunk's octave kernels (main stream)
+    // read, and nothing else orders it behind them - with pyramid-only outputs there is not even a scan
+    // waiting on ev_oct - so it waits for ev_chunk, recorded at the end of every chunk's main-stream work.
+    const int nf_a = (side && up && nf >= 64) ? nf / 2 : nf;
     LAUNCH(c, "k_resize_linear2x_slide", k_resize_linear2x_slide, dim3(((p.cols + 3) / 4 + 255) / 256, (p.rows + 15) / 16, nf_a), dim3(256),
            frames, fstep, fframe, s.bases + s.base_off[0], s.bases_frame, L.pitch[0], p.rows, p.cols, 16);
     if (nf_a < nf) {
-        StreamSwap sw(c, side);
+        if (later_chunk) HIPCHK(c, hipStreamWaitEvent(up, c->ev_chunk, 0));
+        StreamSwap sw(c, up);
         LAUNCH(c, "k_resize_linear2x_slide", k_resize_linear2x_slide, dim3(((p.cols + 3) / 4 + 255) / 256, (p.rows + 15) / 16, nf - nf_a), dim3(256),
                frames + (size_t)nf_a * fframe, fstep, fframe, s.bases + s.base_off[0] + (size_t)nf_a * s.bases_frame, s.bases_frame, L.pitch[0],
                p.rows, p.cols, 16);
@@ -634,7 +663,13 @@ static int enqueue_dog(vslam_ctx* c, const vslam_params& p, const vslam_batch_la
                 HIPCHK(c, hipStreamWaitEvent(side, c->ev_oct[o_done], 0));
                 es = side;
             }
-            if (p.extrema_window == 3) {
+            if (p.extrema_dense) {
+                // extension: the dense 3x3x3 test on every pixel (kernels_extrema_dense.hip.h); the layout's
+                // lattice of this mode is the image itself
+                const DenseGeom dg = dense_geom(L, o, p.min_contrast, nf);
+                hipLaunchKernelGGL(k_extrema_dense, dim3(((dg.cols + 3) / 4 + 255) / 256, (dg.rows + dg.seg - 1) / dg.seg, nf), dim3(256), 0, es,
+                                   pyr, pframe, dg, bits ? bits + L.bits_offset[o] : nullptr, s.lflags + L.bits_offset[o], L.bits_frame_words);
+            } else if (p.extrema_window == 3) {
                 const dim3 eg((L.lat_words[o] + 3) / 4, L.lat_rows[o], nf);
                 if (p.localize)
                     hipLaunchKernelGGL(k_extrema_w3<true>, eg, dim3(256), 0, es, pyr, pframe, g, o, bits, s.lflags, L.bits_frame_words);
@@ -649,12 +684,19 @@ static int enqueue_dog(vslam_ctx* c, const vslam_params& p, const vslam_batch_la
         // stream it overlaps the next octave's kernels instead of forming a serial tail
         if (do_extrema && points && counts) {
             StreamSwap sw(c, side ? side : c->stream);
-            DogEntries ent{s.lflags, L.bits_frame_words, pyr, pframe, g, o, o + 1, points};
-            TRY(enqueue_compaction(c, ent, (size_t)3 * L.lat_rows[o] * L.lat_words[o], nf, s.cws, p.dog_cap, counts, o > 0 ? 1 : 0));
+            const size_t entries = (size_t)3 * L.lat_rows[o] * L.lat_words[o];
+            if (p.extrema_dense) {
+                DenseDogEntries ent{s.lflags + L.bits_offset[o], L.bits_frame_words, pyr, pframe, dense_geom(L, o, p.min_contrast, nf), o, points};
+                TRY(enqueue_compaction(c, ent, entries, nf, s.cws, p.dog_cap, counts, o > 0 ? 1 : 0));
+            } else {
+                DogEntries ent{s.lflags, L.bits_frame_words, pyr, pframe, g, o, o + 1, points};
+                TRY(enqueue_compaction(c, ent, entries, nf, s.cws, p.dog_cap, counts, o > 0 ? 1 : 0));
+            }
             if (after_list) TRY(after_list(o));  // on the stream the list is written on, behind octave o's records
         }
         }  // oo
     }
+    if (side && up) HIPCHK(c, hipEventRecord(c->ev_chunk, c->stream));
     return VSLAM_OK;
 }
 
@@ -756,7 +798,7 @@ int vslam_ctx_destroy(vslam_ctx* c) {
     if (!c) return VSLAM_ERR_INVALID;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (int i = 0; i < 2; ++i)  // a failed batch call may have left side-stream work un-joined
+    for (int i = 0; i < vslam_ctx::kAux; ++i)  // a failed batch call may have left side-stream work un-joined
         if (c->aux[i]) (void)hipStreamSynchronize(c->aux[i]);
     for (auto& kv : c->taps) (void)hipFree(kv.second);
     for (auto& kv : c->strip_taps) (void)hipFree(kv.second);
@@ -769,12 +811,12 @@ int vslam_ctx_destroy(vslam_ctx* c) {
     for (auto& b : c->block_cache) (void)hipFree(b.second);
     if (c->loc_lut) (void)hipFree(c->loc_lut);
     for (auto& kv : c->orient_taps) (void)hipFree(kv.second);
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < vslam_ctx::kAux; ++i) {
         if (c->aux[i]) (void)hipStreamDestroy(c->aux[i]);
         if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
     }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    for (hipEvent_t e : {c->ev_up2, c->ev_list0, c->ev_edge})
+    for (hipEvent_t e : {c->ev_up2, c->ev_chunk, c->ev_list0, c->ev_edge})
         if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ev_oct)
         if (e) (void)hipEventDestroy(e);
@@ -1217,12 +1259,7 @@ int vslam_dog_extrema_dense(vslam_ctx* c, const vslam_pyramid* py, int octave, i
     if (octave < 0 || octave >= py->layout.n_octaves) return fail(c, VSLAM_ERR_RANGE, "octave out of range");
     ARGCHK(c, min_contrast >= 0 && min_contrast <= 65535, "dense extrema: min_contrast out of range");
     const vslam_batch_layout& L = py->layout;
-    DenseGeom g;
-    g.rows = L.rows[octave], g.cols = L.cols[octave], g.pitch = L.pitch[octave];
-    g.wpr = (g.cols + 63) / 64;
-    g.min_contrast = min_contrast;
-    g.P = (unsigned int)((size_t)g.rows * g.pitch);
-    g.dog_off = (unsigned int)(L.octave_offset[octave] + (size_t)VSLAM_NUM_LEVELS * g.P);
+    DenseGeom g = dense_geom(L, octave, min_contrast, 1);
     const size_t words = (size_t)3 * g.rows * g.wpr;
     const unsigned int ocap = (unsigned int)std::min<size_t>(cap, 0x7fffffff);
     TRY(ws_reserve(c, 2 * ws_need(words * 8) + ws_need(sizeof(vslam_point) * (size_t)ocap) + 256 + ws_need(4 * compaction_ws_elems(words, 1))));
@@ -1232,11 +1269,6 @@ int vslam_dog_extrema_dense(vslam_ctx* c, const vslam_pyramid* py, int octave, i
     unsigned int* d_n = ws_take<unsigned int>(c, 1);
     unsigned int* d_cws = ws_take<unsigned int>(c, compaction_ws_elems(words, 1));
     HIPCHK(c, hipMemsetAsync(d_n, 0, 4, c->stream));
-    // a lane walks g.seg rows: long segments amortise the two halo rows, short ones give a single image
-    // enough waves to hide the loads (about 8 per SIMD)
-    const long waves_per_rowseg = 4L * (((g.cols + 3) / 4 + 255) / 256);
-    const long segs_wanted = std::max<long>(1, 8192 / waves_per_rowseg);
-    g.seg = (int)std::min<long>(XD_SEG_MAX, std::max<long>(4, (g.rows + segs_wanted - 1) / segs_wanted));
     LAUNCH(c, "k_extrema_dense", k_extrema_dense, dim3(((g.cols + 3) / 4 + 255) / 256, (g.rows + g.seg - 1) / g.seg, 1), dim3(256),
            py->d_block, L.pyramid_frame_bytes, g, bits ? d_bits : nullptr, d_lf, words);
     DenseDogEntries ent{d_lf, words, py->d_block, L.pyramid_frame_bytes, g, octave, d_pts};
@@ -1623,6 +1655,31 @@ int vslam_detect_batch_dev(vslam_ctx* c, const vslam_params* pp, const uint8_t* 
     const bool want_kps = out->harris_kps && out->harris_counts;
     const bool harris = p.do_harris && (out->response || out->nms_mask || out->nms2 || want_kps);
     ARGCHK(c, !dog || out->pyramid, "detect_batch: the DoG path needs out->pyramid");
+    {   // every buffer against the size the caller states for it: nothing is launched on an undersized buffer
+        ARGCHK(c, out->struct_size == sizeof(vslam_batch_out),
+               "detect_batch: out->struct_size is not sizeof(vslam_batch_out) (set it and every x_bytes; vslam_batch_out_required gives the numbers)");
+        vslam_batch_out need{};
+        if (vslam_batch_out_required(&p, n_frames, &need) != VSLAM_OK) return fail(c, VSLAM_ERR_INVALID, "detect_batch: bad parameters");
+#define VSLAM_SIZECHK(field)                                                                                               \
+    if (out->field && out->field##_bytes < need.field##_bytes)                                                             \
+        return fail(c, VSLAM_ERR_INVALID, std::string("detect_batch: out->" #field " holds ") + std::to_string(out->field##_bytes) + \
+                                              " bytes, " + std::to_string(n_frames) + " frames need " + std::to_string(need.field##_bytes))
+        VSLAM_SIZECHK(response);
+        VSLAM_SIZECHK(nms_mask);
+        VSLAM_SIZECHK(nms2);
+        VSLAM_SIZECHK(harris_kps);
+        VSLAM_SIZECHK(harris_counts);
+        VSLAM_SIZECHK(pyramid);
+        VSLAM_SIZECHK(extrema_bits);
+        VSLAM_SIZECHK(dog_points);
+        VSLAM_SIZECHK(dog_counts);
+        VSLAM_SIZECHK(oriented_points);
+        VSLAM_SIZECHK(oriented_counts);
+        VSLAM_SIZECHK(oriented_survivors);
+        VSLAM_SIZECHK(descriptors);
+        VSLAM_SIZECHK(descriptor_defined);
+#undef VSLAM_SIZECHK
+    }
     const bool orient = dog && p.orient;
     ARGCHK(c, !orient || (p.localize && out->dog_points && out->dog_counts && out->oriented_points && out->oriented_counts &&
                           p.oriented_cap > 0 && p.dog_cap > 0 && p.extrema_window == 3),
@@ -1665,7 +1722,7 @@ int vslam_detect_batch_dev(vslam_ctx* c, const vslam_params* pp, const uint8_t* 
         bool armed = false;
         ~ForkGuard() {
             if (!armed) return;
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < vslam_ctx::kAux; ++i)
                 if (c->aux[i]) (void)hipStreamSynchronize(c->aux[i]);
             (void)hipStreamSynchronize(c->stream);
         }
@@ -1673,8 +1730,7 @@ int vslam_detect_batch_dev(vslam_ctx* c, const vslam_params* pp, const uint8_t* 
     if (use_aux) {
         TRY(ensure_aux(c));
         HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
-        HIPCHK(c, hipStreamWaitEvent(c->aux[0], c->ev_fork, 0));
-        HIPCHK(c, hipStreamWaitEvent(c->aux[1], c->ev_fork, 0));
+        for (int i = 0; i < vslam_ctx::kAux; ++i) HIPCHK(c, hipStreamWaitEvent(c->aux[i], c->ev_fork, 0));
         sh = c->aux[0];
         sx = c->aux[1];
         guard.armed = true;
@@ -1719,7 +1775,8 @@ int vslam_detect_batch_dev(vslam_ctx* c, const vslam_params* pp, const uint8_t* 
                             L.pyramid_frame_bytes, s,
                             out->extrema_bits ? (unsigned long long*)out->extrema_bits + (size_t)f0 * L.bits_frame_words : nullptr,
                             ext, out->dog_points ? out->dog_points + (size_t)f0 * p.dog_cap : nullptr,
-                            out->dog_counts ? out->dog_counts + f0 : nullptr, sx, after_list, after_octave));
+                            out->dog_counts ? out->dog_counts + f0 : nullptr, sx, after_list, after_octave,
+                            use_aux ? c->aux[2] : nullptr, f0 > 0));
             if (orient) {  // filterKeypoints behind the list, on the stream that produced it
                 StreamSwap sw(c, sx ? sx : c->stream);
                 TRY(enqueue_orient_batch(c, p, L, opl, nf, out->pyramid + (size_t)f0 * L.pyramid_frame_bytes, L.pyramid_frame_bytes,
@@ -1737,11 +1794,26 @@ int vslam_detect_batch_dev(vslam_ctx* c, const vslam_params* pp, const uint8_t* 
         }
     }
     if (use_aux)  // join
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < vslam_ctx::kAux; ++i) {
             HIPCHK(c, hipEventRecord(c->ev_join[i], c->aux[i]));
             HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[i], 0));
         }
     guard.armed = false;
+    return VSLAM_OK;
+}
+
+int vslam_pack_lists_dev(vslam_ctx* c, const void* lists, size_t record_bytes, uint32_t cap, const uint32_t* counts, int n_frames,
+                         void* packed, size_t packed_bytes, uint64_t* offsets) {
+    TRY(bind_device(c));
+    ARGCHK(c, lists && counts && offsets && n_frames > 0 && cap > 0 && (packed || packed_bytes == 0), "pack_lists: bad arguments");
+    ARGCHK(c, record_bytes >= 4 && record_bytes % 4 == 0 && record_bytes <= 4096, "pack_lists: record_bytes must be a multiple of 4");
+    const unsigned int rec_dw = (unsigned int)(record_bytes / 4);
+    LAUNCH(c, "k_pack_offsets", k_pack_offsets, dim3(1), dim3(256), counts, cap, n_frames, (unsigned long long*)offsets);
+    const unsigned long long frame_dw = (unsigned long long)cap * rec_dw;
+    const unsigned int gx = (unsigned int)std::min<unsigned long long>((frame_dw + 2047) / 2048, 96);
+    if (packed_bytes >= 4)
+        LAUNCH(c, "k_pack_copy", k_pack_copy, dim3(gx, 1, n_frames), dim3(256), (const unsigned int*)lists, rec_dw, cap, counts,
+               (const unsigned long long*)offsets, (unsigned int*)packed, (unsigned long long)(packed_bytes / 4));
     return VSLAM_OK;
 }
 

@@ -118,6 +118,7 @@ int make_layout(const vslam_params* p, vslam_batch_layout* L) {
         return VSLAM_ERR_INVALID;
     if (p->n_octaves > 0 && (!(p->sigma0 > 0) || p->extrema_window < 3 || (p->extrema_window & 1) == 0))
         return VSLAM_ERR_INVALID;
+    if (p->n_octaves > 0 && p->extrema_dense && (p->extrema_window != 3 || p->localize || p->orient)) return VSLAM_ERR_INVALID;
     std::memset(L, 0, sizeof(*L));
     L->n_octaves = p->n_octaves;
     int r = p->rows * 2, c = p->cols * 2;
@@ -126,7 +127,10 @@ int make_layout(const vslam_params* p, vslam_batch_layout* L) {
         if (r <= 0 || c <= 0) return VSLAM_ERR_INVALID;
         L->rows[o] = r;
         L->cols[o] = c;
-        extrema_lattice(r, c, p->extrema_window, &L->lat_rows[o], &L->lat_cols[o]);
+        if (p->extrema_dense)  // dense 3x3x3 test: one site per pixel
+            L->lat_rows[o] = r, L->lat_cols[o] = c;
+        else
+            extrema_lattice(r, c, p->extrema_window, &L->lat_rows[o], &L->lat_cols[o]);
         L->lat_words[o] = (L->lat_cols[o] + 63) / 64;
         L->octave_offset[o] = off;
         L->bits_offset[o] = woff;
@@ -193,9 +197,40 @@ void vslam_params_default(vslam_params* p, int rows, int cols) {
     p->min_contrast = 8;
     p->localize = 0;
     p->orient = 0;
-    p->oriented_cap = 1u << 16;
-    p->harris_cap = 1u << 18;
-    p->dog_cap = 1u << 18;
+    p->extrema_dense = 0;
+    // list capacities follow the frame area: 1 record per 8 pixels (Harris, DoG), 1 per 32 (oriented),
+    // rounded up to 4096 -> 262144 / 262144 / 65536 at 1920x1080 (the synthetic 1080p frame gives ~62k + ~74k);
+    // small frames keep a floor that holds even an all-noise frame's lists (65536 / 65536 / 16384)
+    const unsigned long long N = rows > 0 && cols > 0 ? (unsigned long long)rows * (unsigned long long)cols : 0ull;
+    auto cap_of = [](unsigned long long v, unsigned long long lo) {
+        v = (v + 4095ull) & ~4095ull;
+        return (uint32_t)(v < lo ? lo : v > 0x40000000ull ? 0x40000000ull : v);
+    };
+    p->oriented_cap = cap_of(N / 32, 1ull << 14);
+    p->harris_cap = cap_of(N / 8, 1ull << 16);
+    p->dog_cap = cap_of(N / 8, 1ull << 16);
+}
+
+int vslam_batch_out_required(const vslam_params* p, int n_frames, vslam_batch_out* z) {
+    vslam_batch_layout L;
+    if (!z || n_frames <= 0 || vslam::make_layout(p, &L) != VSLAM_OK) return VSLAM_ERR_INVALID;
+    const size_t n = (size_t)n_frames, N = (size_t)p->rows * p->cols;
+    z->struct_size = sizeof(vslam_batch_out);
+    z->response_bytes = n * N * sizeof(float);
+    z->nms_mask_bytes = n * N;
+    z->nms2_bytes = n * N * sizeof(float);
+    z->harris_kps_bytes = n * p->harris_cap * sizeof(vslam_kp);
+    z->harris_counts_bytes = n * sizeof(uint32_t);
+    z->pyramid_bytes = n * L.pyramid_frame_bytes;
+    z->extrema_bits_bytes = n * L.bits_frame_words * sizeof(uint64_t);
+    z->dog_points_bytes = n * p->dog_cap * sizeof(vslam_point);
+    z->dog_counts_bytes = n * sizeof(uint32_t);
+    z->oriented_points_bytes = n * p->oriented_cap * sizeof(vslam_point);
+    z->oriented_counts_bytes = n * sizeof(uint32_t);
+    z->oriented_survivors_bytes = n * sizeof(uint32_t);
+    z->descriptors_bytes = n * p->oriented_cap * 128 * sizeof(float);
+    z->descriptor_defined_bytes = n * p->oriented_cap;
+    return VSLAM_OK;
 }
 
 int vslam_batch_layout_query(const vslam_params* p, vslam_batch_layout* out) { return vslam::make_layout(p, out); }
