@@ -404,6 +404,13 @@ int vslam_detect_batch_dev(vslam_ctx* ctx, const vslam_params* p, const uint8_t*
 int vslam_pack_lists_dev(vslam_ctx* ctx, const void* lists, size_t record_bytes, uint32_t cap, const uint32_t* counts,
                          int n_frames, void* packed, size_t packed_bytes, uint64_t* offsets);
 
+/* The sending side of the one collective of the multi-GPU path: totals[0] = sum of
+ * harris_counts[0..n_frames), totals[1] = the same for dog_counts (either list may be NULL -> 0), as two
+ * uint64 in DEVICE memory, asynchronous on the context stream - so that the rank's {harris, dog} pair
+ * can go into ncclAllGather on the same stream without a host round trip. */
+int vslam_count_totals_dev(vslam_ctx* ctx, const uint32_t* harris_counts, const uint32_t* dog_counts, int n_frames,
+                           uint64_t* totals);
+
 /* Timing hook for bench.py: when enabled, the context brackets every launch of the
  * named kernel with HIP events on its stream; vslam_kernel_timing_read synchronises and
  * returns launches and total milliseconds since the last reset. */

@@ -22,7 +22,7 @@ def built():
 
 
 def test_cxx_mirror_builds(built):
-    for exe in ("Harris", "DoG", "Pyramid_Test", "RotateImgTest"):
+    for exe in ("Harris", "DoG", "Pyramid_Test", "RotateImgTest", "Stream", "BatchDetector_Test"):
         assert os.access(os.path.join(built, exe), os.X_OK)
 
 
@@ -45,10 +45,10 @@ def _cmake_project(built, tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     r = subprocess.run(["cmake", "--build", b, "-j", "4"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    for exe in ("Harris", "DoG", "Pyramid_Test", "RotateImgTest"):
+    for exe in ("Harris", "DoG", "Pyramid_Test", "RotateImgTest", "Stream", "BatchDetector_Test"):
         assert os.access(os.path.join(b, exe), os.X_OK)
     r = subprocess.run(["ctest", "-N"], capture_output=True, text=True, timeout=120, cwd=b)
-    for name in ("Harris", "DoG", "Pyramid_Test", "RotateImgTest"):
+    for name in ("Harris", "DoG", "Pyramid_Test", "RotateImgTest", "Stream", "Stream_hostfed", "BatchDetector_Test"):
         assert ": " + name in r.stdout, r.stdout
     r = subprocess.run(["ctest", "-R", "RotateImgTest", "--output-on-failure"], capture_output=True, text=True, timeout=120, cwd=b)
     assert r.returncode == 0, r.stdout + r.stderr
@@ -153,3 +153,98 @@ def test_dog_executable_writes_the_reference_descriptor_file(built, tmp_path):
     body = np.frombuffer(raw[12:], "<f4").reshape(-1, 128)
     assert np.array_equal(body, want, equal_nan=True)
     assert got["descriptors"] == len(want) > 0 and got["undefined_windows"] == 0
+
+
+# ---- the C++ host of the throughput path: BatchDetector, Stream, RCCL count all-gather
+
+def _rank_env(rank, world, port):
+    return dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_stream_rendezvous_of_the_rccl_id_without_a_gpu(built, world):
+    # the N > 1 bootstrap of the RCCL communicator (rank 0's ncclUniqueId over TCP to every rank) on its own:
+    # `world` processes on the CPU, every rank must end up with rank 0's 128 bytes
+    port = 29840 + world
+    procs = [subprocess.Popen([os.path.join(built, "Stream"), "--rdv-selftest"], env=_rank_env(r, world, port), stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for r in reversed(range(world))]  # rank 0 last: the others must retry
+    outs = [p.communicate(timeout=120) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    got = [json.loads(o[0].strip().splitlines()[-1]) for o in outs]
+    assert sorted(g["rank"] for g in got) == list(range(world)) and all(g["world"] == world for g in got)
+    assert len({g["id_hash"] for g in got}) == 1
+
+
+def test_stream_rendezvous_times_out_loudly(built):
+    # a rank that never finds rank 0 fails with a message instead of hanging (60 s by default, shortened here)
+    env = dict(_rank_env(1, 2, 29870), VSLAM_RDV_PORT="1", VSLAM_RDV_TIMEOUT_MS="1500")  # nothing listens on port 1
+    p = subprocess.Popen([os.path.join(built, "Stream"), "--rdv-selftest"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    try:
+        out = p.communicate(timeout=100)
+    finally:
+        p.kill()
+    assert p.returncode == 1 and "could not reach rank 0" in out[1]
+
+
+@pytest.mark.gpu
+def test_batch_detector_test_passes(built):
+    r = subprocess.run([os.path.join(built, "BatchDetector_Test")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["failures"] == 0 and out["harris"] > 0 and out["dog"] > 0
+
+
+def _read_dump(path):
+    import numpy as np
+
+    from visualslam_amd import capi
+
+    raw = open(path, "rb").read()
+    magic, n, rows, cols = np.frombuffer(raw[:16], "<u4")
+    assert magic == 0x504B5356
+    off, frames = 16, []
+    for _ in range(n):
+        nh, nd, th, td = np.frombuffer(raw[off: off + 16], "<u4")
+        off += 16
+        kp = np.frombuffer(raw[off: off + 12 * nh], capi.KP_DTYPE)
+        off += 12 * nh
+        pt = np.frombuffer(raw[off: off + 24 * nd], capi.POINT_DTYPE)
+        off += 24 * nd
+        frames.append((kp, pt, int(th), int(td)))
+    assert off == len(raw)
+    return int(rows), int(cols), frames
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["device", "hostfed"])
+def test_stream_one_rank_over_rccl_matches_the_oracle(built, tmp_path, mode):
+    # the C++ host end to end: one process = one rank, RCCL communicator of one rank (ncclCommInitRank +
+    # ncclAllGather from librccl, no torch), BatchDetector driving vslam_detect_batch_dev; the per-frame lists
+    # of the last batch against the oracle on four frames of the camera stream (stream id = rank = 0)
+    import numpy as np
+
+    import oracle
+    from visualslam_amd import synth
+
+    rows, cols, n = 270, 480, 6
+    dump = tmp_path / "lists.bin"
+    r = subprocess.run([os.path.join(built, "Stream"), "--mode", mode, "--frames", str(n), "--batches", "4", "--warmup", "1", "--rows", str(rows),
+                        "--cols", str(cols), "--dump", str(dump)], capture_output=True, text=True, timeout=600, env=_rank_env(0, 1, 29890))
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["exe"] == "Stream" and line["mode"] == mode and line["n_gpus"] == 1 and line["frames_per_sec"] > 0
+    gr, gc, frames = _read_dump(dump)
+    assert (gr, gc, len(frames)) == (rows, cols, n)
+    tot_h = tot_d = 0
+    for f, (kp, pt, th, td) in enumerate(frames):
+        tot_h, tot_d = tot_h + th, tot_d + td
+        if f in (0, 1, 3, n - 1):
+            img = synth.frame_np(rows, cols, f, 0)
+            want_k = oracle.harris_keypoints(oracle.nms2(oracle.harris_response(img), 5)[0])
+            assert th == len(want_k) and kp.tobytes() == want_k.tobytes(), f
+            pyr = oracle.Pyramid(img, 4, 1.6)
+            want_p = np.concatenate([pyr.extrema(o, 3, 8)[1] for o in range(4)])
+            pyr.close()
+            assert td == len(want_p) and pt.tobytes() == want_p.tobytes(), f
+    # the all-gathered totals (one rank: its own) are the sums of the per-frame counts
+    assert line["keypoints_per_batch"] == {"harris": tot_h, "dog": tot_d} and line["rank0_counts"] == [tot_h, tot_d]

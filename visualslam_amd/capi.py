@@ -120,6 +120,7 @@ SIGNATURES = {
     "vslam_batch_out_required": (_I, [C.POINTER(Params), _I, C.POINTER(BatchOut)]),
     "vslam_detect_batch_dev": (_I, [_P, C.POINTER(Params), _P, _Z, _I, C.POINTER(BatchOut)]),
     "vslam_pack_lists_dev": (_I, [_P, _P, _Z, C.c_uint32, _P, _I, _P, _Z, _P]),
+    "vslam_count_totals_dev": (_I, [_P, _P, _P, _I, _P]),
     "vslam_kernel_timing_enable": (_I, [_P, C.c_char_p]),
     "vslam_kernel_timing_read": (_I, [_P, C.POINTER(_I), C.POINTER(_D)]),
     "vslam_kernel_names": (C.c_char_p, []),
@@ -473,6 +474,12 @@ class Context:
             raise ValueError("pack_lists: bad tensors")
         self._chk(lib().vslam_pack_lists_dev(self._h, lists.data_ptr(), rb, cap, counts.data_ptr(), n, packed.data_ptr(),
                                              packed.numel() * packed.element_size(), offsets.data_ptr()), "vslam_pack_lists_dev")
+
+    def count_totals(self, harris_counts, dog_counts, totals):
+        """vslam_count_totals_dev: int32 [n] count tensors (either may be None) -> totals int64 [2], on the context stream."""
+        n = (harris_counts if harris_counts is not None else dog_counts).numel()
+        self._chk(lib().vslam_count_totals_dev(self._h, harris_counts.data_ptr() if harris_counts is not None else None,
+                                               dog_counts.data_ptr() if dog_counts is not None else None, n, totals.data_ptr()), "vslam_count_totals_dev")
 
     def kernel_timing_enable(self, name: str | None):
         self._chk(lib().vslam_kernel_timing_enable(self._h, name.encode() if name else None), "vslam_kernel_timing_enable")

@@ -351,4 +351,25 @@ __global__ __launch_bounds__(256) void k_pack_copy(const unsigned int* __restric
         if (d0 + i < packed_dw) packed[d0 + i] = src[i];
 }
 
+// one block: totals[0] = sum of a[0..n), totals[1] = sum of b[0..n) (either may be null -> 0), 64-bit
+__global__ __launch_bounds__(256) void k_count_totals(const unsigned int* __restrict__ a, const unsigned int* __restrict__ b, int n,
+                                                       unsigned long long* __restrict__ totals) {
+    __shared__ unsigned long long sa[4], sb[4];
+    unsigned long long ta = 0, tb = 0;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        if (a) ta += a[i];
+        if (b) tb += b[i];
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+        ta += __shfl_down(ta, off);
+        tb += __shfl_down(tb, off);
+    }
+    if ((threadIdx.x & 63) == 0) sa[threadIdx.x >> 6] = ta, sb[threadIdx.x >> 6] = tb;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        totals[0] = sa[0] + sa[1] + sa[2] + sa[3];
+        totals[1] = sb[0] + sb[1] + sb[2] + sb[3];
+    }
+}
+
 }  // namespace vslam

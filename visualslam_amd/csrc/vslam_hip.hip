@@ -100,7 +100,7 @@ static const char* const kKernelNames =
     "k_resize_linear2x\nk_blur_h_generic\nk_blur_v_generic\n"
     "k_dog5\nk_resize_nearest_half\nk_extrema\nk_pyr_octave\n"
     "k_gauss_v_strip\nk_gauss_h_strip\nk_resize_linear2x_slide\nk_resize_nearest_half_v4\nk_extrema_w3\nk_extrema_dense\nk_localize_points\nk_orient_keypoints\nk_edge_response_windows\nk_level_gradients\nk_pack_rows\nk_edge_flags\nk_orient_survivors\n"
-    "k_harris_strip\nk_flag_count\nk_chunk_scan\nk_flag_scatter\nk_level_gradients\nk_sift_descriptors\nk_pack_offsets\nk_pack_copy";
+    "k_harris_strip\nk_flag_count\nk_chunk_scan\nk_flag_scatter\nk_level_gradients\nk_sift_descriptors\nk_pack_offsets\nk_pack_copy\nk_count_totals";
 
 static std::pair<hipEvent_t, hipEvent_t>* timing_slot(vslam_ctx* c);
 
@@ -1814,6 +1814,13 @@ int vslam_pack_lists_dev(vslam_ctx* c, const void* lists, size_t record_bytes, u
     if (packed_bytes >= 4)
         LAUNCH(c, "k_pack_copy", k_pack_copy, dim3(gx, 1, n_frames), dim3(256), (const unsigned int*)lists, rec_dw, cap, counts,
                (const unsigned long long*)offsets, (unsigned int*)packed, (unsigned long long)(packed_bytes / 4));
+    return VSLAM_OK;
+}
+
+int vslam_count_totals_dev(vslam_ctx* c, const uint32_t* harris_counts, const uint32_t* dog_counts, int n_frames, uint64_t* totals) {
+    TRY(bind_device(c));
+    ARGCHK(c, totals && n_frames > 0 && (harris_counts || dog_counts), "count_totals: bad arguments");
+    LAUNCH(c, "k_count_totals", k_count_totals, dim3(1), dim3(256), harris_counts, dog_counts, n_frames, (unsigned long long*)totals);
     return VSLAM_OK;
 }
 

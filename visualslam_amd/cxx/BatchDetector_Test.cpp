@@ -1,0 +1,141 @@
+// Headless, asserting test of the C++ throughput host (batch_detector.hpp) - registered with CTest like the
+// reference's target names.  Checks, all on the GPU through the C ABI:
+//   1. the host-fed pipeline (submit / collect, several batches in flight, packed lists) returns, frame by
+//      frame, exactly the lists the device-resident call leaves in HBM;
+//   2. those lists equal what the per-image API of vslam_cxx.hpp produces for the same frame
+//      (HarrisKeypoints; GaussPyramid + scaleSpaceCandidates per octave) - the drop-in functions and the
+//      batched path are the same detector;
+//   3. the C ABI refuses an undersized output buffer with VSLAM_ERR_INVALID before launching anything
+//      (include/vslam.h: vslam_batch_out carries buffer sizes), and a struct without struct_size.
+//   usage: BatchDetector_Test [WxH] [frames]
+#include <hip/hip_runtime_api.h>
+
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "batch_detector.hpp"
+#include "imgio.hpp"
+#include "vslam_cxx.hpp"
+
+static int failures = 0;
+#define EXPECT(cond)                                                          \
+    do {                                                                      \
+        if (!(cond)) {                                                        \
+            ++failures;                                                       \
+            std::fprintf(stderr, "FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); \
+        }                                                                     \
+    } while (0)
+
+int main(int argc, char** argv) {
+    try {
+        int cols = 480, rows = 270, n = 6;
+        if (argc > 1) std::sscanf(argv[1], "%dx%d", &cols, &rows);
+        if (argc > 2) n = std::atoi(argv[2]);
+        const size_t N = (size_t)rows * cols;
+        uint8_t* h_frames = (uint8_t*)vslam::BatchDetector::alloc_pinned((size_t)n * N);
+        std::vector<cv::Mat> imgs;
+        for (int f = 0; f < n; ++f) {
+            imgs.push_back(imgio::synthetic(rows, cols, f, 5));
+            std::memcpy(h_frames + (size_t)f * N, imgs.back().data, N);
+        }
+        vslam::BatchDetector::Options opt;
+        opt.rows = rows, opt.cols = cols, opt.batch = n, opt.slots = 3;
+        vslam::BatchDetector det(opt);
+        const vslam_params& p = det.params();
+
+        // ---- 1. host-fed: five batches through three slots, every result identical
+        std::vector<vslam_kp> kp0;
+        std::vector<vslam_point> pt0;
+        std::vector<uint64_t> hoff, doff;
+        int submitted = 0, collected = 0;
+        const int total = 5;
+        for (; submitted < 3; ++submitted) det.submit(h_frames, n);
+        while (collected < total) {
+            const vslam::BatchResult& r = det.collect();
+            EXPECT(r.n_frames == n && !r.truncated);
+            if (collected == 0) {
+                kp0.assign(r.harris, r.harris + r.harris_records);
+                pt0.assign(r.dog, r.dog + r.dog_records);
+                hoff.assign(r.harris_offsets, r.harris_offsets + n + 1);
+                doff.assign(r.dog_offsets, r.dog_offsets + n + 1);
+                EXPECT(r.harris_records == hoff[n] && r.dog_records == doff[n]);
+            } else {
+                EXPECT(r.harris_records == kp0.size() && r.dog_records == pt0.size());
+                EXPECT(std::memcmp(r.harris, kp0.data(), kp0.size() * sizeof(vslam_kp)) == 0);
+                EXPECT(std::memcmp(r.dog, pt0.data(), pt0.size() * sizeof(vslam_point)) == 0);
+                EXPECT(std::memcmp(r.harris_offsets, hoff.data(), (n + 1) * 8) == 0 && std::memcmp(r.dog_offsets, doff.data(), (n + 1) * 8) == 0);
+            }
+            ++collected;
+            if (submitted < total) det.submit(h_frames, n), ++submitted;
+        }
+        EXPECT(det.in_flight() == 0);
+        bool threw = false;
+        try {
+            det.collect();
+        } catch (const vslam::Error&) {
+            threw = true;
+        }
+        EXPECT(threw);
+
+        // ---- device-resident call on the same frames: lists in HBM equal the host-fed ones
+        uint8_t* d_frames = nullptr;
+        EXPECT(hipMalloc((void**)&d_frames, (size_t)n * N) == hipSuccess);
+        EXPECT(hipMemcpy(d_frames, h_frames, (size_t)n * N, hipMemcpyHostToDevice) == hipSuccess);
+        det.detect_device(d_frames, N, n);
+        det.sync();
+        const vslam_batch_out& o = det.device_outputs();
+        std::vector<uint32_t> hc(n), dc(n);
+        EXPECT(hipMemcpy(hc.data(), o.harris_counts, 4 * n, hipMemcpyDeviceToHost) == hipSuccess);
+        EXPECT(hipMemcpy(dc.data(), o.dog_counts, 4 * n, hipMemcpyDeviceToHost) == hipSuccess);
+        uint64_t tot[2] = {0, 0}, sum[2] = {0, 0};
+        EXPECT(hipMemcpy(tot, det.device_totals(), 16, hipMemcpyDeviceToHost) == hipSuccess);
+        for (int f = 0; f < n; ++f) {
+            sum[0] += hc[f], sum[1] += dc[f];
+            EXPECT(hc[f] == hoff[f + 1] - hoff[f] && dc[f] == doff[f + 1] - doff[f]);
+            std::vector<vslam_kp> k(hc[f]);
+            std::vector<vslam_point> q(dc[f]);
+            if (hc[f]) EXPECT(hipMemcpy(k.data(), o.harris_kps + (size_t)f * p.harris_cap, hc[f] * sizeof(vslam_kp), hipMemcpyDeviceToHost) == hipSuccess);
+            if (dc[f]) EXPECT(hipMemcpy(q.data(), o.dog_points + (size_t)f * p.dog_cap, dc[f] * sizeof(vslam_point), hipMemcpyDeviceToHost) == hipSuccess);
+            EXPECT(std::memcmp(k.data(), kp0.data() + hoff[f], k.size() * sizeof(vslam_kp)) == 0);
+            EXPECT(std::memcmp(q.data(), pt0.data() + doff[f], q.size() * sizeof(vslam_point)) == 0);
+        }
+        EXPECT(tot[0] == sum[0] && tot[1] == sum[1] && sum[0] > 0 && sum[1] > 0);
+
+        // ---- 2. the per-image drop-in functions give the same lists (frames 0 and n-1)
+        for (int f : {0, n - 1}) {
+            const std::vector<vslam_kp> kps = HarrisKeypoints(imgs[f], 0.04f);
+            EXPECT(kps.size() == hoff[f + 1] - hoff[f]);
+            EXPECT(kps.empty() || std::memcmp(kps.data(), kp0.data() + hoff[f], kps.size() * sizeof(vslam_kp)) == 0);
+            GaussPyramid pyramid{imgs[f], p.n_octaves, p.sigma0};
+            std::vector<SLAM::point> cand;
+            for (int oc = 0; oc < pyramid.getNumOctaves(); ++oc) scaleSpaceCandidates(cand, pyramid, oc, p.extrema_window, p.min_contrast);
+            EXPECT(cand.size() == doff[f + 1] - doff[f]);
+            EXPECT(cand.empty() || std::memcmp(cand.data(), pt0.data() + doff[f], cand.size() * sizeof(vslam_point)) == 0);
+        }
+
+        // ---- 3. undersized buffers are refused by the C ABI itself
+        vslam_batch_out bad = o;
+        bad.pyramid_bytes -= 1;
+        int rc = vslam_detect_batch_dev(det.context(), &p, d_frames, N, n, &bad);
+        EXPECT(rc == VSLAM_ERR_INVALID && std::strstr(vslam_last_error(det.context()), "pyramid") != nullptr);
+        bad = o;
+        bad.dog_points_bytes = (size_t)n * p.dog_cap * sizeof(vslam_point) - sizeof(vslam_point);
+        EXPECT(vslam_detect_batch_dev(det.context(), &p, d_frames, N, n, &bad) == VSLAM_ERR_INVALID);
+        bad = o;
+        bad.struct_size = 0;
+        EXPECT(vslam_detect_batch_dev(det.context(), &p, d_frames, N, n, &bad) == VSLAM_ERR_INVALID);
+        bad = o;  // a larger buffer than needed is fine
+        bad.pyramid_bytes += 4096;
+        EXPECT(vslam_detect_batch_dev(det.context(), &p, d_frames, N, n, &bad) == VSLAM_OK);
+        det.sync();
+        (void)hipFree(d_frames);
+        vslam::BatchDetector::free_pinned(h_frames);
+        std::printf("{\"exe\": \"BatchDetector_Test\", \"rows\": %d, \"cols\": %d, \"frames\": %d, \"harris\": %llu, \"dog\": %llu, \"failures\": %d}\n", rows, cols,
+                    n, (unsigned long long)sum[0], (unsigned long long)sum[1], failures);
+        return failures ? 2 : 0;
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "BatchDetector_Test: %s\n", e.what());
+        return EXIT_FAILURE;
+    }
+}

@@ -1,0 +1,261 @@
+// Headless camera-stream driver of the throughput path: ONE PROCESS PER GPU, one camera stream per process
+// (BASELINE configs 4 and 5).  It is to the batched path what `Harris` / `DoG` are to the reference's
+// per-image main()s (Harris_corners.cpp:146-193, Diff_of_Gauss.cpp:727-877): the same detection, fed
+// with batches of frames instead of one imread(), with the display replaced by one JSON line.
+//
+//   Stream [--mode device|hostfed] [--frames 256] [--batches 8] [--warmup 2] [--rows 1080 --cols 1920]
+//          [--octaves 4] [--source synth|<file of raw 8-bit frames>] [--dump <file>] [--rdv-selftest]
+//
+//   device   frames are uploaded once and stay in HBM; every step = BatchDetector::detect_device +
+//            the RCCL all-gather of the {harris, dog} counts on the same stream (what bench.py times);
+//   hostfed  every batch starts in pinned host memory and its keypoint lists end there, uploads /
+//            kernels / downloads of consecutive batches overlapped (BatchDetector::submit / collect);
+//            the all-gather runs once per batch on the host-side totals.
+//
+// Ranks: RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT as torchrun sets them (or by hand:
+// `for r in 0 1 ..; do RANK=$r WORLD_SIZE=N LOCAL_RANK=$r ./Stream & done`); the GPU is LOCAL_RANK, the
+// camera stream id is RANK.  Counts cross ranks with ncclAllGather from librccl (count_exchange.hpp) -
+// no torch, no MPI.  Timing follows the bench contract: barrier, K steps, barrier, max over ranks.
+// --dump writes the keypoint lists of the last batch (hostfed: as collected; device: downloaded after the
+// run) for the parity test: u32 {magic 'VSKP', n_frames, rows, cols}, then per frame u32 {n_harris, n_dog,
+// harris_total, dog_total} + n_harris vslam_kp + n_dog vslam_point.
+#include <hip/hip_runtime_api.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "batch_detector.hpp"
+#include "count_exchange.hpp"
+#include "imgio.hpp"
+#include "vslam_cxx.hpp"
+
+namespace {
+
+struct Args {
+    std::string mode = "device", source = "synth", dump;
+    int frames = 256, batches = 8, warmup = 2, rows = 1080, cols = 1920, octaves = 4;
+    bool rdv_selftest = false;
+};
+
+Args parse(int argc, char** argv) {
+    Args a;
+    for (int i = 1; i < argc; ++i) {
+        const std::string k = argv[i];
+        auto val = [&]() -> std::string {
+            if (i + 1 >= argc) throw std::runtime_error("missing value after " + k);
+            return argv[++i];
+        };
+        if (k == "--mode") a.mode = val();
+        else if (k == "--frames") a.frames = std::stoi(val());
+        else if (k == "--batches") a.batches = std::stoi(val());
+        else if (k == "--warmup") a.warmup = std::stoi(val());
+        else if (k == "--rows") a.rows = std::stoi(val());
+        else if (k == "--cols") a.cols = std::stoi(val());
+        else if (k == "--octaves") a.octaves = std::stoi(val());
+        else if (k == "--source") a.source = val();
+        else if (k == "--dump") a.dump = val();
+        else if (k == "--rdv-selftest") a.rdv_selftest = true;
+        else throw std::runtime_error("unknown argument " + k);
+    }
+    if ((a.mode != "device" && a.mode != "hostfed") || a.frames <= 0 || a.batches <= 0 || a.warmup < 0 || a.rows <= 0 || a.cols <= 0 || a.octaves < 0)
+        throw std::runtime_error("bad arguments");
+    return a;
+}
+
+// n frames of the camera stream `stream_id` starting at frame `first` into dst (dense rows): the synthetic
+// generator of SURVEY.md section 8d (imgio::synthetic, identical to visualslam_amd/synth.py), or a file of
+// raw 8-bit frames read cyclically.
+void fill_frames(const Args& a, int stream_id, int first, int n, uint8_t* dst) {
+    const size_t N = (size_t)a.rows * a.cols;
+    if (a.source == "synth") {
+        const int nt = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+        std::vector<std::thread> th;
+        for (int t = 0; t < nt; ++t)
+            th.emplace_back([&, t] {
+                for (int f = t; f < n; f += nt) {
+                    const cv::Mat m = imgio::synthetic(a.rows, a.cols, first + f, stream_id);
+                    std::memcpy(dst + (size_t)f * N, m.data, N);
+                }
+            });
+        for (auto& t : th) t.join();
+        return;
+    }
+    FILE* fp = std::fopen(a.source.c_str(), "rb");
+    if (!fp) throw std::runtime_error("cannot open " + a.source);
+    std::fseek(fp, 0, SEEK_END);
+    const long total = std::ftell(fp) / (long)N;
+    if (total <= 0) {
+        std::fclose(fp);
+        throw std::runtime_error(a.source + ": shorter than one frame");
+    }
+    for (int f = 0; f < n; ++f) {
+        std::fseek(fp, (long)(((long)first + f) % total) * (long)N, SEEK_SET);
+        if (std::fread(dst + (size_t)f * N, 1, N, fp) != N) {
+            std::fclose(fp);
+            throw std::runtime_error(a.source + ": read error");
+        }
+    }
+    std::fclose(fp);
+}
+
+void dump_lists(const std::string& path, int rows, int cols, const vslam::BatchResult& r) {
+    FILE* fp = std::fopen(path.c_str(), "wb");
+    if (!fp) throw std::runtime_error("cannot write " + path);
+    const uint32_t head[4] = {0x504b5356u, (uint32_t)r.n_frames, (uint32_t)rows, (uint32_t)cols};
+    std::fwrite(head, 4, 4, fp);
+    for (int f = 0; f < r.n_frames; ++f) {
+        const vslam::FrameKeypoints k = r.frame(f);
+        const uint32_t h[4] = {(uint32_t)k.n_harris, (uint32_t)k.n_dog, k.harris_total, k.dog_total};
+        std::fwrite(h, 4, 4, fp);
+        std::fwrite(k.harris, sizeof(vslam_kp), k.n_harris, fp);
+        std::fwrite(k.dog, sizeof(vslam_point), k.n_dog, fp);
+    }
+    std::fclose(fp);
+}
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    try {
+        const Args a = parse(argc, argv);
+        const vslam::RankEnv env = vslam::RankEnv::from_environment();
+        if (a.rdv_selftest) {  // the TCP hand-off of the RCCL id alone (no GPU): rank 0's bytes must reach every rank
+            unsigned char id[128];
+            for (int i = 0; i < 128; ++i) id[i] = env.rank == 0 ? (unsigned char)(i * 7 + 3) : 0;
+            vslam::tcp_broadcast_from_rank0(env, id, sizeof(id));
+            unsigned sum = 0;
+            for (int i = 0; i < 128; ++i) sum = sum * 31 + id[i];
+            std::printf("{\"exe\": \"Stream\", \"rdv_selftest\": true, \"rank\": %d, \"world\": %d, \"id_hash\": %u}\n", env.rank, env.world, sum);
+            return 0;
+        }
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) throw std::runtime_error("no HIP device: the product has no CPU fallback");
+        const int device = env.local_rank % ndev;
+        const size_t N = (size_t)a.rows * a.cols;
+        const bool hostfed = a.mode == "hostfed";
+
+        vslam::BatchDetector::Options opt;
+        opt.device = device;
+        opt.rows = a.rows, opt.cols = a.cols, opt.batch = a.frames;
+        opt.host_fed = hostfed;
+        if (a.octaves != 4) {
+            opt.custom_params = true;
+            vslam_params_default(&opt.params, a.rows, a.cols);
+            opt.params.n_octaves = a.octaves;
+        }
+        vslam::BatchDetector det(opt);
+        vslam::CountExchange ex(env, device);  // RCCL communicator over all ranks (collective)
+        const hipStream_t cs = (hipStream_t)det.stream();
+
+        // the camera stream: stream_id = rank.  One batch of frames in pinned host memory.
+        uint8_t* h_frames = (uint8_t*)vslam::BatchDetector::alloc_pinned((size_t)a.frames * N);
+        fill_frames(a, env.rank, 0, a.frames, h_frames);
+
+        uint64_t kp_local[2] = {0, 0};
+        std::vector<uint64_t> all;
+        double dt = 0;
+        const vslam::BatchResult* last = nullptr;
+        vslam::BatchResult dev_last;
+        std::vector<uint64_t> dl_off;
+        std::vector<uint32_t> dl_cnt;
+        std::vector<vslam_kp> dl_h;
+        std::vector<vslam_point> dl_p;
+        if (!hostfed) {
+            uint8_t* d_frames = nullptr;
+            if (hipMalloc((void**)&d_frames, (size_t)a.frames * N) != hipSuccess) throw std::runtime_error("hipMalloc(frames)");
+            if (hipMemcpy(d_frames, h_frames, (size_t)a.frames * N, hipMemcpyHostToDevice) != hipSuccess) throw std::runtime_error("upload");
+            auto step = [&] {
+                det.detect_device(d_frames, N, a.frames);
+                ex.all_gather_async(det.device_totals(), cs);  // 16 bytes per rank, same stream: no host round trip
+            };
+            for (int i = 0; i < a.warmup; ++i) step();
+            ex.barrier(cs);
+            const double t0 = now_s();
+            for (int i = 0; i < a.batches; ++i) step();
+            det.sync();
+            ex.barrier(cs);
+            dt = now_s() - t0;
+            all = ex.fetch(cs);
+            kp_local[0] = all[2 * env.rank], kp_local[1] = all[2 * env.rank + 1];
+            if (!a.dump.empty()) {  // download the lists of the last batch for the parity check (not timed)
+                const vslam_batch_out& o = det.device_outputs();
+                const vslam_params& p = det.params();
+                dl_off.assign(2 * (a.frames + 1), 0);
+                dl_cnt.assign(2 * a.frames, 0);
+                if (o.harris_counts) (void)hipMemcpy(dl_cnt.data(), o.harris_counts, 4 * a.frames, hipMemcpyDeviceToHost);
+                if (o.dog_counts) (void)hipMemcpy(dl_cnt.data() + a.frames, o.dog_counts, 4 * a.frames, hipMemcpyDeviceToHost);
+                for (int f = 0; f < a.frames; ++f) {
+                    dl_off[f + 1] = dl_off[f] + std::min<uint32_t>(dl_cnt[f], p.harris_cap);
+                    dl_off[a.frames + 1 + f + 1] = dl_off[a.frames + 1 + f] + std::min<uint32_t>(dl_cnt[a.frames + f], p.dog_cap);
+                }
+                dl_h.resize(dl_off[a.frames]);
+                dl_p.resize(dl_off[2 * a.frames + 1]);
+                for (int f = 0; f < a.frames; ++f) {
+                    const size_t nh = dl_off[f + 1] - dl_off[f], np = dl_off[a.frames + 2 + f] - dl_off[a.frames + 1 + f];
+                    if (nh) (void)hipMemcpy(dl_h.data() + dl_off[f], o.harris_kps + (size_t)f * p.harris_cap, nh * sizeof(vslam_kp), hipMemcpyDeviceToHost);
+                    if (np) (void)hipMemcpy(dl_p.data() + dl_off[a.frames + 1 + f], o.dog_points + (size_t)f * p.dog_cap, np * sizeof(vslam_point), hipMemcpyDeviceToHost);
+                }
+                dev_last.n_frames = a.frames;
+                dev_last.harris_offsets = dl_off.data(), dev_last.dog_offsets = dl_off.data() + a.frames + 1;
+                dev_last.harris_counts = dl_cnt.data(), dev_last.dog_counts = dl_cnt.data() + a.frames;
+                dev_last.harris = dl_h.data(), dev_last.dog = dl_p.data();
+                dev_last.harris_records = dl_h.size(), dev_last.dog_records = dl_p.size();
+                last = &dev_last;
+            }
+            (void)hipFree(d_frames);
+        } else {
+            uint64_t* d_tot = nullptr;  // host-side totals go through the same RCCL all-gather, once per batch
+            if (hipMalloc((void**)&d_tot, 16) != hipSuccess) throw std::runtime_error("hipMalloc");
+            const int depth = std::max(1, opt.slots);
+            bool truncated = false;
+            auto run = [&](int nb) {
+                int sub = 0;
+                for (; sub < std::min(depth, nb); ++sub) det.submit(h_frames, a.frames);
+                for (int k = 0; k < nb; ++k) {
+                    const vslam::BatchResult& r = det.collect();
+                    truncated |= r.truncated;
+                    if (sub < nb) det.submit(h_frames, a.frames), ++sub;
+                    kp_local[0] = kp_local[1] = 0;
+                    for (int f = 0; f < r.n_frames; ++f) kp_local[0] += r.harris_counts[f], kp_local[1] += r.dog_counts[f];
+                    (void)hipMemcpyAsync(d_tot, kp_local, 16, hipMemcpyHostToDevice, cs);
+                    ex.all_gather_async(d_tot, cs);
+                    last = &r;
+                }
+            };
+            if (a.warmup) run(a.warmup);
+            ex.barrier(cs);
+            const double t0 = now_s();
+            run(a.batches);
+            det.sync();
+            ex.barrier(cs);
+            dt = now_s() - t0;
+            all = ex.fetch(cs);
+            (void)hipFree(d_tot);
+            if (truncated) std::fprintf(stderr, "Stream: rank %d: lists truncated (raise the caps or the host budget)\n", env.rank);
+        }
+        const double dt_max = ex.max_over_ranks(dt, cs);
+        if (!a.dump.empty() && last) dump_lists(a.dump, a.rows, a.cols, *last);
+        uint64_t gh = 0, gd = 0;
+        for (int r = 0; r < env.world; ++r) gh += all[2 * r], gd += all[2 * r + 1];
+        if (env.rank == 0) {
+            const double fps = (double)a.frames * a.batches * env.world / dt_max;
+            std::printf("{\"exe\": \"Stream\", \"host\": \"C++ (BatchDetector) + RCCL ncclAllGather\", \"mode\": \"%s\", \"n_gpus\": %d, \"frames_per_batch\": %d, "
+                        "\"batches\": %d, \"warmup\": %d, \"rows\": %d, \"cols\": %d, \"octaves\": %d, \"frames_per_sec\": %.2f, \"ms_per_batch\": %.4f, "
+                        "\"keypoints_per_batch\": {\"harris\": %llu, \"dog\": %llu}, \"keypoints_per_sec\": %.1f, \"rank0_counts\": [%llu, %llu]}\n",
+                        a.mode.c_str(), env.world, a.frames, a.batches, a.warmup, a.rows, a.cols, det.params().n_octaves, fps, dt_max / a.batches * 1e3,
+                        (unsigned long long)gh, (unsigned long long)gd, (double)(gh + gd) * a.batches / dt_max, (unsigned long long)all[0],
+                        (unsigned long long)all[1]);
+        }
+        vslam::BatchDetector::free_pinned(h_frames);
+        return 0;
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "Stream: %s\n", e.what());
+        return EXIT_FAILURE;
+    }
+}

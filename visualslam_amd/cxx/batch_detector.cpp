@@ -1,0 +1,225 @@
+#include "batch_detector.hpp"
+
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cstring>
+#include <string>
+
+#include "vslam_cxx.hpp"
+
+namespace vslam {
+
+namespace {
+void hip_check(hipError_t e, const char* what) {
+    if (e != hipSuccess)
+        throw Error(e == hipErrorOutOfMemory ? VSLAM_ERR_NOMEM : VSLAM_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIPX(expr) hip_check((expr), #expr)
+}  // namespace
+
+FrameKeypoints BatchResult::frame(int f) const {
+    if (f < 0 || f >= n_frames) throw Error(VSLAM_ERR_RANGE, "BatchResult::frame: index out of range");
+    FrameKeypoints k;
+    // records beyond the host budget are missing from the END of the packed list: clip every frame to it
+    const uint64_t h0 = std::min(harris_offsets[f], harris_records), h1 = std::min(harris_offsets[f + 1], harris_records);
+    const uint64_t d0 = std::min(dog_offsets[f], dog_records), d1 = std::min(dog_offsets[f + 1], dog_records);
+    k.harris = harris + h0;
+    k.n_harris = (size_t)(h1 - h0);
+    k.dog = dog + d0;
+    k.n_dog = (size_t)(d1 - d0);
+    k.harris_total = harris_counts[f];
+    k.dog_total = dog_counts[f];
+    return k;
+}
+
+void* BatchDetector::alloc_pinned(size_t bytes) {
+    void* p = nullptr;
+    HIPX(hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault));
+    return p;
+}
+void BatchDetector::free_pinned(void* p) {
+    if (p) (void)hipHostFree(p);
+}
+
+BatchDetector::BatchDetector(const Options& opt) : opt_(opt) {
+    if (opt.batch <= 0 || opt.rows <= 0 || opt.cols <= 0 || opt.slots < 1) throw Error(VSLAM_ERR_INVALID, "BatchDetector: bad options");
+    if (opt.custom_params)
+        p_ = opt.params;
+    else
+        vslam_params_default(&p_, opt.rows, opt.cols);
+    p_.rows = opt.rows;
+    p_.cols = opt.cols;
+    int rc = vslam_batch_layout_query(&p_, &L_);
+    if (rc != VSLAM_OK) throw Error(rc, "BatchDetector: vslam_batch_layout_query rejected the parameters");
+    HIPX(hipSetDevice(opt.device));
+    hipStream_t cs, us, ds;
+    HIPX(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+    HIPX(hipStreamCreateWithFlags(&us, hipStreamNonBlocking));
+    HIPX(hipStreamCreateWithFlags(&ds, hipStreamNonBlocking));
+    compute_ = cs, up_ = us, down_ = ds;
+    rc = vslam_ctx_create(opt.device, compute_, &ctx_);
+    if (rc != VSLAM_OK) throw Error(rc, std::string("vslam_ctx_create: ") + vslam_status_string(rc) + " (no usable HIP device: there is no CPU fallback)");
+
+    vslam_batch_out need{};
+    check(vslam_batch_out_required(&p_, opt.batch, &need), ctx_, "vslam_batch_out_required");
+    auto dmalloc = [&](size_t bytes) {
+        void* p = nullptr;
+        HIPX(hipMalloc(&p, bytes ? bytes : 256));
+        dev_allocs_.push_back(p);
+        return p;
+    };
+    auto pinned = [&](size_t bytes) {
+        void* p = alloc_pinned(bytes);
+        pinned_allocs_.push_back(p);
+        return p;
+    };
+    // image outputs: one set, shared by all slots (the kernels of consecutive batches are ordered on one stream)
+    vslam_batch_out img{};
+    img.struct_size = sizeof(vslam_batch_out);
+    const bool dog = p_.n_octaves > 0;
+    if (p_.do_harris) {
+        img.response = (float*)dmalloc(need.response_bytes), img.response_bytes = need.response_bytes;
+        img.nms_mask = (uint8_t*)dmalloc(need.nms_mask_bytes), img.nms_mask_bytes = need.nms_mask_bytes;
+    }
+    if (dog) {
+        img.pyramid = (uint8_t*)dmalloc(need.pyramid_bytes), img.pyramid_bytes = need.pyramid_bytes;
+        img.extrema_bits = (uint64_t*)dmalloc(need.extrema_bits_bytes), img.extrema_bits_bytes = need.extrema_bits_bytes;
+    }
+    d_totals_ = (uint64_t*)dmalloc(2 * sizeof(uint64_t));
+    HIPX(hipMemset(d_totals_, 0, 2 * sizeof(uint64_t)));
+    const int nslots = opt.host_fed ? opt.slots : 1;
+    const size_t n = (size_t)opt.batch;
+    packed_cap_h_ = std::min<size_t>(n * p_.harris_cap, n * opt.host_records_per_frame);
+    packed_cap_p_ = std::min<size_t>(n * p_.dog_cap, n * opt.host_records_per_frame);
+    slots_.resize(nslots);
+    for (Slot& s : slots_) {
+        s.out = img;
+        if (p_.do_harris) {
+            s.out.harris_kps = (vslam_kp*)dmalloc(need.harris_kps_bytes), s.out.harris_kps_bytes = need.harris_kps_bytes;
+            s.out.harris_counts = (uint32_t*)dmalloc(need.harris_counts_bytes), s.out.harris_counts_bytes = need.harris_counts_bytes;
+            HIPX(hipMemset(s.out.harris_counts, 0, need.harris_counts_bytes));
+        }
+        if (dog) {
+            s.out.dog_points = (vslam_point*)dmalloc(need.dog_points_bytes), s.out.dog_points_bytes = need.dog_points_bytes;
+            s.out.dog_counts = (uint32_t*)dmalloc(need.dog_counts_bytes), s.out.dog_counts_bytes = need.dog_counts_bytes;
+            HIPX(hipMemset(s.out.dog_counts, 0, need.dog_counts_bytes));
+        }
+        hipEvent_t e;
+        HIPX(hipEventCreateWithFlags(&e, hipEventDisableTiming)), s.up_done = e;
+        HIPX(hipEventCreateWithFlags(&e, hipEventDisableTiming)), s.comp_done = e;
+        HIPX(hipEventCreateWithFlags(&e, hipEventDisableTiming)), s.down_done = e;
+        if (!opt.host_fed) continue;
+        s.d_frames = (uint8_t*)dmalloc(n * (size_t)p_.rows * p_.cols);
+        s.d_hpacked = (vslam_kp*)dmalloc(packed_cap_h_ * sizeof(vslam_kp));
+        s.d_ppacked = (vslam_point*)dmalloc(packed_cap_p_ * sizeof(vslam_point));
+        s.d_off = (uint64_t*)dmalloc(2 * (n + 1) * sizeof(uint64_t));
+        HIPX(hipMemset(s.d_off, 0, 2 * (n + 1) * sizeof(uint64_t)));
+        s.h_off = (uint64_t*)pinned(2 * (n + 1) * sizeof(uint64_t));
+        s.h_cnt = (uint32_t*)pinned(2 * n * sizeof(uint32_t));
+        std::memset(s.h_off, 0, 2 * (n + 1) * sizeof(uint64_t));
+        std::memset(s.h_cnt, 0, 2 * n * sizeof(uint32_t));
+        s.h_hpacked = (vslam_kp*)pinned(packed_cap_h_ * sizeof(vslam_kp));
+        s.h_ppacked = (vslam_point*)pinned(packed_cap_p_ * sizeof(vslam_point));
+    }
+    HIPX(hipDeviceSynchronize());
+}
+
+BatchDetector::~BatchDetector() {
+    (void)hipSetDevice(opt_.device);
+    (void)hipDeviceSynchronize();
+    if (ctx_) (void)vslam_ctx_destroy(ctx_);
+    for (Slot& s : slots_)
+        for (void* e : {s.up_done, s.comp_done, s.down_done})
+            if (e) (void)hipEventDestroy((hipEvent_t)e);
+    for (void* p : dev_allocs_) (void)hipFree(p);
+    for (void* p : pinned_allocs_) (void)hipHostFree(p);
+    for (void* s : {up_, down_, compute_})
+        if (s) (void)hipStreamDestroy((hipStream_t)s);
+}
+
+void BatchDetector::sync() {
+    HIPX(hipSetDevice(opt_.device));
+    HIPX(hipStreamSynchronize((hipStream_t)compute_));
+}
+
+void BatchDetector::run_on_slot(Slot& s, const uint8_t* d_frames, size_t stride, int n) {
+    check(vslam_detect_batch_dev(ctx_, &p_, d_frames, stride, n, &s.out), ctx_, "vslam_detect_batch_dev");
+    s.n = n;
+}
+
+void BatchDetector::detect_device(const uint8_t* d_frames, size_t frame_stride, int n) {
+    if (n <= 0 || n > opt_.batch) throw Error(VSLAM_ERR_INVALID, "BatchDetector::detect_device: n outside 1..batch");
+    HIPX(hipSetDevice(opt_.device));
+    Slot& s = slots_[0];
+    run_on_slot(s, d_frames, frame_stride, n);
+    check(vslam_count_totals_dev(ctx_, s.out.harris_counts, s.out.dog_counts, n, d_totals_), ctx_, "vslam_count_totals_dev");
+}
+
+void BatchDetector::submit(const uint8_t* host_frames, int n) {
+    if (!opt_.host_fed) throw Error(VSLAM_ERR_INVALID, "BatchDetector::submit: constructed with host_fed = false");
+    if (!host_frames || n <= 0 || n > opt_.batch) throw Error(VSLAM_ERR_INVALID, "BatchDetector::submit: bad arguments");
+    if (in_flight() >= (int)slots_.size()) throw Error(VSLAM_ERR_INVALID, "BatchDetector::submit: every slot is in flight - collect() first");
+    HIPX(hipSetDevice(opt_.device));
+    Slot& s = slots_[submitted_ % slots_.size()];
+    const hipStream_t up = (hipStream_t)up_, cs = (hipStream_t)compute_;
+    const size_t N = (size_t)p_.rows * p_.cols;
+    // the slot's frame buffer is free once the kernels of its previous batch have run (comp_done), its list
+    // buffers once that batch's lists have been downloaded (down_done; collect() has waited for it already)
+    HIPX(hipStreamWaitEvent(up, (hipEvent_t)s.comp_done, 0));
+    HIPX(hipMemcpyAsync(s.d_frames, host_frames, (size_t)n * N, hipMemcpyHostToDevice, up));
+    HIPX(hipEventRecord((hipEvent_t)s.up_done, up));
+    HIPX(hipStreamWaitEvent(cs, (hipEvent_t)s.up_done, 0));
+    HIPX(hipStreamWaitEvent(cs, (hipEvent_t)s.down_done, 0));
+    run_on_slot(s, s.d_frames, N, n);
+    const size_t nb = (size_t)opt_.batch;
+    if (s.out.harris_kps)
+        check(vslam_pack_lists_dev(ctx_, s.out.harris_kps, sizeof(vslam_kp), p_.harris_cap, s.out.harris_counts, n, s.d_hpacked,
+                                   packed_cap_h_ * sizeof(vslam_kp), s.d_off),
+              ctx_, "vslam_pack_lists_dev (harris)");
+    if (s.out.dog_points)
+        check(vslam_pack_lists_dev(ctx_, s.out.dog_points, sizeof(vslam_point), p_.dog_cap, s.out.dog_counts, n, s.d_ppacked,
+                                   packed_cap_p_ * sizeof(vslam_point), s.d_off + (nb + 1)),
+              ctx_, "vslam_pack_lists_dev (dog)");
+    // the small things travel on the compute stream right behind the kernels: offsets and true counts
+    HIPX(hipMemcpyAsync(s.h_off, s.d_off, 2 * (nb + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, cs));
+    if (s.out.harris_counts) HIPX(hipMemcpyAsync(s.h_cnt, s.out.harris_counts, (size_t)n * 4, hipMemcpyDeviceToHost, cs));
+    if (s.out.dog_counts) HIPX(hipMemcpyAsync(s.h_cnt + nb, s.out.dog_counts, (size_t)n * 4, hipMemcpyDeviceToHost, cs));
+    HIPX(hipEventRecord((hipEvent_t)s.comp_done, cs));
+    ++submitted_;
+}
+
+const BatchResult& BatchDetector::collect() {
+    if (in_flight() <= 0) throw Error(VSLAM_ERR_INVALID, "BatchDetector::collect: nothing in flight");
+    HIPX(hipSetDevice(opt_.device));
+    Slot& s = slots_[collected_ % slots_.size()];
+    const hipStream_t ds = (hipStream_t)down_;
+    const size_t nb = (size_t)opt_.batch;
+    HIPX(hipEventSynchronize((hipEvent_t)s.comp_done));  // offsets and counts are on the host now
+    BatchResult& r = s.res;
+    r = BatchResult{};
+    r.n_frames = s.n;
+    r.harris_offsets = s.h_off;
+    r.dog_offsets = s.h_off + (nb + 1);
+    r.harris_counts = s.h_cnt;
+    r.dog_counts = s.h_cnt + nb;
+    r.harris = s.h_hpacked;
+    r.dog = s.h_ppacked;
+    const uint64_t th = s.out.harris_kps ? r.harris_offsets[s.n] : 0, tp = s.out.dog_points ? r.dog_offsets[s.n] : 0;
+    r.harris_records = std::min<uint64_t>(th, packed_cap_h_);
+    r.dog_records = std::min<uint64_t>(tp, packed_cap_p_);
+    r.truncated = th > packed_cap_h_ || tp > packed_cap_p_;
+    for (int f = 0; f < s.n && !r.truncated; ++f)
+        r.truncated = (s.out.harris_kps && r.harris_counts[f] > p_.harris_cap) || (s.out.dog_points && r.dog_counts[f] > p_.dog_cap);
+    // only the records that exist
+    if (r.harris_records)
+        HIPX(hipMemcpyAsync(s.h_hpacked, s.d_hpacked, r.harris_records * sizeof(vslam_kp), hipMemcpyDeviceToHost, ds));
+    if (r.dog_records)
+        HIPX(hipMemcpyAsync(s.h_ppacked, s.d_ppacked, r.dog_records * sizeof(vslam_point), hipMemcpyDeviceToHost, ds));
+    HIPX(hipEventRecord((hipEvent_t)s.down_done, ds));
+    HIPX(hipEventSynchronize((hipEvent_t)s.down_done));
+    ++collected_;
+    return r;
+}
+
+}  // namespace vslam

@@ -1,0 +1,173 @@
+#include "count_exchange.hpp"
+
+#include <arpa/inet.h>
+#include <hip/hip_runtime_api.h>
+#include <netinet/in.h>
+#include <netinet/tcp.h>
+#include <poll.h>
+#include <rccl/rccl.h>
+#include <sys/socket.h>
+#include <unistd.h>
+
+#include <cerrno>
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+
+#include "vslam_cxx.hpp"
+
+namespace vslam {
+
+namespace {
+int env_int(const char* name, int def) {
+    const char* v = std::getenv(name);
+    return v && *v ? std::atoi(v) : def;
+}
+[[noreturn]] void fail(const std::string& what) { throw Error(VSLAM_ERR_HIP, what); }
+void hipx(hipError_t e, const char* what) {
+    if (e != hipSuccess) fail(std::string(what) + ": " + hipGetErrorString(e));
+}
+void ncclx(ncclResult_t r, const char* what) {
+    if (r != ncclSuccess) fail(std::string(what) + ": " + ncclGetErrorString(r));
+}
+#define HIPX(e) hipx((e), #e)
+#define NCCLX(e) ncclx((e), #e)
+
+// 60 s to let slow ranks start; VSLAM_RDV_TIMEOUT_MS overrides (tests)
+const int kTimeoutMs = env_int("VSLAM_RDV_TIMEOUT_MS", 60000);
+
+bool io_all(int fd, void* buf, size_t n, bool writing) {
+    char* p = static_cast<char*>(buf);
+    const auto t_end = std::chrono::steady_clock::now() + std::chrono::milliseconds(kTimeoutMs);
+    while (n) {
+        pollfd pf{fd, (short)(writing ? POLLOUT : POLLIN), 0};
+        const int left = (int)std::chrono::duration_cast<std::chrono::milliseconds>(t_end - std::chrono::steady_clock::now()).count();
+        if (left <= 0 || ::poll(&pf, 1, left) <= 0) return false;
+        const ssize_t k = writing ? ::send(fd, p, n, MSG_NOSIGNAL) : ::recv(fd, p, n, 0);
+        if (k < 0 && (errno == EINTR || errno == EAGAIN)) continue;
+        if (k <= 0) return false;
+        p += k;
+        n -= (size_t)k;
+    }
+    return true;
+}
+}  // namespace
+
+RankEnv RankEnv::from_environment() {
+    RankEnv e;
+    e.rank = env_int("RANK", 0);
+    e.world = env_int("WORLD_SIZE", 1);
+    e.local_rank = env_int("LOCAL_RANK", e.rank);
+    if (const char* a = std::getenv("MASTER_ADDR"); a && *a) e.addr = a;
+    if (e.addr == "localhost") e.addr = "127.0.0.1";
+    e.rdv_port = env_int("VSLAM_RDV_PORT", env_int("MASTER_PORT", 29533) + 1);
+    if (e.world < 1 || e.rank < 0 || e.rank >= e.world) throw Error(VSLAM_ERR_INVALID, "RANK / WORLD_SIZE out of range");
+    return e;
+}
+
+void tcp_broadcast_from_rank0(const RankEnv& env, void* bytes, size_t n) {
+    if (env.world <= 1) return;
+    sockaddr_in sa{};
+    sa.sin_family = AF_INET;
+    sa.sin_port = htons((uint16_t)env.rdv_port);
+    if (::inet_pton(AF_INET, env.addr.c_str(), &sa.sin_addr) != 1) fail("rendezvous: MASTER_ADDR must be an IPv4 address, got " + env.addr);
+    if (env.rank == 0) {
+        const int ls = ::socket(AF_INET, SOCK_STREAM, 0);
+        if (ls < 0) fail("rendezvous: socket()");
+        const int one = 1;
+        ::setsockopt(ls, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
+        if (::bind(ls, reinterpret_cast<sockaddr*>(&sa), sizeof(sa)) != 0 || ::listen(ls, env.world) != 0) {
+            const std::string msg = std::string("rendezvous: cannot listen on ") + env.addr + ":" + std::to_string(env.rdv_port) + ": " + std::strerror(errno);
+            ::close(ls);
+            fail(msg);
+        }
+        // every peer introduces itself with its rank; each rank is served exactly once
+        std::vector<char> seen(env.world, 0);
+        for (int served = 1; served < env.world; ++served) {
+            pollfd pf{ls, POLLIN, 0};
+            if (::poll(&pf, 1, kTimeoutMs) <= 0) {
+                ::close(ls);
+                fail("rendezvous: rank 0 timed out waiting for " + std::to_string(env.world - served) + " rank(s)");
+            }
+            const int fd = ::accept(ls, nullptr, nullptr);
+            if (fd < 0) {
+                ::close(ls);
+                fail("rendezvous: accept()");
+            }
+            int32_t peer = -1;
+            const bool ok = io_all(fd, &peer, sizeof(peer), false) && peer > 0 && peer < env.world && !seen[peer] && io_all(fd, bytes, n, true);
+            ::close(fd);
+            if (!ok) {
+                ::close(ls);
+                fail("rendezvous: bad or duplicate peer (rank " + std::to_string(peer) + ")");
+            }
+            seen[peer] = 1;
+        }
+        ::close(ls);
+    } else {
+        const auto t_end = std::chrono::steady_clock::now() + std::chrono::milliseconds(kTimeoutMs);
+        for (;;) {  // rank 0 may not be listening yet
+            const int fd = ::socket(AF_INET, SOCK_STREAM, 0);
+            if (fd < 0) fail("rendezvous: socket()");
+            if (::connect(fd, reinterpret_cast<sockaddr*>(&sa), sizeof(sa)) == 0) {
+                int32_t me = env.rank;
+                const bool ok = io_all(fd, &me, sizeof(me), true) && io_all(fd, bytes, n, false);
+                ::close(fd);
+                if (!ok) fail("rendezvous: rank " + std::to_string(env.rank) + " lost the connection to rank 0");
+                return;
+            }
+            ::close(fd);
+            if (std::chrono::steady_clock::now() > t_end)
+                fail("rendezvous: rank " + std::to_string(env.rank) + " could not reach rank 0 at " + env.addr + ":" + std::to_string(env.rdv_port));
+            std::this_thread::sleep_for(std::chrono::milliseconds(50));
+        }
+    }
+}
+
+CountExchange::CountExchange(const RankEnv& env, int device) : env_(env), device_(device) {
+    HIPX(hipSetDevice(device_));
+    ncclUniqueId id;
+    std::memset(&id, 0, sizeof(id));
+    if (env_.rank == 0) NCCLX(ncclGetUniqueId(&id));
+    tcp_broadcast_from_rank0(env_, &id, sizeof(id));
+    ncclComm_t comm;
+    NCCLX(ncclCommInitRank(&comm, env_.world, id, env_.rank));
+    comm_ = comm;
+    HIPX(hipMalloc((void**)&d_all_, sizeof(uint64_t) * 2 * (size_t)env_.world));
+    HIPX(hipMemset(d_all_, 0, sizeof(uint64_t) * 2 * (size_t)env_.world));
+    HIPX(hipMalloc((void**)&d_scratch_, 2 * sizeof(double)));
+}
+
+CountExchange::~CountExchange() {
+    (void)hipSetDevice(device_);
+    (void)hipDeviceSynchronize();
+    if (comm_) (void)ncclCommDestroy((ncclComm_t)comm_);
+    if (d_all_) (void)hipFree(d_all_);
+    if (d_scratch_) (void)hipFree(d_scratch_);
+}
+
+void CountExchange::all_gather_async(const uint64_t* d_local, void* stream) {
+    NCCLX(ncclAllGather(d_local, d_all_, 2, ncclUint64, (ncclComm_t)comm_, (hipStream_t)stream));
+}
+
+std::vector<uint64_t> CountExchange::fetch(void* stream) {
+    std::vector<uint64_t> all(2 * (size_t)env_.world);
+    HIPX(hipMemcpyAsync(all.data(), d_all_, all.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPX(hipStreamSynchronize((hipStream_t)stream));
+    return all;
+}
+
+double CountExchange::max_over_ranks(double v, void* stream) {
+    const hipStream_t s = (hipStream_t)stream;
+    HIPX(hipMemcpyAsync(d_scratch_, &v, sizeof(double), hipMemcpyHostToDevice, s));
+    NCCLX(ncclAllReduce(d_scratch_, d_scratch_ + 1, 1, ncclDouble, ncclMax, (ncclComm_t)comm_, s));
+    double out = v;
+    HIPX(hipMemcpyAsync(&out, d_scratch_ + 1, sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPX(hipStreamSynchronize(s));
+    return out;
+}
+
+void CountExchange::barrier(void* stream) { (void)max_over_ranks(0.0, stream); }
+
+}  // namespace vslam
