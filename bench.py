@@ -97,6 +97,27 @@ def cpu_baseline(rows, cols, n_oct, sample_frames, gpu_keypoints=None):
     }
 
 
+def cxx_host_runs(rows, cols, n, octaves):
+    """frames/s of the C++ throughput host on this workload: visualslam_amd/bin/Stream, one rank over RCCL."""
+    import subprocess
+
+    exe = os.path.join(ROOT, "visualslam_amd", "bin", "Stream")
+    if not os.path.exists(exe):
+        r = subprocess.run(["make", "-C", os.path.join(ROOT, "visualslam_amd", "cxx")], capture_output=True, text=True)
+        if r.returncode != 0:
+            return {"error": "building the C++ host failed: " + (r.stdout + r.stderr)[-400:]}
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK=os.environ.get("LOCAL_RANK", "0"), MASTER_ADDR="127.0.0.1")
+    res = {}
+    for mode in ("device", "hostfed"):
+        try:
+            r = subprocess.run([exe, "--mode", mode, "--frames", str(n), "--batches", "10", "--warmup", "3", "--rows", str(rows), "--cols", str(cols),
+                                "--octaves", str(octaves)], capture_output=True, text=True, timeout=600, env=env)
+            res[mode] = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {"error": (r.stdout + r.stderr)[-400:]}
+        except Exception as e:
+            res[mode] = {"error": repr(e)}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -113,6 +134,7 @@ def main():
                     help="1: also run filterKeypoints on every frame's keypoint list (SURVEY 8f row 3); implies --localize 1")
     ap.add_argument("--cpu-sample", type=int, default=6, help="frames in the CPU baseline sample (0 = skip)")
     ap.add_argument("--modes", type=int, default=1, help="1: also time the localize / orient list modes (the `modes` object)")
+    ap.add_argument("--cxx-host", type=int, default=1, help="1: also run the C++ Stream executable on the same workload (N = 1 only)")
     ap.add_argument("--stream", choices=["side", "null"], default="side",
                     help="stream of the whole job: a torch side stream (default) or torch's default (NULL) stream")
     args = ap.parse_args()
@@ -176,11 +198,15 @@ def main():
 
     shared = {}  # the big output buffers are shared by the modes (the pyramids alone are 31 GB)
 
-    def run_mode(localize, orient, steps, warmup, kname, describe=0):
+    def run_mode(localize, orient, steps, warmup, kname, describe=0, dense=0, frames_t=None):
         """K timed steps of one list mode; returns per-mode results (times: max over ranks)."""
-        p = capi.default_params(rows, cols, n_octaves=args.octaves, localize=1 if orient else localize, orient=orient)
+        frames_t = frames if frames_t is None else frames_t
+        p = capi.default_params(rows, cols, n_octaves=args.octaves, localize=1 if orient else localize, orient=orient, extrema_dense=dense)
         L = capi.batch_layout(p)
-        if not shared:
+        if dense:  # the dense scan has its own (larger) bitmask; every other buffer is shared
+            if "dense_bits" not in shared:
+                shared["dense_bits"] = torch.empty((n, L.bits_frame_words), dtype=torch.int64, device=dev)
+        if "response" not in shared:
             shared.update(
                 response=torch.empty((n, rows, cols), dtype=torch.float32, device=dev),
                 nms_mask=torch.empty((n, rows, cols), dtype=torch.uint8, device=dev),
@@ -191,23 +217,22 @@ def main():
                 dog_points=torch.empty((n, p.dog_cap, 6), dtype=torch.int32, device=dev),
                 dog_counts=torch.zeros(n, dtype=torch.int32, device=dev),
             )
-        out = dict(shared)
+        out = {k: v for k, v in shared.items() if k != "dense_bits"}
+        if dense:
+            out["extrema_bits"] = shared["dense_bits"]
         if orient:
             out["oriented_points"] = torch.empty((n, p.oriented_cap, 6), dtype=torch.int32, device=dev)
             out["oriented_counts"] = torch.zeros(n, dtype=torch.int32, device=dev)
             out["oriented_survivors"] = torch.zeros(n, dtype=torch.int32, device=dev)
-        if describe:  # descriptors of a small per-frame budget: 128 floats per oriented point
-            p.oriented_cap = min(p.oriented_cap, 4096)
-            out["oriented_points"] = out["oriented_points"][:, : p.oriented_cap].contiguous()
+        if describe:  # 128 floats per oriented point at the full per-frame capacity (8.6 GB for 256 x 65536)
             out["descriptors"] = torch.empty((n, p.oriented_cap, 128), dtype=torch.float32, device=dev)
             out["descriptor_defined"] = torch.zeros((n, p.oriented_cap), dtype=torch.uint8, device=dev)
         counts_local = torch.zeros(2, dtype=torch.int64, device=dev)
         counts_all = torch.zeros((world, 2), dtype=torch.int64, device=cdev)
 
         def step():
-            ctx.detect_batch(p, frames, **out)
-            counts_local[0] = out["harris_counts"].sum()
-            counts_local[1] = out["dog_counts"].sum()
+            ctx.detect_batch(p, frames_t, **out)
+            ctx.count_totals(out["harris_counts"], out["dog_counts"], counts_local)  # {harris, dog} of this rank, on the device (one small kernel)
             sharding.gather_counts(counts_local.to(cdev), counts_all)  # the one collective of the path: 16 B per rank over RCCL
 
         for _ in range(warmup):
@@ -232,6 +257,8 @@ def main():
             dist.all_reduce(flags, op=dist.ReduceOp.SUM)
         totals = counts_all.sum(0).tolist()
         fl = flags.tolist()
+        if describe:
+            del out["descriptors"], out["descriptor_defined"]
         return {"p": p, "L": L, "dt": float(red.item()), "launches": launches, "kms": kms, "harris": totals[0], "dog": totals[1],
                 "list_overflow": bool(fl[0]), "oriented": fl[1], "oriented_truncated": bool(fl[2])}
 
@@ -263,14 +290,23 @@ def main():
     # :787), measured in the same process on the same frames with fewer steps
     modes = None
     if args.modes and args.octaves > 0 and not (args.localize or args.orient):
-        modes = {}
-        for name, (lz, orr, de) in (("localize", (1, 0, 0)), ("orient", (1, 1, 0)), ("describe", (1, 1, 1))):
-            m = run_mode(lz, orr, max(2, args.steps // 2), 1, None, de)
+        # on the checkerboard batch the orientation stage sees ~36 points per frame, so the list
+        # modes were timed on near-empty work.  They run on a batch whose every second frame is the uniform-
+        # noise frame of SURVEY 8d (tens of thousands of oriented points each); `candidates` is the default
+        # mode on that same batch, for reference.  Full list capacities, nothing clamped.
+        mixed = synth.frames_torch(n, rows, cols, stream_id=rank, device=dev, noise_every=2)
+        modes = {"content": "the bench's camera stream with every second frame replaced by a uniform-noise frame (synth kind=noise)"}
+        for name, (lz, orr, de, dn) in (("candidates", (0, 0, 0, 0)), ("localize", (1, 0, 0, 0)), ("orient", (1, 1, 0, 0)), ("describe", (1, 1, 1, 0)),
+                                        ("dense", (0, 0, 0, 1))):
             ms = max(2, args.steps // 2)
+            m = run_mode(lz, orr, ms, 1, None, de, dn, frames_t=mixed)
             modes[name] = {"frames_per_sec": n * world * ms / m["dt"], "ms_per_step": m["dt"] / ms * 1e3, "steps": ms,
-                           "dog_points_per_step": m["dog"], "list_overflow": m["list_overflow"],
-                           **({"oriented_points_per_step": m["oriented"], "oriented_truncated": m["oriented_truncated"]} if orr else {}),
-                           **({"what": "the whole DoG executable: pyramid, initialKeypointDetection, filterKeypoints, SIFT descriptors"} if de else {})}
+                           "harris_points_per_step": m["harris"], "dog_points_per_step": m["dog"], "list_overflow": m["list_overflow"],
+                           **({"oriented_points_per_step": m["oriented"], "oriented_truncated": m["oriented_truncated"],
+                               "oriented_cap": int(m["p"].oriented_cap)} if orr else {}),
+                           **({"what": "the whole DoG executable: pyramid, initialKeypointDetection, filterKeypoints, SIFT descriptors of every oriented point"} if de else {}),
+                           **({"what": "extension: dense 3x3x3 scale-space test on every pixel of levels 1..3 (params.extrema_dense) instead of the reference's lattice test"} if dn else {})}
+        del mixed
 
     if rank == 0:
         algo = kernel_algorithmic_bytes(L, rows, cols)
@@ -285,7 +321,7 @@ def main():
             # --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled per MI355X_MICROARCH.md) and
             # committed as profiles/traffic.json; counters cannot be read from inside this process,
             # so the figure is the committed profile's, scaled to this run's frames per launch
-            traffic = tsrc = None
+            traffic = tsrc = tprof = None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tpath):
                 tj = json.load(open(tpath))
@@ -293,9 +329,12 @@ def main():
                 if t:
                     traffic = t["hbm_bytes_per_frame"] * n * args.steps / launches
                     tsrc = "profiles/traffic.json: " + tj.get("_round", "rocprofv3 --pmc passes")
+                    # NOT measured in this run: the committed profile's per-frame figure times this run's frames per launch
+                    tprof = {"live": False, "hbm_bytes_per_frame": t["hbm_bytes_per_frame"], "profiled_frames_per_batch": tj.get("_frames"),
+                             "profile": tj.get("_round"), "scaled_to_frames_per_launch": n * args.steps / launches}
             roof = {
                 "kernel": kname, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": tsrc,
+                "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": tsrc, "traffic_profiled": tprof,
                 "limited_by": "valu-dot issue rate, see roofline_valu" if kname == "k_pyr_octave" else None,
                 "launches": launches, "avg_launch_ms": kms / launches,
                 "algorithmic_bytes_per_frame": algo.get(kname, 0),
@@ -354,8 +393,18 @@ def main():
             "roofline_valu": valu,
             "cpu_baseline": cpu_baseline(rows, cols, args.octaves, cs, gpu_kp_sample) if (world == 1 and args.cpu_sample > 0) else None,
         }
-        print(json.dumps(line))
+    # The same workload driven by the C++ host (visualslam_amd/cxx: BatchDetector + Stream, RCCL from librccl,
+    # no torch in that process): device-resident, and host-fed (pinned frames in, packed lists out).  Child
+    # processes, after this process has released the GPU memory; N = 1 only; never part of `value`.
+    cxx_wanted = rank == 0 and world == 1 and args.cxx_host
     ctx.close()
+    if cxx_wanted:
+        shared.clear()
+        del frames
+        torch.cuda.empty_cache()
+        line["cxx_host"] = cxx_host_runs(rows, cols, n, args.octaves)
+    if rank == 0:
+        print(json.dumps(line))
     if use_dist:
         dist.destroy_process_group()
 

@@ -10,7 +10,7 @@
 //            the RCCL all-gather of the {harris, dog} counts on the same stream (what bench.py times);
 //   hostfed  every batch starts in pinned host memory and its keypoint lists end there, uploads /
 //            kernels / downloads of consecutive batches overlapped (BatchDetector::submit / collect);
-//            the all-gather runs once per batch on the host-side totals.
+//            the all-gather of a batch's counts follows its kernels on the same stream.
 //
 // Ranks: RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT as torchrun sets them (or by hand:
 // `for r in 0 1 ..; do RANK=$r WORLD_SIZE=N LOCAL_RANK=$r ./Stream & done`); the GPU is LOCAL_RANK, the
@@ -157,7 +157,6 @@ int main(int argc, char** argv) {
         uint8_t* h_frames = (uint8_t*)vslam::BatchDetector::alloc_pinned((size_t)a.frames * N);
         fill_frames(a, env.rank, 0, a.frames, h_frames);
 
-        uint64_t kp_local[2] = {0, 0};
         std::vector<uint64_t> all;
         double dt = 0;
         const vslam::BatchResult* last = nullptr;
@@ -182,7 +181,6 @@ int main(int argc, char** argv) {
             ex.barrier(cs);
             dt = now_s() - t0;
             all = ex.fetch(cs);
-            kp_local[0] = all[2 * env.rank], kp_local[1] = all[2 * env.rank + 1];
             if (!a.dump.empty()) {  // download the lists of the last batch for the parity check (not timed)
                 const vslam_batch_out& o = det.device_outputs();
                 const vslam_params& p = det.params();
@@ -210,21 +208,21 @@ int main(int argc, char** argv) {
             }
             (void)hipFree(d_frames);
         } else {
-            uint64_t* d_tot = nullptr;  // host-side totals go through the same RCCL all-gather, once per batch
-            if (hipMalloc((void**)&d_tot, 16) != hipSuccess) throw std::runtime_error("hipMalloc");
+            // the all-gather of a batch's counts is enqueued right behind its kernels (device-side totals): the
+            // host never waits for it inside the loop
             const int depth = std::max(1, opt.slots);
             bool truncated = false;
+            auto submit = [&] {
+                det.submit(h_frames, a.frames);
+                ex.all_gather_async(det.device_totals(), cs);
+            };
             auto run = [&](int nb) {
                 int sub = 0;
-                for (; sub < std::min(depth, nb); ++sub) det.submit(h_frames, a.frames);
+                for (; sub < std::min(depth, nb); ++sub) submit();
                 for (int k = 0; k < nb; ++k) {
                     const vslam::BatchResult& r = det.collect();
                     truncated |= r.truncated;
-                    if (sub < nb) det.submit(h_frames, a.frames), ++sub;
-                    kp_local[0] = kp_local[1] = 0;
-                    for (int f = 0; f < r.n_frames; ++f) kp_local[0] += r.harris_counts[f], kp_local[1] += r.dog_counts[f];
-                    (void)hipMemcpyAsync(d_tot, kp_local, 16, hipMemcpyHostToDevice, cs);
-                    ex.all_gather_async(d_tot, cs);
+                    if (sub < nb) submit(), ++sub;
                     last = &r;
                 }
             };
@@ -236,7 +234,6 @@ int main(int argc, char** argv) {
             ex.barrier(cs);
             dt = now_s() - t0;
             all = ex.fetch(cs);
-            (void)hipFree(d_tot);
             if (truncated) std::fprintf(stderr, "Stream: rank %d: lists truncated (raise the caps or the host budget)\n", env.rank);
         }
         const double dt_max = ex.max_over_ranks(dt, cs);

@@ -86,8 +86,9 @@ BatchDetector::BatchDetector(const Options& opt) : opt_(opt) {
         img.pyramid = (uint8_t*)dmalloc(need.pyramid_bytes), img.pyramid_bytes = need.pyramid_bytes;
         img.extrema_bits = (uint64_t*)dmalloc(need.extrema_bits_bytes), img.extrema_bits_bytes = need.extrema_bits_bytes;
     }
-    d_totals_ = (uint64_t*)dmalloc(2 * sizeof(uint64_t));
-    HIPX(hipMemset(d_totals_, 0, 2 * sizeof(uint64_t)));
+    d_totals_all_ = (uint64_t*)dmalloc(2 * sizeof(uint64_t) * (size_t)std::max(1, opt.slots));
+    HIPX(hipMemset(d_totals_all_, 0, 2 * sizeof(uint64_t) * (size_t)std::max(1, opt.slots)));
+    d_totals_ = d_totals_all_;
     const int nslots = opt.host_fed ? opt.slots : 1;
     const size_t n = (size_t)opt.batch;
     packed_cap_h_ = std::min<size_t>(n * p_.harris_cap, n * opt.host_records_per_frame);
@@ -153,6 +154,7 @@ void BatchDetector::detect_device(const uint8_t* d_frames, size_t frame_stride, 
     HIPX(hipSetDevice(opt_.device));
     Slot& s = slots_[0];
     run_on_slot(s, d_frames, frame_stride, n);
+    d_totals_ = d_totals_all_;
     check(vslam_count_totals_dev(ctx_, s.out.harris_counts, s.out.dog_counts, n, d_totals_), ctx_, "vslam_count_totals_dev");
 }
 
@@ -172,6 +174,10 @@ void BatchDetector::submit(const uint8_t* host_frames, int n) {
     HIPX(hipStreamWaitEvent(cs, (hipEvent_t)s.up_done, 0));
     HIPX(hipStreamWaitEvent(cs, (hipEvent_t)s.down_done, 0));
     run_on_slot(s, s.d_frames, N, n);
+    // this batch's {harris, dog} totals stay on the device (one pair per slot): the count all-gather can be
+    // enqueued right behind submit() without the host seeing them
+    d_totals_ = d_totals_all_ + 2 * (submitted_ % slots_.size());
+    check(vslam_count_totals_dev(ctx_, s.out.harris_counts, s.out.dog_counts, n, d_totals_), ctx_, "vslam_count_totals_dev");
     const size_t nb = (size_t)opt_.batch;
     if (s.out.harris_kps)
         check(vslam_pack_lists_dev(ctx_, s.out.harris_kps, sizeof(vslam_kp), p_.harris_cap, s.out.harris_counts, n, s.d_hpacked,

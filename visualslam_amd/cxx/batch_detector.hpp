@@ -75,8 +75,8 @@ public:
     // The device buffers detect_device (and the most recent submit) wrote: response, nms_mask, pyramid,
     // extrema_bits shared by all batches; lists of slot 0 for detect_device.
     const vslam_batch_out& device_outputs() const { return slots_[0].out; }
-    // {harris, dog} totals of the last detect_device() as two uint64 in device memory (vslam_count_totals_dev):
-    // the send buffer of the count all-gather, valid on stream()
+    // {harris, dog} totals of the last detect_device() / submit() as two uint64 in device memory
+    // (vslam_count_totals_dev; one pair per slot): the send buffer of the count all-gather, valid on stream()
     const uint64_t* device_totals() const { return d_totals_; }
     void sync();
 
@@ -115,7 +115,7 @@ private:
     void *compute_ = nullptr, *up_ = nullptr, *down_ = nullptr;  // hipStream_t
     std::vector<Slot> slots_;
     std::vector<void*> dev_allocs_, pinned_allocs_;
-    uint64_t* d_totals_ = nullptr;
+    uint64_t *d_totals_ = nullptr, *d_totals_all_ = nullptr;
     size_t packed_cap_h_ = 0, packed_cap_p_ = 0;  // records
     uint64_t submitted_ = 0, collected_ = 0;
 };

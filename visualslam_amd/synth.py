@@ -59,8 +59,11 @@ def _i64(v: int) -> int:
     return v - (1 << 64) if v >= (1 << 63) else v
 
 
-def frames_torch(n: int, rows: int, cols: int, stream_id: int = 0, first_frame: int = 0, device="cpu"):
+def frames_torch(n: int, rows: int, cols: int, stream_id: int = 0, first_frame: int = 0, device="cpu", noise_every: int = 0):
     """Same frames as frames_np, generated with torch int64 ops on ``device``.
+
+    noise_every = k > 0: every k-th frame (f % k == k - 1) is the uniform-noise KAT frame of SURVEY 8d
+    (frame_np(kind="noise")) instead of the checkerboard - content that populates the orientation stage.
 
     int64 add/mul wrap like uint64; the logical right shifts are emulated by masking
     the sign-extended bits of torch's arithmetic shift.
@@ -84,6 +87,9 @@ def frames_torch(n: int, rows: int, cols: int, stream_id: int = 0, first_frame: 
         z = (z ^ lsr(z, 30)) * _i64(0xBF58476D1CE4E5B9)
         z = (z ^ lsr(z, 27)) * _i64(0x94D049BB133111EB)
         z = z ^ lsr(z, 31)
+        if noise_every > 0 and f % noise_every == noise_every - 1:
+            out[f] = (z & 255).to(torch.uint8)
+            continue
         noise = (z & 31) - 16
         out[f] = torch.clamp(base + noise, 0, 255).to(torch.uint8)
     return out
