@@ -110,7 +110,7 @@ def cxx_host_runs(rows, cols, n, octaves):
     res = {}
     for mode in ("device", "hostfed"):
         try:
-            r = subprocess.run([exe, "--mode", mode, "--frames", str(n), "--batches", "10", "--warmup", "3", "--rows", str(rows), "--cols", str(cols),
+            r = subprocess.run([exe, "--mode", mode, "--frames", str(n), "--batches", "30" if mode == "device" else "40", "--warmup", "6", "--rows", str(rows), "--cols", str(cols),
                                 "--octaves", str(octaves)], capture_output=True, text=True, timeout=600, env=env)
             res[mode] = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {"error": (r.stdout + r.stderr)[-400:]}
         except Exception as e:

@@ -21,8 +21,10 @@
 // harris_total, dog_total} + n_harris vslam_kp + n_dog vslam_point.
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -38,7 +40,7 @@ namespace {
 struct Args {
     std::string mode = "device", source = "synth", dump;
     int frames = 256, batches = 8, warmup = 2, rows = 1080, cols = 1920, octaves = 4;
-    bool rdv_selftest = false;
+    bool rdv_selftest = false, no_allgather = false;
 };
 
 Args parse(int argc, char** argv) {
@@ -59,6 +61,7 @@ Args parse(int argc, char** argv) {
         else if (k == "--source") a.source = val();
         else if (k == "--dump") a.dump = val();
         else if (k == "--rdv-selftest") a.rdv_selftest = true;
+        else if (k == "--no-allgather") a.no_allgather = true;  // diagnosis only: the per-step collective left out
         else throw std::runtime_error("unknown argument " + k);
     }
     if ((a.mode != "device" && a.mode != "hostfed") || a.frames <= 0 || a.batches <= 0 || a.warmup < 0 || a.rows <= 0 || a.cols <= 0 || a.octaves < 0)
@@ -123,6 +126,10 @@ double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock:
 
 int main(int argc, char** argv) {
     try {
+        // The HIP runtime spreads a process's streams over 4 hardware queues by default; this process has the
+        // library's three side streams, the copy streams of the host-fed pipeline and RCCL's own.  Streams that
+        // share a queue serialise (measured: -2 % frames/s device-resident).  Must be set before HIP starts.
+        ::setenv("GPU_MAX_HW_QUEUES", "8", 0);
         const Args a = parse(argc, argv);
         const vslam::RankEnv env = vslam::RankEnv::from_environment();
         if (a.rdv_selftest) {  // the TCP hand-off of the RCCL id alone (no GPU): rank 0's bytes must reach every rank
@@ -158,7 +165,7 @@ int main(int argc, char** argv) {
         fill_frames(a, env.rank, 0, a.frames, h_frames);
 
         std::vector<uint64_t> all;
-        double dt = 0;
+        double dt = 0, steady_ms = 0;
         const vslam::BatchResult* last = nullptr;
         vslam::BatchResult dev_last;
         std::vector<uint64_t> dl_off;
@@ -171,7 +178,7 @@ int main(int argc, char** argv) {
             if (hipMemcpy(d_frames, h_frames, (size_t)a.frames * N, hipMemcpyHostToDevice) != hipSuccess) throw std::runtime_error("upload");
             auto step = [&] {
                 det.detect_device(d_frames, N, a.frames);
-                ex.all_gather_async(det.device_totals(), cs);  // 16 bytes per rank, same stream: no host round trip
+                if (!a.no_allgather) ex.all_gather_async(det.device_totals(), cs);  // 16 bytes per rank, same stream: no host round trip
             };
             for (int i = 0; i < a.warmup; ++i) step();
             ex.barrier(cs);
@@ -216,11 +223,14 @@ int main(int argc, char** argv) {
                 det.submit(h_frames, a.frames);
                 ex.all_gather_async(det.device_totals(), cs);
             };
+            std::vector<double> t_collect;
             auto run = [&](int nb) {
                 int sub = 0;
+                t_collect.clear();
                 for (; sub < std::min(depth, nb); ++sub) submit();
                 for (int k = 0; k < nb; ++k) {
                     const vslam::BatchResult& r = det.collect();
+                    t_collect.push_back(now_s());
                     truncated |= r.truncated;
                     if (sub < nb) submit(), ++sub;
                     last = &r;
@@ -235,6 +245,14 @@ int main(int argc, char** argv) {
             dt = now_s() - t0;
             all = ex.fetch(cs);
             if (truncated) std::fprintf(stderr, "Stream: rank %d: lists truncated (raise the caps or the host budget)\n", env.rank);
+            // steady state of the pipeline: the median interval between consecutive collect() returns (the whole-run
+            // figure also carries the first upload and the last download, which nothing overlaps)
+            if (t_collect.size() >= 4) {
+                std::vector<double> d;
+                for (size_t i = 1; i < t_collect.size(); ++i) d.push_back(t_collect[i] - t_collect[i - 1]);
+                std::sort(d.begin(), d.end());
+                steady_ms = d[d.size() / 2] * 1e3;
+            }
         }
         const double dt_max = ex.max_over_ranks(dt, cs);
         if (!a.dump.empty() && last) dump_lists(a.dump, a.rows, a.cols, *last);
@@ -244,10 +262,11 @@ int main(int argc, char** argv) {
             const double fps = (double)a.frames * a.batches * env.world / dt_max;
             std::printf("{\"exe\": \"Stream\", \"host\": \"C++ (BatchDetector) + RCCL ncclAllGather\", \"mode\": \"%s\", \"n_gpus\": %d, \"frames_per_batch\": %d, "
                         "\"batches\": %d, \"warmup\": %d, \"rows\": %d, \"cols\": %d, \"octaves\": %d, \"frames_per_sec\": %.2f, \"ms_per_batch\": %.4f, "
-                        "\"keypoints_per_batch\": {\"harris\": %llu, \"dog\": %llu}, \"keypoints_per_sec\": %.1f, \"rank0_counts\": [%llu, %llu]}\n",
+                        "\"keypoints_per_batch\": {\"harris\": %llu, \"dog\": %llu}, \"keypoints_per_sec\": %.1f, \"rank0_counts\": [%llu, %llu], "
+                        "\"steady_ms_per_batch\": %.4f, \"steady_frames_per_sec\": %.2f}\n",
                         a.mode.c_str(), env.world, a.frames, a.batches, a.warmup, a.rows, a.cols, det.params().n_octaves, fps, dt_max / a.batches * 1e3,
                         (unsigned long long)gh, (unsigned long long)gd, (double)(gh + gd) * a.batches / dt_max, (unsigned long long)all[0],
-                        (unsigned long long)all[1]);
+                        (unsigned long long)all[1], steady_ms, steady_ms > 0 ? a.frames * 1e3 / steady_ms * env.world : 0.0);
         }
         vslam::BatchDetector::free_pinned(h_frames);
         return 0;

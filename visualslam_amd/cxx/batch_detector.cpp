@@ -53,10 +53,15 @@ BatchDetector::BatchDetector(const Options& opt) : opt_(opt) {
     int rc = vslam_batch_layout_query(&p_, &L_);
     if (rc != VSLAM_OK) throw Error(rc, "BatchDetector: vslam_batch_layout_query rejected the parameters");
     HIPX(hipSetDevice(opt.device));
-    hipStream_t cs, us, ds;
+    // Streams map onto a small number of hardware queues (4 by default): every extra stream can end up
+    // sharing a queue - and therefore serialising - with the library's side streams, so the copy streams
+    // exist only in host-fed use (device-resident Stream runs lost 4 % to two idle streams).
+    hipStream_t cs, us = nullptr, ds = nullptr;
     HIPX(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
-    HIPX(hipStreamCreateWithFlags(&us, hipStreamNonBlocking));
-    HIPX(hipStreamCreateWithFlags(&ds, hipStreamNonBlocking));
+    if (opt.host_fed) {
+        HIPX(hipStreamCreateWithFlags(&us, hipStreamNonBlocking));
+        HIPX(hipStreamCreateWithFlags(&ds, hipStreamNonBlocking));
+    }
     compute_ = cs, up_ = us, down_ = ds;
     rc = vslam_ctx_create(opt.device, compute_, &ctx_);
     if (rc != VSLAM_OK) throw Error(rc, std::string("vslam_ctx_create: ") + vslam_status_string(rc) + " (no usable HIP device: there is no CPU fallback)");
