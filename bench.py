@@ -34,7 +34,8 @@ def kernel_algorithmic_bytes(L, rows, cols):
         "k_harris_strip": 6 * N,                 # u8 frame in, f32 response + u8 NMS mask out (one pass)
         "k_resize_linear2x_slide": N,            # DoG path's read of the frame
         "k_pyr_octave": 11 * sum(P[:2]),         # 6 Gaussian + 5 DoG images of octaves 0-1 (LDS-tiled)
-        "k_gauss_h_strip": 11 * sum(P[2:]),      # the same for the coarse octaves (strip kernels)
+        "k_gauss_band": 11 * sum(P[2:]),         # the same for the coarse octaves (fused band kernel)
+        "k_gauss_h_strip": 11 * sum(P[2:]),      # ... or the two strip kernels, where a band does not fit the LDS
     }
 
 

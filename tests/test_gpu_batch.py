@@ -439,7 +439,7 @@ def test_fast_paths_are_the_ones_that_run(env):
     # (a silent fall-back to the generic kernels would still pass parity)
     ctx, torch = env
     frames = synth.frames_np(1, 480, 640, stream_id=1)
-    for name, want in (("k_pyr_octave", 2), ("k_harris_strip", 1), ("k_gauss_h_strip", 2), ("k_resize_linear2x_slide", 1)):
+    for name, want in (("k_pyr_octave", 2), ("k_harris_strip", 1), ("k_gauss_band", 2), ("k_resize_linear2x_slide", 1)):
         ctx.kernel_timing_enable(name)
         run_batch(ctx, torch, frames)
         launches, ms = ctx.kernel_timing_read()
@@ -447,7 +447,7 @@ def test_fast_paths_are_the_ones_that_run(env):
         assert launches >= want and ms > 0, (name, launches)
     # widths that are not a multiple of 8 take the same kernels (pitched planes)
     odd = synth.frames_np(1, 310, 438, stream_id=1)
-    for name, want in (("k_pyr_octave", 2), ("k_gauss_h_strip", 2)):
+    for name, want in (("k_pyr_octave", 2), ("k_gauss_band", 2)):
         ctx.kernel_timing_enable(name)
         run_batch(ctx, torch, odd)
         launches, ms = ctx.kernel_timing_read()
@@ -476,6 +476,20 @@ def test_serial_stream_mode_matches_oracle():
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, VSLAM_AUX_STREAMS="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "__graft_entry__.py"), "smoke"], capture_output=True, text=True,
+                       timeout=600, env=env, cwd=root)
+    assert r.returncode == 0 and "smoke ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_two_kernel_strip_path_still_matches_oracle():
+    # the coarse octaves normally run the fused band kernel; the two strip kernels remain the path for
+    # octaves whose band does not fit the LDS (VSLAM_BAND_KERNEL=0 forces it, read once per process)
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VSLAM_BAND_KERNEL="0")
     r = subprocess.run([sys.executable, os.path.join(root, "__graft_entry__.py"), "smoke"], capture_output=True, text=True,
                        timeout=600, env=env, cwd=root)
     assert r.returncode == 0 and "smoke ok" in r.stdout, r.stdout + r.stderr

@@ -271,6 +271,180 @@ __global__ __launch_bounds__(256) void k_gauss_h_strip(const uint16_t* __restric
     }
 }
 
+// ------------------------------------------------------------------------------ fused band kernel
+// Round 3: both passes of a coarse octave in ONE kernel, the 16-bit row sums never leave the CU.
+//   One 512-thread workgroup = a band of SH output rows x ALL columns of one frame's octave.
+//   LDS: rp [(SH + 2 RM) / 4][colsP] dwords - the band's rows plus the vertical halo RM of the octave base,
+//        byte-transposed (4 vertically adjacent pixels per dword), reflect-101 resolved at fill time
+//        (the whole 480 x 270 base of octave 3 is 127 KB; a band of octave 2 is 8 + 120 rows x 960);
+//        hp [SH][pw] dwords - the current level's row sums of the band as u16 pairs with the
+//        reflect-101 extension, exactly the image k_gauss_h_strip stages from the scratch.
+//   Per level: vertical dot4 items (4 columns x 4 rows, window alignment by the per-level offset
+//   delta as in k_pyr_octave) -> hp; reflect halos copied inside LDS; horizontal dot2 items
+//   (8 columns x RI rows, h_item_level above) -> pack, saturating DoG, 8-byte stores.
+// Against the two strip kernels this removes the [frame][6][P] u16 scratch (12 P bytes written and read
+// again per frame: 15.5 MB of a 1080p frame's 24 MB strip traffic), the second launch and the
+// horizontal kernel's staging loads.  The price is occupancy: one workgroup per CU (2 waves per SIMD).
+// grid = (1, ceil(rows / SH), frames); block = 512; dynamic LDS = ((wq + 1) * colsP + SH * pw) * 4 bytes, wq = (SH + 2 RM) / 4.
+template <int DELTA>
+__device__ __forceinline__ void band_vertical_item(const uint4* __restrict__ col, int colsP4, const uint4* __restrict__ tab, int M,
+                                                   uint32_t hbias, uint32_t (&acc)[4][4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[j][c] = hbias;
+    uint4 tprev = make_uint4(0, 0, 0, 0);
+#pragma unroll 2
+    for (int m = 0; m < M; ++m) {
+        const uint4 v = col[m * colsP4];
+        const uint4 tcur = tab[m];  // wave-uniform: scalar load
+        const uint32_t tc[4] = {tcur.x, tcur.y, tcur.z, tcur.w}, tp[4] = {tprev.x, tprev.y, tprev.z, tprev.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            // row j of the item starts DELTA + j bytes into the first dword of the column window
+            const uint32_t t = DELTA + j < 4 ? tc[DELTA + j] : tp[DELTA + j - 4];
+            acc[j][0] = udot4(v.x, t, acc[j][0]);
+            acc[j][1] = udot4(v.y, t, acc[j][1]);
+            acc[j][2] = udot4(v.z, t, acc[j][2]);
+            acc[j][3] = udot4(v.w, t, acc[j][3]);
+        }
+        tprev = tcur;
+    }
+}
+
+template <int SH, int RI>
+__global__ __launch_bounds__(512) void k_gauss_band(const uint8_t* __restrict__ base, size_t bframe, uint8_t* __restrict__ oct_out,
+                                                     size_t pframe, int rows, int cols, int pitch, int RM, int colsP, int pw,
+                                                     const StripTaps* __restrict__ taps, uint8_t* __restrict__ next_base,
+                                                     size_t nframe, int nrows, int ncols, int npitch) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const int wq = (SH + 2 * RM) >> 2;
+    uint32_t* rp = smem;                     // [wq + 1][colsP]: one spare row quad, the last tap dword of a window may start in it (zero taps)
+    uint32_t* hp = smem + (wq + 1) * colsP;  // [SH][pw]
+    const int tid = threadIdx.x;
+    const int y0 = blockIdx.y * SH;
+    const uint8_t* src = base + blockIdx.z * bframe;
+    uint8_t* out = oct_out + blockIdx.z * pframe;
+    const size_t P = (size_t)rows * pitch;
+    const int ncq = (cols + 3) >> 2;  // 4-column groups
+
+    // ---- stage rows [y0 - RM, y0 + SH + RM) of the base, byte-transposed ------------------------------
+    for (int it = tid; it < wq * ncq; it += 512) {
+        const int yq = it / ncq, xq = it - yq * ncq;
+        uint32_t a[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)  // the dword may run into the row padding (pitch is a multiple of 16): those columns feed nothing
+            a[k] = *reinterpret_cast<const uint32_t*>(src + (size_t)reflect101(y0 - RM + 4 * yq + k, rows) * pitch + 4 * xq);
+        const uint32_t p01l = __builtin_amdgcn_perm(a[1], a[0], 0x05010400), p01h = __builtin_amdgcn_perm(a[1], a[0], 0x07030602);
+        const uint32_t p23l = __builtin_amdgcn_perm(a[3], a[2], 0x05010400), p23h = __builtin_amdgcn_perm(a[3], a[2], 0x07030602);
+        uint4 t;
+        t.x = __builtin_amdgcn_perm(p23l, p01l, 0x05040100);
+        t.y = __builtin_amdgcn_perm(p23l, p01l, 0x07060302);
+        t.z = __builtin_amdgcn_perm(p23h, p01h, 0x05040100);
+        t.w = __builtin_amdgcn_perm(p23h, p01h, 0x07060302);
+        *reinterpret_cast<uint4*>(rp + yq * colsP + 4 * xq) = t;
+    }
+
+    uint32_t hbias = STRIP_HBIAS;
+    asm volatile("" : "+v"(hbias));
+    const int ncg = (cols + 7) >> 3, items = ncg * (SH / RI);
+    uint32_t prev_e[2][RI][2], prev_o[2][RI][2];
+    int item_cg[2], item_rg[2];
+    uint32_t item_off[2];
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii) {
+        const int it = tid + ii * 512;
+        item_cg[ii] = it % ncg, item_rg[ii] = it / ncg;
+        item_off[ii] = (uint32_t)(y0 + RI * item_rg[ii]) * (uint32_t)pitch + (uint32_t)(8 * item_cg[ii]);
+    }
+    const uint16_t* hp16 = reinterpret_cast<const uint16_t*>(hp);
+
+    for (int l = 0; l < VSLAM_NUM_LEVELS; ++l) {
+        const int n = taps->n[l], r = n >> 1, dl = r & 1, PL = r + dl;
+        __syncthreads();  // staging done (l = 0) / the previous level's horizontal reads of hp are done
+        // ---- vertical pass: band rows 4q .. 4q+3, columns 4cg .. 4cg+3 -> hp -------------------------
+        {
+            const int A = (RM - r) >> 2, delta = (RM - r) & 3;  // the window of band row 0 starts delta bytes into dword A of its column
+            const int M = ((delta + 3 + n - 1) >> 2) + 1;
+            const uint4* tab = reinterpret_cast<const uint4*>(&taps->v4[l][0][0]);
+            for (int it = tid; it < ncq * (SH / 4); it += 512) {
+                const int cg = it % ncq, q = it / ncq;
+                const uint4* col = reinterpret_cast<const uint4*>(rp + (q + A) * colsP + 4 * cg);
+                uint32_t acc[4][4];
+                switch (delta) {  // wave-uniform
+                    case 0: band_vertical_item<0>(col, colsP >> 2, tab, M, hbias, acc); break;
+                    case 1: band_vertical_item<1>(col, colsP >> 2, tab, M, hbias, acc); break;
+                    case 2: band_vertical_item<2>(col, colsP >> 2, tab, M, hbias, acc); break;
+                    default: band_vertical_item<3>(col, colsP >> 2, tab, M, hbias, acc); break;
+                }
+                uint32_t* d = hp + (4 * q) * pw + (PL >> 1) + 2 * cg;  // pair index of image column 4cg (PL is even)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    d[j * pw] = __builtin_amdgcn_perm(acc[j][1], acc[j][0], 0x05040100);
+                    d[j * pw + 1] = __builtin_amdgcn_perm(acc[j][3], acc[j][2], 0x05040100);
+                }
+            }
+        }
+        __syncthreads();
+        // ---- reflect-101 halos of the band's rows, copied inside LDS: PL/2 pairs left, PL/2 + 1 right -
+        {
+            const int nh = (PL >> 1) + 1;
+            for (int it = tid; it < SH * 2 * nh; it += 512) {
+                const int jr = it / (2 * nh), i = it - jr * (2 * nh);
+                const int pi = i < nh ? i - nh + (PL >> 1) : (cols >> 1) + (PL >> 1) + (i - nh);
+                if (pi < 0) continue;
+                const int x = 2 * pi - PL;
+                if (x >= 0 && x + 1 < cols) continue;
+                const uint16_t* row = hp16 + jr * 2 * pw + PL;  // element of image column 0
+                hp[jr * pw + pi] = (uint32_t)row[reflect101(x, cols)] | ((uint32_t)row[reflect101(x + 1, cols)] << 16);
+            }
+        }
+        __syncthreads();
+        // ---- horizontal pass + epilogue (as k_gauss_h_strip) ------------------------------------------
+        const int nb = (((7 + dl + 2 * r) >> 1) >> 2) + 1;
+        const uint32_t* tp = &taps->hp[l][0];
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+            const int it = tid + ii * 512;
+            if (it < items) {
+                const int cg = item_cg[ii], rg = item_rg[ii];
+                uint32_t acc[RI][8];
+                if (dl)
+                    h_item_level<1, RI>(hp + (RI * rg) * pw, pw, 8 * cg, nb, tp, acc);
+                else
+                    h_item_level<0, RI>(hp + (RI * rg) * pw, pw, 8 * cg, nb, tp, acc);
+                const int x = 8 * cg;
+#pragma unroll
+                for (int jr = 0; jr < RI; ++jr) {
+                    const int y = y0 + RI * rg + jr;
+                    uint32_t g[2], d[2] = {0, 0};
+#pragma unroll
+                    for (int hw = 0; hw < 2; ++hw) {
+                        const uint32_t e = __builtin_amdgcn_perm(acc[jr][4 * hw + 2], acc[jr][4 * hw + 0], 0x0c060c02);
+                        const uint32_t o = __builtin_amdgcn_perm(acc[jr][4 * hw + 3], acc[jr][4 * hw + 1], 0x0c060c02);
+                        g[hw] = __builtin_amdgcn_perm(o, e, 0x06020400);
+                        if (l > 0) d[hw] = __builtin_amdgcn_perm(pk_sub_sat_u16(o, prev_o[ii][jr][hw]), pk_sub_sat_u16(e, prev_e[ii][jr][hw]), 0x06020400);
+                        prev_e[ii][jr][hw] = e;
+                        prev_o[ii][jr][hw] = o;
+                    }
+                    if (y < rows) {
+                        const uint32_t off = item_off[ii] + (uint32_t)(jr * pitch);
+                        uint8_t* gp = out + (size_t)l * P;
+                        *reinterpret_cast<uint2*>(gp + off) = make_uint2(g[0], g[1]);
+                        if (l > 0) {
+                            uint8_t* dp = out + (size_t)(VSLAM_NUM_LEVELS + l - 1) * P;
+                            *reinterpret_cast<uint2*>(dp + off) = make_uint2(d[0], d[1]);
+                        }
+                        if (l == 3 && next_base && (y & 1) == 0 && (y >> 1) < nrows && (x >> 1) < ncols)
+                            *reinterpret_cast<uint32_t*>(next_base + blockIdx.z * nframe + (size_t)(y >> 1) * npitch + (x >> 1)) =
+                                __builtin_amdgcn_perm(g[1], g[0], 0x06040200);
+                    }
+                }
+            }
+        }
+    }
+}
+
 // Host side: build the tables for one octave.
 static bool strip_pack_taps(const uint16_t* const t[6], const int n[6], StripTaps& out) {
     memset(&out, 0, sizeof(out));

@@ -99,7 +99,7 @@ static int fail(vslam_ctx* c, int code, const std::string& msg) {
 static const char* const kKernelNames =
     "k_resize_linear2x\nk_blur_h_generic\nk_blur_v_generic\n"
     "k_dog5\nk_resize_nearest_half\nk_extrema\nk_pyr_octave\n"
-    "k_gauss_v_strip\nk_gauss_h_strip\nk_resize_linear2x_slide\nk_resize_nearest_half_v4\nk_extrema_w3\nk_extrema_dense\nk_localize_points\nk_orient_keypoints\nk_edge_response_windows\nk_level_gradients\nk_pack_rows\nk_edge_flags\nk_orient_survivors\n"
+    "k_gauss_v_strip\nk_gauss_h_strip\nk_gauss_band\nk_resize_linear2x_slide\nk_resize_nearest_half_v4\nk_extrema_w3\nk_extrema_dense\nk_localize_points\nk_orient_keypoints\nk_edge_response_windows\nk_level_gradients\nk_pack_rows\nk_edge_flags\nk_orient_survivors\n"
     "k_harris_strip\nk_flag_count\nk_chunk_scan\nk_flag_scatter\nk_level_gradients\nk_sift_descriptors\nk_pack_offsets\nk_pack_copy\nk_count_totals";
 
 static std::pair<hipEvent_t, hipEvent_t>* timing_slot(vslam_ctx* c);
@@ -177,9 +177,12 @@ struct StreamSwap {
 
 // Raises a kernel's dynamic shared memory ceiling to the most any launch of it may ask for.
 static constexpr int kMaxDynLds = 150 * 1024;
-static int raise_dyn_lds(vslam_ctx* c, const void* fn) {
+// What one workgroup may really take (160 KB on MI355X), read from the device at the first context
+// creation; only the fused band kernel plans against it (plan_octave), the other kernels stay below kMaxDynLds.
+static int g_lds_limit = kMaxDynLds;
+static int raise_dyn_lds(vslam_ctx* c, const void* fn, int limit = kMaxDynLds) {
     if (c->lds_raised.count(fn)) return VSLAM_OK;
-    HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds));
+    HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, limit));
     c->lds_raised.insert(fn);
     return VSLAM_OK;
 }
@@ -260,7 +263,7 @@ static inline dim3 grid_rows(int cols, int rows, int frames = 1) { return dim3((
 // ---------------------------------------------------------------- enqueue helpers (device)
 
 // ---- octave path selection -----------------------------------------------------------------
-enum class OctPath { Tile0, Tile1, Strip, Generic };
+enum class OctPath { Tile0, Tile1, Band, Strip, Generic };
 
 struct OctPlan {
     OctPath path = OctPath::Generic;
@@ -269,6 +272,8 @@ struct OctPlan {
     int ke[6] = {};                 // zero-trimmed widths the fast kernels run with
     std::vector<uint16_t> taps[6];  // trimmed taps
     int sh = 0;                     // rows per horizontal strip workgroup
+    int band_sh = 0, band_ri = 0, band_rm = 0, band_colsP = 0, band_pw = 0;  // fused band kernel (OctPath::Band)
+    size_t band_lds = 0;
 };
 
 static bool taps_fit_u8(const OctPlan& pl) {
@@ -310,6 +315,24 @@ static OctPlan plan_octave(double sigma0, int o, int rows, int cols) {
         pl.sh = cols <= 1024 ? 16 : cols <= 2048 ? 8 : cols <= 4096 ? 4 : 0;
         const size_t pw = (size_t)strip_pw(cols, nmax);
         if (pl.sh && v_lds <= 150 * 1024 && pl.sh * pw * 4 <= 150 * 1024) pl.path = OctPath::Strip;
+        // the fused band kernel (both passes in one launch, row sums stay in LDS) when a band of 16 or 8 rows
+        // with its vertical halo fits one CU's LDS and gives every thread at most two horizontal items
+        static const bool use_band = [] {
+            const char* e = std::getenv("VSLAM_BAND_KERNEL");
+            return !(e && e[0] == '0');
+        }();
+        if (use_band && pl.path == OctPath::Strip) {
+            const int colsP = ((cols + 3) & ~3) + 4;  // dword pitch of a row quad (+4: spreads the quads over the banks)
+            for (int sh : {16, 8}) {
+                const size_t lds = ((size_t)((sh + 2 * RM) / 4 + 1) * colsP + (size_t)sh * pw) * 4;
+                const int ri = ((cols + 7) / 8) * (sh / 2) <= 1024 ? 2 : 4;
+                if (lds <= (size_t)g_lds_limit && ((cols + 7) / 8) * (sh / ri) <= 1024) {
+                    pl.path = OctPath::Band;
+                    pl.band_sh = sh, pl.band_ri = ri, pl.band_rm = RM, pl.band_colsP = colsP, pl.band_pw = (int)pw, pl.band_lds = lds;
+                    break;
+                }
+            }
+        }
     }
     return pl;
 }
@@ -385,6 +408,30 @@ static int enqueue_strip_octave(vslam_ctx* c, double sigma0, int o, const OctPla
     }
 }
 
+
+// Coarse octave, fused: one launch, the row sums stay in LDS (k_gauss_band).
+template <int SH, int RI>
+static int launch_band(vslam_ctx* c, const OctPlan& pl, const StripTaps* taps, const uint8_t* base, size_t bframe, uint8_t* oct, size_t pframe,
+                       int rows, int cols, int pitch, int nf, uint8_t* next_base, size_t nframe, int nrows, int ncols, int npitch) {
+    TRY(raise_dyn_lds(c, reinterpret_cast<const void*>(&k_gauss_band<SH, RI>), g_lds_limit));  // no static LDS in this kernel
+    {
+        TimedScope ts(c, "k_gauss_band");
+        hipLaunchKernelGGL((k_gauss_band<SH, RI>), dim3(1, (rows + SH - 1) / SH, nf), dim3(512), pl.band_lds, c->stream, base, bframe, oct, pframe, rows,
+                           cols, pitch, pl.band_rm, pl.band_colsP, pl.band_pw, taps, next_base, nframe, nrows, ncols, npitch);
+    }
+    HIPCHK(c, hipGetLastError());
+    return VSLAM_OK;
+}
+static int enqueue_band_octave(vslam_ctx* c, double sigma0, int o, const OctPlan& pl, const uint8_t* base, size_t bframe, uint8_t* oct,
+                               size_t pframe, int rows, int cols, int pitch, int nf, uint8_t* next_base, size_t nframe, int nrows, int ncols,
+                               int npitch) {
+    const StripTaps* taps;
+    TRY(get_strip_taps(c, sigma0, o, pl, &taps));
+#define VSLAM_BAND(SH, RI) launch_band<SH, RI>(c, pl, taps, base, bframe, oct, pframe, rows, cols, pitch, nf, next_base, nframe, nrows, ncols, npitch)
+    if (pl.band_sh == 16) return pl.band_ri == 2 ? VSLAM_BAND(16, 2) : VSLAM_BAND(16, 4);
+    return pl.band_ri == 2 ? VSLAM_BAND(8, 2) : VSLAM_BAND(8, 4);
+#undef VSLAM_BAND
+}
 
 // GaussianBlur CV_8U on nf dense images; h = u16 scratch of nf*rows*cols elements.
 static int enqueue_blur(vslam_ctx* c, const uint8_t* src, size_t sstep, size_t sframe, uint8_t* dst, size_t dstep,
@@ -638,6 +685,8 @@ static int enqueue_dog(vslam_ctx* c, const vslam_params& p, const vslam_batch_la
             TRY(tiled(nf_a, nf - nf_a));
         } else if (is_tiled)
             TRY(tiled(0, nf));
+        else if (pl.path == OctPath::Band)
+            TRY(enqueue_band_octave(c, p.sigma0, o, pl, base, s.bases_frame, oct, pframe, rows, cols, pitch, nf, nb, s.bases_frame, nr, nc, np));
         else if (pl.path == OctPath::Strip)
             TRY(enqueue_strip_octave(c, p.sigma0, o, pl, base, s.bases_frame, oct, pframe, s.h, rows, cols, pitch, nf, nb, s.bases_frame, nr, nc, np));
         else {
@@ -779,6 +828,11 @@ int vslam_ctx_create(int device, void* stream, vslam_ctx** out) {
     vslam_ctx* c = new (std::nothrow) vslam_ctx();
     if (!c) return VSLAM_ERR_NOMEM;
     c->device = device;
+    {
+        int lds = 0;
+        if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess && lds > kMaxDynLds) g_lds_limit = lds;
+        (void)hipGetLastError();
+    }
     if (stream == VSLAM_STREAM_LEGACY) {
         c->stream = nullptr;  // the NULL stream itself: every HIP call below takes it as "stream 0"
     } else if (stream) {
