@@ -315,11 +315,15 @@ static OctPlan plan_octave(double sigma0, int o, int rows, int cols) {
         pl.sh = cols <= 1024 ? 16 : cols <= 2048 ? 8 : cols <= 4096 ? 4 : 0;
         const size_t pw = (size_t)strip_pw(cols, nmax);
         if (pl.sh && v_lds <= 150 * 1024 && pl.sh * pw * 4 <= 150 * 1024) pl.path = OctPath::Strip;
-        // the fused band kernel (both passes in one launch, row sums stay in LDS) when a band of 16 or 8 rows
-        // with its vertical halo fits one CU's LDS and gives every thread at most two horizontal items
+        // The fused band kernel (both passes in one launch, row sums stay in LDS) when a band of 16 or 8 rows
+        // with its vertical halo fits one CU's LDS and gives every thread at most two horizontal items.
+        // OPT-IN (VSLAM_BAND_KERNEL=1), not the default: measured on MI355X, 256 x 1080p, same box, it takes
+        // 2.9 ms per launch against 1.9 ms for the two strip kernels of the same octave (20.1 vs 18.05 ms per
+        // step): the band's base rows fill the LDS, so one workgroup = 2 waves per SIMD runs per CU with three
+        // barriers per level, and that costs more than the 15.5 MB per frame of scratch traffic it removes.
         static const bool use_band = [] {
             const char* e = std::getenv("VSLAM_BAND_KERNEL");
-            return !(e && e[0] == '0');
+            return e && e[0] == '1';
         }();
         if (use_band && pl.path == OctPath::Strip) {
             const int colsP = ((cols + 3) & ~3) + 4;  // dword pitch of a row quad (+4: spreads the quads over the banks)
