@@ -1,8 +1,10 @@
-"""PCIe-inclusive throughput of the batched path: frames start in pinned host memory and the
+"""PCIe-inclusive throughput of the batched path from Python: frames start in pinned host memory and the
 keypoint lists end there.  Double-buffered: the upload of batch k+1 and the download of batch
-k-1's lists overlap the kernels of batch k (three streams).  Prints one JSON line.
+k-1's lists overlap the kernels of batch k (three streams).  Since round 3 the lists are packed on the
+device (vslam_pack_lists_dev) and only the records that exist are downloaded.  Prints one JSON line.
+The C++ form of this pipeline is visualslam_amd/cxx/batch_detector.hpp (`Stream --mode hostfed`).
 
-    python tools/bench_hostfed.py [--frames 256 --steps 6]
+    python tools/bench_hostfed.py [--frames 256 --steps 40]
 """
 import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,7 +15,7 @@ from visualslam_amd import capi, synth
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=256)
-    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--rows", type=int, default=1080)
     ap.add_argument("--cols", type=int, default=1920)
     a = ap.parse_args()
@@ -26,8 +28,8 @@ def main():
     p = capi.default_params(rows, cols)
     L = capi.batch_layout(p)
     host_frames = synth.frames_torch(n, rows, cols).pin_memory()
-    # per-frame lists come back trimmed to a fixed budget (the counts say how many are valid)
-    hk_keep, dp_keep = 1 << 16, 80 * 1024
+    # the lists come back packed: sum over frames of min(count, cap) records, against a per-batch budget
+    hk_budget, dp_budget = n * (1 << 17), n * (1 << 17)
     bufs = []
     for _ in range(2):
         bufs.append(dict(
@@ -36,9 +38,11 @@ def main():
             harris_counts=torch.zeros(n, dtype=torch.int32, device=dev),
             dog_points=torch.empty((n, p.dog_cap, 6), dtype=torch.int32, device=dev),
             dog_counts=torch.zeros(n, dtype=torch.int32, device=dev),
-            h_kps=torch.empty((n, hk_keep, 3), dtype=torch.int32).pin_memory(),
-            h_pts=torch.empty((n, dp_keep, 6), dtype=torch.int32).pin_memory(),
-            h_cnt=torch.empty((2, n), dtype=torch.int32).pin_memory(),
+            d_kps=torch.empty((hk_budget, 3), dtype=torch.int32, device=dev), d_pts=torch.empty((dp_budget, 6), dtype=torch.int32, device=dev),
+            d_off=torch.zeros((2, n + 1), dtype=torch.int64, device=dev),
+            h_kps=torch.empty((hk_budget, 3), dtype=torch.int32).pin_memory(),
+            h_pts=torch.empty((dp_budget, 6), dtype=torch.int32).pin_memory(),
+            h_off=torch.zeros((2, n + 1), dtype=torch.int64).pin_memory(),
             up_done=torch.cuda.Event(), comp_done=torch.cuda.Event(), down_done=torch.cuda.Event()))
     shared = dict(response=torch.empty((n, rows, cols), dtype=torch.float32, device=dev),
                   nms_mask=torch.empty((n, rows, cols), dtype=torch.uint8, device=dev),
@@ -57,40 +61,44 @@ def main():
         with torch.cuda.stream(compute):
             ctx.detect_batch(p, b["frames"], harris_kps=b["harris_kps"], harris_counts=b["harris_counts"],
                              dog_points=b["dog_points"], dog_counts=b["dog_counts"], **shared)
+            ctx.pack_lists(b["harris_kps"], b["harris_counts"], b["d_kps"], b["d_off"][0])
+            ctx.pack_lists(b["dog_points"], b["dog_counts"], b["d_pts"], b["d_off"][1])
+            b["h_off"].copy_(b["d_off"], non_blocking=True)
             b["comp_done"].record(compute)
 
     def download(b):
+        b["comp_done"].synchronize()  # the offsets are on the host: only the records that exist travel
+        nh, nd = min(int(b["h_off"][0, n]), hk_budget), min(int(b["h_off"][1, n]), dp_budget)
         with torch.cuda.stream(down):
-            down.wait_event(b["comp_done"])
-            b["h_kps"].copy_(b["harris_kps"][:, :hk_keep], non_blocking=True)
-            b["h_pts"].copy_(b["dog_points"][:, :dp_keep], non_blocking=True)
-            b["h_cnt"][0].copy_(b["harris_counts"], non_blocking=True)
-            b["h_cnt"][1].copy_(b["dog_counts"], non_blocking=True)
+            b["h_kps"][:nh].copy_(b["d_kps"][:nh], non_blocking=True)
+            b["h_pts"][:nd].copy_(b["d_pts"][:nd], non_blocking=True)
             b["down_done"].record(down)
+        return nh, nd
 
     for b in bufs:
         b["comp_done"].record(compute)
         b["down_done"].record(down)
-    # warm-up + steady state
-    for phase, steps in (("warm", 2), ("timed", a.steps)):
+    # warm-up + steady state: batch s+1 is uploaded and enqueued before the host waits for batch s
+    for phase, steps in (("warm", 3), ("timed", a.steps)):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         upload(bufs[0])
+        run(bufs[0])
         for s in range(steps):
             cur, nxt = bufs[s % 2], bufs[(s + 1) % 2]
             if s + 1 < steps:
+                nxt["down_done"].synchronize()
                 upload(nxt)
-            run(cur)
-            download(cur)
+                run(nxt)
+            nh, nd = download(cur)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-    hk = int(bufs[0]["h_cnt"][0].max()); dp = int(bufs[0]["h_cnt"][1].max())
     up_bytes = n * rows * cols
-    down_bytes = n * (hk_keep * 12 + dp_keep * 24 + 8)
-    print(json.dumps({"mode": "host-fed, double-buffered, lists downloaded", "frames_per_batch": n, "steps": a.steps,
+    down_bytes = nh * 12 + nd * 24 + 16 * (n + 1)
+    print(json.dumps({"mode": "host-fed from Python, double-buffered, packed lists downloaded", "frames_per_batch": n, "steps": a.steps,
                       "frames_per_sec": n * a.steps / dt, "ms_per_batch": dt / a.steps * 1e3,
                       "upload_MB_per_batch": up_bytes / 1e6, "download_MB_per_batch": down_bytes / 1e6,
-                      "max_harris_per_frame": hk, "max_dog_per_frame": dp, "list_budget": [hk_keep, dp_keep]}))
+                      "harris_records_per_batch": nh, "dog_records_per_batch": nd}))
 
 
 if __name__ == "__main__":

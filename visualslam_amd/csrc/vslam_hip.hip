@@ -152,7 +152,10 @@ static int ensure_aux(vslam_ctx* c) {
         prio_lo = 0;
     }
     for (int i = 0; i < vslam_ctx::kAux; ++i) {
-        if (hipStreamCreateWithPriority(&c->aux[i], hipStreamNonBlocking, prio_lo) != hipSuccess) {
+        // aux[0], aux[1] (Harris chain, scans and lists) yield to the octave kernels; aux[2] carries only the
+        // second-half upsample, which the main stream WAITS for: at low priority it was starved for the whole
+        // first-half octave kernel whenever its start slipped behind that kernel's (C++ host, 0.35 ms per step)
+        if (hipStreamCreateWithPriority(&c->aux[i], hipStreamNonBlocking, i == 2 ? 0 : prio_lo) != hipSuccess) {
             (void)hipGetLastError();  // priorities are a speed matter only
             HIPCHK(c, hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking));
         }

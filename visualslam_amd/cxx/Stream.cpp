@@ -26,6 +26,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
@@ -40,7 +41,7 @@ namespace {
 struct Args {
     std::string mode = "device", source = "synth", dump;
     int frames = 256, batches = 8, warmup = 2, rows = 1080, cols = 1920, octaves = 4;
-    bool rdv_selftest = false, no_allgather = false;
+    bool rdv_selftest = false, no_allgather = false, no_rccl = false;
 };
 
 Args parse(int argc, char** argv) {
@@ -62,6 +63,7 @@ Args parse(int argc, char** argv) {
         else if (k == "--dump") a.dump = val();
         else if (k == "--rdv-selftest") a.rdv_selftest = true;
         else if (k == "--no-allgather") a.no_allgather = true;  // diagnosis only: the per-step collective left out
+        else if (k == "--no-rccl") a.no_rccl = true;            // diagnosis only: single rank without a communicator
         else throw std::runtime_error("unknown argument " + k);
     }
     if ((a.mode != "device" && a.mode != "hostfed") || a.frames <= 0 || a.batches <= 0 || a.warmup < 0 || a.rows <= 0 || a.cols <= 0 || a.octaves < 0)
@@ -157,7 +159,35 @@ int main(int argc, char** argv) {
             opt.params.n_octaves = a.octaves;
         }
         vslam::BatchDetector det(opt);
-        vslam::CountExchange ex(env, device);  // RCCL communicator over all ranks (collective)
+        // RCCL communicator over all ranks (collective).  --no-rccl (diagnosis, one rank only): no communicator at
+        // all, the "all-gather" of the single rank is a 16-byte device copy.
+        struct Exchange {
+            std::unique_ptr<vslam::CountExchange> cx;
+            uint64_t* d_one = nullptr;
+            int rank = 0;
+            void all_gather_async(const uint64_t* d_local, void* s) {
+                if (cx) return cx->all_gather_async(d_local, s);
+                (void)hipMemcpyAsync(d_one, d_local, 16, hipMemcpyDeviceToDevice, (hipStream_t)s);
+            }
+            std::vector<uint64_t> fetch(void* s) {
+                if (cx) return cx->fetch(s);
+                std::vector<uint64_t> v(2);
+                (void)hipMemcpyAsync(v.data(), d_one, 16, hipMemcpyDeviceToHost, (hipStream_t)s);
+                (void)hipStreamSynchronize((hipStream_t)s);
+                return v;
+            }
+            void barrier(void* s) {
+                if (cx) return cx->barrier(s);
+                (void)hipStreamSynchronize((hipStream_t)s);
+            }
+            double max_over_ranks(double v, void* s) { return cx ? cx->max_over_ranks(v, s) : v; }
+        } ex;
+        if (a.no_rccl) {
+            if (env.world != 1) throw std::runtime_error("--no-rccl is for single-rank runs");
+            if (hipMalloc((void**)&ex.d_one, 16) != hipSuccess || hipMemset(ex.d_one, 0, 16) != hipSuccess) throw std::runtime_error("hipMalloc");
+        } else {
+            ex.cx = std::make_unique<vslam::CountExchange>(env, device);
+        }
         const hipStream_t cs = (hipStream_t)det.stream();
 
         // the camera stream: stream_id = rank.  One batch of frames in pinned host memory.
