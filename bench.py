@@ -203,6 +203,8 @@ def main():
         """K timed steps of one list mode; returns per-mode results (times: max over ranks)."""
         frames_t = frames if frames_t is None else frames_t
         p = capi.default_params(rows, cols, n_octaves=args.octaves, localize=1 if orient else localize, orient=orient, extrema_dense=dense)
+        if dense:  # every pixel of three levels is a site: a noise frame has ~4x the candidates of the lattice test's worst case
+            p.dog_cap = 4 * p.dog_cap
         L = capi.batch_layout(p)
         if dense:  # the dense scan has its own (larger) bitmask; every other buffer is shared
             if "dense_bits" not in shared:
@@ -221,6 +223,7 @@ def main():
         out = {k: v for k, v in shared.items() if k != "dense_bits"}
         if dense:
             out["extrema_bits"] = shared["dense_bits"]
+            out["dog_points"] = torch.empty((n, p.dog_cap, 6), dtype=torch.int32, device=dev)
         if orient:
             out["oriented_points"] = torch.empty((n, p.oriented_cap, 6), dtype=torch.int32, device=dev)
             out["oriented_counts"] = torch.zeros(n, dtype=torch.int32, device=dev)

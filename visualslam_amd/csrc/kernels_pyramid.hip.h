@@ -69,7 +69,10 @@ struct PyrCfg {
     static constexpr int T4M = ((3 + NMAX - 1) >> 2) + 1;  // tap dwords per alignment
     static constexpr int TPM = NMAX + 1;                   // tap pairs
     static constexpr int LDS_BYTES = (RQ * RWP + TH * HPP) * 4;
-    static_assert(TW % 16 == 0 && TH % 8 == 0 && (TH / 4) * (TW / 8) == 256, "one pass-2 item per thread");
+    static constexpr int NT = (TH / 4) * (TW / 8);  // threads per workgroup: one pass-2 item (8 columns x 4 rows) each
+    static constexpr int NW = NT / 64;
+    static_assert(TW % 16 == 0 && TH % 8 == 0 && NT % 256 == 0 && NT <= 1024,
+                  "a multiple of four waves, one per SIMD: 384-thread workgroups (384 x 32 tiles) ran 16 % slower, their six waves sit 2-2-1-1");
     static_assert((N0 & 1) && (N1 & 1) && (N2 & 1) && (N3 & 1) && (N4 & 1) && (N5 & 1), "odd kernels");
 };
 
@@ -102,11 +105,12 @@ __device__ __forceinline__ void pyr_level(const PyrTaps<CFG>* __restrict__ taps,
     // always falls on wave 0 - 18 item rounds per tile against 12 for each other wave - and the waves of
     // a workgroup sit on different SIMDs, so one SIMD of the CU carries the excess of every resident
     // workgroup.  Rotating the partial round over the waves with the level evens it out (+1.1 % frames/s).
-    constexpr int N1 = NCG * (TH / 4), FULL1 = N1 / 256 * 256;
-    for (int k = 0; k < (N1 + 255) / 256; ++k) {
-        int it = tid + 256 * k;
-        if (k == N1 / 256) {
-            it = FULL1 + ((tid - 64 * (L & 3)) & 255);
+    constexpr int NT = CFG::NT;
+    constexpr int N1 = NCG * (TH / 4), FULL1 = N1 / NT * NT;
+    for (int k = 0; k < (N1 + NT - 1) / NT; ++k) {
+        int it = tid + NT * k;
+        if (k == N1 / NT) {
+            it = FULL1 + (tid + NT - 64 * (L % CFG::NW)) % NT;
             if (it >= N1) break;
         }
         const int cg = it % NCG, rq = it / NCG;
@@ -145,7 +149,7 @@ __device__ __forceinline__ void pyr_level(const PyrTaps<CFG>* __restrict__ taps,
     uint32_t z2;
     asm volatile("s_mov_b32 %0, 0" : "=s"(z2));
     const uint32_t* __restrict__ tp = &taps->tp[L][0] + z2;
-    const int xg = tid & (CFG::TW / 8 - 1), rg = tid / (CFG::TW / 8);
+    const int xg = tid % (CFG::TW / 8), rg = tid / (CFG::TW / 8);
     uint32_t acc[4][8];
 #pragma unroll
     for (int jr = 0; jr < 4; ++jr)
@@ -218,11 +222,12 @@ __device__ __forceinline__ void pyr_level(const PyrTaps<CFG>* __restrict__ taps,
     }
 }
 
-// grid = (ceil(cols/TW), ceil(rows/TH), frames); block = 256; dynamic LDS = CFG::LDS_BYTES.
+// grid = (ceil(cols/TW), ceil(rows/TH), frames); block = CFG::NT (256 for the 128 x 64 and 256 x 32 tiles);
+// dynamic LDS = CFG::LDS_BYTES.
 // rows / cols arbitrary; `pitch` (row pitch of the base and of every output plane) and `npitch`
 // (next base) are multiples of 16 and >= the width rounded up to 8 (8-byte row stores).
 template <class CFG>
-__global__ __launch_bounds__(256) void k_pyr_octave(const uint8_t* __restrict__ base, size_t bframe,
+__global__ __launch_bounds__(CFG::NT) void k_pyr_octave(const uint8_t* __restrict__ base, size_t bframe,
                                                      uint8_t* __restrict__ oct_out, size_t pframe, int rows, int cols,
                                                      int pitch, const PyrTaps<CFG>* __restrict__ taps,
                                                      uint8_t* __restrict__ next_base, size_t nframe, int nrows, int ncols,
@@ -253,7 +258,7 @@ __global__ __launch_bounds__(256) void k_pyr_octave(const uint8_t* __restrict__ 
     if (interior) {
         // 16 pixels x 4 rows per item: 16-byte coalesced loads, four 4x4 byte transposes, four
         // 16-byte LDS stores (RW is a multiple of 16, tile origin - R is 16-byte aligned)
-        for (int it = tid; it < RQ * (RW / 16); it += 256) {
+        for (int it = tid; it < RQ * (RW / 16); it += CFG::NT) {
             const int yq = it / (RW / 16), xs = it - yq * (RW / 16);
             const uint8_t* p = src + (size_t)(tile_y0 - R + 4 * yq) * pitch + (tile_x0 - R + 16 * xs);
             uint4 a[4];
@@ -275,7 +280,7 @@ __global__ __launch_bounds__(256) void k_pyr_octave(const uint8_t* __restrict__ 
         }
     } else {
         // border tiles: one dword x 4 rows per item, BORDER_REFLECT_101 resolved per byte
-        for (int it = tid; it < RQ * (RW / 4); it += 256) {
+        for (int it = tid; it < RQ * (RW / 4); it += CFG::NT) {
             const int yq = it / (RW / 4), xq = it - yq * (RW / 4);
             const int gy = tile_y0 - R + 4 * yq, gx = tile_x0 - R + 4 * xq;
             uint32_t a[4];
@@ -305,7 +310,7 @@ __global__ __launch_bounds__(256) void k_pyr_octave(const uint8_t* __restrict__ 
     // 32-bit multiplies are quarter rate, and the offsets do not depend on the level
     uint32_t row_off[4];
     {
-        const int xg = tid & (CFG::TW / 8 - 1), rg = tid / (CFG::TW / 8);
+        const int xg = tid % (CFG::TW / 8), rg = tid / (CFG::TW / 8);
 #pragma unroll
         for (int jr = 0; jr < 4; ++jr)
             row_off[jr] = (uint32_t)(tile_y0 + 4 * rg + jr) * (uint32_t)pitch + (uint32_t)(tile_x0 + 8 * xg);

@@ -579,7 +579,7 @@ static int enqueue_pyr_octave(vslam_ctx* c, double sigma0, int o, const OctPlan&
     const dim3 grid((cols + CFG::TW - 1) / CFG::TW, (rows + CFG::TH - 1) / CFG::TH, nf);
     {
         TimedScope ts(c, "k_pyr_octave");
-        hipLaunchKernelGGL(k_pyr_octave<CFG>, grid, dim3(256), CFG::LDS_BYTES, c->stream, base, bframe, oct_out, pframe, rows,
+        hipLaunchKernelGGL(k_pyr_octave<CFG>, grid, dim3(CFG::NT), CFG::LDS_BYTES, c->stream, base, bframe, oct_out, pframe, rows,
                            cols, pitch, taps, next_base, nframe, nrows, ncols, npitch);
     }
     HIPCHK(c, hipGetLastError());
@@ -647,6 +647,8 @@ static int enqueue_dog(vslam_ctx* c, const vslam_params& p, const vslam_batch_la
     // chunk's whole list chain.  It overwrites bases the previous chunk's octave kernels (main stream)
     // read, and nothing else orders it behind them - with pyramid-only outputs there is not even a scan
     // waiting on ev_oct - so it waits for ev_chunk, recorded at the end of every chunk's main-stream work.
+    // (quarters and eighths were measured again in round 3 with the side upsample at normal priority: 21.41 /
+    // 21.44 ms against 21.29 for halves in the same configuration - no gain)
     const int nf_a = (side && up && nf >= 64) ? nf / 2 : nf;
     LAUNCH(c, "k_resize_linear2x_slide", k_resize_linear2x_slide, dim3(((p.cols + 3) / 4 + 255) / 256, (p.rows + 15) / 16, nf_a), dim3(256),
            frames, fstep, fframe, s.bases + s.base_off[0], s.bases_frame, L.pitch[0], p.rows, p.cols, 16);
@@ -669,20 +671,19 @@ static int enqueue_dog(vslam_ctx* c, const vslam_params& p, const vslam_batch_la
         const bool fuse_next = has_next && pl.path != OctPath::Generic;
         uint8_t* nb = fuse_next ? s.bases + s.base_off[o + 1] : nullptr;
         const int nr = has_next ? L.rows[o + 1] : 0, nc = has_next ? L.cols[o + 1] : 0, np = has_next ? L.pitch[o + 1] : 0;
-        // tile shape: the wide tile when it needs no more tile area than the tall one
-        const bool wide = (long)((cols + 255) / 256) * ((rows + 31) / 32) <= (long)((cols + 127) / 128) * ((rows + 63) / 64);
+        // tile shape: the wide tile (256 x 32) when it needs no more tile area than the tall one (128 x 64).
+        // A 384 x 32 tile (1920 = 5 x 384) on 384-thread workgroups was measured in round 3: six waves per
+        // workgroup sit 2-2-1-1 on the four SIMDs and meet at every barrier: 21.3 vs 18.3 ms per step.
+        const int shape = (long)((cols + 255) / 256) * ((rows + 31) / 32) <= (long)((cols + 127) / 128) * ((rows + 63) / 64) ? 1 : 0;
         // frames [f_lo, f_lo + n) of this octave through the LDS-tiled kernel
         auto tiled = [&](int f_lo, int n) -> int {
             const uint8_t* b = base + (size_t)f_lo * s.bases_frame;
             uint8_t* oc = oct + (size_t)f_lo * pframe;
             uint8_t* nbh = nb ? nb + (size_t)f_lo * s.bases_frame : nullptr;
-            if (pl.path == OctPath::Tile0 && wide)
-                return enqueue_pyr_octave<PyrCfgOct0W>(c, p.sigma0, o, pl, b, s.bases_frame, oc, pframe, rows, cols, pitch, n, nbh, s.bases_frame, nr, nc, np);
-            if (pl.path == OctPath::Tile0)
-                return enqueue_pyr_octave<PyrCfgOct0>(c, p.sigma0, o, pl, b, s.bases_frame, oc, pframe, rows, cols, pitch, n, nbh, s.bases_frame, nr, nc, np);
-            if (wide)
-                return enqueue_pyr_octave<PyrCfgOct1W>(c, p.sigma0, o, pl, b, s.bases_frame, oc, pframe, rows, cols, pitch, n, nbh, s.bases_frame, nr, nc, np);
-            return enqueue_pyr_octave<PyrCfgOct1>(c, p.sigma0, o, pl, b, s.bases_frame, oc, pframe, rows, cols, pitch, n, nbh, s.bases_frame, nr, nc, np);
+#define VSLAM_TILED(CFG) enqueue_pyr_octave<CFG>(c, p.sigma0, o, pl, b, s.bases_frame, oc, pframe, rows, cols, pitch, n, nbh, s.bases_frame, nr, nc, np)
+            if (pl.path == OctPath::Tile0) return shape == 1 ? VSLAM_TILED(PyrCfgOct0W) : VSLAM_TILED(PyrCfgOct0);
+            return shape == 1 ? VSLAM_TILED(PyrCfgOct1W) : VSLAM_TILED(PyrCfgOct1);
+#undef VSLAM_TILED
         };
         const bool is_tiled = pl.path == OctPath::Tile0 || pl.path == OctPath::Tile1;
         if (o == 0 && nf_a < nf && !is_tiled) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_up2, 0));  // octave 0 needs every base
