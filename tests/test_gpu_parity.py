@@ -352,3 +352,20 @@ def test_process_gradients(ctx, shape, n_oct):
     with pytest.raises(capi.VslamError):
         got.gradients(0, 6)
     got.close()
+
+
+def test_fast_correctly_rounded_sqrt_is_exhaustively_exact(tmp_path):
+    # round 3: the magnitudes (cv::magnitude of integer Sobel differences) use a 9-instruction correctly
+    # rounded f32 square root instead of the f64 one; every argument that can occur (0 .. 2*255^2) is compared
+    import json
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "sqrt_check")
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-o", exe, os.path.join(root, "tools", "sqrt_check.hip")],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert r.returncode == 0 and out["mismatches"] == 0 and out["checked"] == 2 * 255 * 255 + 1, out

@@ -296,9 +296,7 @@ __global__ __launch_bounds__(256) void k_level_gradients(const uint8_t* __restri
     if (gy) gy[o] = y;
     if (mag) {
         const float xx = x * x, yy = y * y;
-        // IEEE-correct f32 square root: sqrt in f64 then one rounding (53 >= 2*24 + 2 bits), because
-        // the f32 hardware sqrt is not correctly rounded
-        mag[o] = (float)sqrt((double)(xx + yy));
+        mag[o] = sqrt_rn_small(xx + yy);  // IEEE-correct f32 square root (the bare v_sqrt_f32 is not)
     }
     if (orient) orient[o] = fast_atan2_deg(y, x);
 }

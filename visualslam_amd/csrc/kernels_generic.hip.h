@@ -22,6 +22,21 @@ __device__ __forceinline__ int reflect101(int p, int len) {
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+// Correctly rounded f32 square root (cv::magnitude on x86 is sqrtss / sqrtps) for the arguments this
+// library has: x*x + y*y of integer Sobel differences, i.e. integers in [0, 2 * 255^2] - normal numbers
+// or zero, so the denormal scaling of the general sequence is not needed.  v_sqrt_f32 is within one ulp;
+// the two exact residuals (one FMA each) decide between the result and its neighbours.  9 instructions
+// instead of the f64 square root the round-2 kernels used (tools/sqrt_check.hip compares the two over
+// every possible argument).
+__device__ __forceinline__ float sqrt_rn_small(float x) {
+    float s = __builtin_amdgcn_sqrtf(x);
+    const float sm = __uint_as_float(__float_as_uint(s) - 1u), sp = __uint_as_float(__float_as_uint(s) + 1u);
+    const float rm = __builtin_fmaf(-sm, s, x), rp = __builtin_fmaf(-sp, s, x);
+    s = rm <= 0.0f ? sm : s;  // s*(s - ulp) >= x: the result was one ulp high
+    s = rp > 0.0f ? sp : s;   // s*(s + ulp) <  x: one ulp low
+    return s;
+}
+
 // cv::convertScaleAbs element as the reference's x86-64 OpenCV evaluates it: cvRound (cvtss2si /
 // cvtps2dq, round half even) returns INT_MIN for NaN and for |x| >= 2^31, which
 // saturate_cast<uchar> maps to 0; [255.5, 2^31) saturates to 255.

@@ -77,7 +77,7 @@ __device__ __forceinline__ float magnitude_at(const uint8_t* __restrict__ G, int
     float x, y;
     gradient_at(G, gpitch, rows, cols, r, c, x, y);
     const float xx = x * x, yy = y * y;
-    return (float)sqrt((double)(xx + yy));  // correctly rounded f32 square root
+    return sqrt_rn_small(xx + yy);  // correctly rounded f32 square root
 }
 
 // grid = (G, frames), 256 threads, dynamic LDS = lds_floats * 4 bytes (row / column maps + strip + region);
@@ -89,8 +89,7 @@ __global__ __launch_bounds__(256) void k_orient_survivors(const vslam_point* __r
                                                            unsigned long long* __restrict__ masks) {
     extern __shared__ __attribute__((aligned(16))) float orient_smem[];
     __shared__ float mw[OR_WIN * OR_WIN];
-    __shared__ uint8_t bin[OR_WIN * OR_WIN];
-    __shared__ float histo[OR_BINS];
+    __shared__ unsigned long long binmask[OR_BINS][4];  // per bin, per wave: which of the wave's 64 pixels fall into it
     const int f = blockIdx.y;
     const unsigned int ns = min(scounts[f], scap);
     for (unsigned int k = blockIdx.x; k < ns; k += gridDim.x) {
@@ -137,6 +136,7 @@ __global__ __launch_bounds__(256) void k_orient_survivors(const vslam_point* __r
             }
         }
         __syncthreads();
+        int bin_of;
         {
             const int i = threadIdx.x >> 4, j = threadIdx.x & 15;
             float s0 = kt[R] * rb[(i + R) * OR_WIN + j];
@@ -146,21 +146,39 @@ __global__ __launch_bounds__(256) void k_orient_survivors(const vslam_point* __r
             gradient_at(G, gpitch, rows, cols, clampi(y + i - OR_PAD, 0, rows - 1), clampi(x + j - OR_PAD, 0, cols - 1), gx, gy);
             const float reductionCoeff = (float)OR_BINS / 360.0f;            // :114
             const int index = (int)(fast_atan2_deg(gy, gx) * reductionCoeff);  // :126
-            bin[threadIdx.x] = (uint8_t)min(max(index, 0), OR_BINS - 1);
+            bin_of = min(max(index, 0), OR_BINS - 1);
         }
-        __syncthreads();
-        if (threadIdx.x < OR_BINS) {  // one lane per bin, pixels in row-major order: the reference's += order
-            float h = 0.0f;
-            for (int p = 0; p < OR_WIN * OR_WIN; ++p)
-                if (bin[p] == threadIdx.x) h += mw[p];
-            histo[threadIdx.x] = h;
+        // The histogram (:112-133) adds a bin's magnitudes in pixel order; a lane per bin walking all 256 pixels
+        // (round 2) kept one wave busy for 256 dependent iterations while three waited.  Each wave now ballots
+        // its 64 pixels bin by bin (ascending pixel index inside a mask = the reference's order), and the bin's
+        // lane adds only its own pixels: a handful instead of 256.
+        {
+            const int mybin = bin_of;
+#pragma unroll 4
+            for (int b = 0; b < OR_BINS; ++b) {
+                const unsigned long long m = __ballot(mybin == b);
+                if ((threadIdx.x & 63) == 0) binmask[b][threadIdx.x >> 6] = m;
+            }
         }
         __syncthreads();
         if (threadIdx.x < 64) {
-            float mx = histo[0];
-            for (int b = 1; b < OR_BINS; ++b) mx = fmaxf(mx, histo[b]);
-            const float peakThreshold = mx * 0.8f;                                           // :358
-            const bool peak = threadIdx.x < OR_BINS && histo[threadIdx.x] > peakThreshold;  // :362
+            float h = 0.0f;
+            if (threadIdx.x < OR_BINS) {
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    unsigned long long m = binmask[threadIdx.x][w];
+                    while (m) {
+                        h += mw[64 * w + __builtin_ctzll(m)];
+                        m &= m - 1;
+                    }
+                }
+            }
+            // the 36 sums sit in lanes 0..35 of this wave: maximum and peak test without another pass through LDS
+            float mx = threadIdx.x < OR_BINS ? h : 0.0f;  // sums of non-negative weights: 0 is neutral, and bin 0 is among them
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+            const float peakThreshold = mx * 0.8f;                          // :358
+            const bool peak = threadIdx.x < OR_BINS && h > peakThreshold;  // :362
             const unsigned long long m = __ballot(peak);
             if (threadIdx.x == 0) masks[(size_t)f * scap + k] = m;
         }

@@ -75,7 +75,7 @@ __device__ __forceinline__ void sift_one_keypoint(SiftShared& sh, const vslam_po
             const float gx = (float)((int)G[(size_t)r * gpitch + reflect101(c + 1, cols)] - (int)G[(size_t)r * gpitch + reflect101(c - 1, cols)]);
             const float gy = (float)((int)G[(size_t)reflect101(r + 1, rows) * gpitch + c] - (int)G[(size_t)reflect101(r - 1, rows) * gpitch + c]);
             const float xx = gx * gx, yy = gy * gy;
-            sh.mag[t] = (float)sqrt((double)(xx + yy));  // cv::magnitude, correctly rounded (kernels_aux.hip.h)
+            sh.mag[t] = sqrt_rn_small(xx + yy);          // cv::magnitude, correctly rounded (kernels_generic.hip.h)
             o = fast_atan2_deg(gy, gx);                  // cv::phase(..., true)
         }
     }
