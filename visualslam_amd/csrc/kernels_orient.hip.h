@@ -80,21 +80,27 @@ __global__ __launch_bounds__(256) void k_orient_keypoints(const vslam_point* __r
     const int span = OR_WIN + 2 * R;
     float* rb = orient_smem;                                  // [span][16] row-filtered strip
     int* cx = reinterpret_cast<int*>(orient_smem + span * OR_WIN);  // [span] source column of padded column x - R + i
-    for (int i = threadIdx.x; i < span; i += 256) cx[i] = clampi(reflect101(x + i - R, pcols) - OR_PAD, 0, cols - 1);
+    float* kl = orient_smem + span * OR_WIN + span;                 // [span >= kn] the taps: from LDS, not from memory, inside the filter loops
+    for (int i = threadIdx.x; i < span; i += 256) {
+        cx[i] = clampi(reflect101(x + i - R, pcols) - OR_PAD, 0, cols - 1);
+        if (i < kn) kl[i] = k[i];
+    }
     __syncthreads();
     for (int it = threadIdx.x; it < span * OR_WIN; it += 256) {
         const int rr = it >> 4, c = it & 15;
         const int sy = clampi(reflect101(y + rr - R, prows) - OR_PAD, 0, rows - 1);  // padOctave = replicate
         const float* __restrict__ S = M + (size_t)sy * cols;
-        float s0 = k[0] * S[cx[c]];
-        for (int i = 1; i < kn; ++i) s0 += k[i] * S[cx[c + i]];
+        float s0 = kl[0] * S[cx[c]];
+#pragma unroll 4
+        for (int i = 1; i < kn; ++i) s0 += kl[i] * S[cx[c + i]];
         rb[it] = s0;
     }
     __syncthreads();
     {
         const int i = threadIdx.x >> 4, j = threadIdx.x & 15;
-        float s0 = k[R] * rb[(i + R) * OR_WIN + j];
-        for (int t = 1; t <= R; ++t) s0 += k[R + t] * (rb[(i + R + t) * OR_WIN + j] + rb[(i + R - t) * OR_WIN + j]);
+        float s0 = kl[R] * rb[(i + R) * OR_WIN + j];
+#pragma unroll 4
+        for (int t = 1; t <= R; ++t) s0 += kl[R + t] * (rb[(i + R + t) * OR_WIN + j] + rb[(i + R - t) * OR_WIN + j]);
         mw[threadIdx.x] = s0;
         const float reductionCoeff = (float)OR_BINS / 360.0f;  // :114
         const float o = lv.orient[level][(size_t)clampi(y + i - OR_PAD, 0, rows - 1) * cols + clampi(x + j - OR_PAD, 0, cols - 1)];
@@ -119,7 +125,7 @@ __global__ __launch_bounds__(256) void k_orient_keypoints(const vslam_point* __r
     }
 }
 
-static inline size_t orient_lds_bytes(int R) { return (size_t)(OR_WIN + 2 * R) * OR_WIN * 4 + (size_t)(OR_WIN + 2 * R) * 4; }
+static inline size_t orient_lds_bytes(int R) { return (size_t)(OR_WIN + 2 * R) * OR_WIN * 4 + (size_t)(OR_WIN + 2 * R) * 8; }  // strip + column map + taps
 
 // StructureMatrix (Harris_corners.cpp:10-29) / computeEdgeResponse (Diff_of_Gauss.cpp:79-109) on
 // caller-gathered windows (the per-point C++ entry points): gxw / gyw hold n windows of `elems`

@@ -40,7 +40,9 @@ struct SiftLevels {  // per Gaussian level of the octave (null / 0 when no keypo
 // G = the keypoint's 8-bit Gaussian level, k / kn = the f32 taps of sigma = 1.5 * sigma(octave, level),
 // a = (cos, sin) of its angle.  Writes the 128 floats and the defined flag (0: the rotated window
 // leaves the padded level, descriptor zeroed).  Ends with the workgroup's shared arrays free again.
+constexpr int SIFT_KMAX = 640;  // blur taps staged in LDS (309 for octave 3 of the reference pyramid); longer kernels read them from memory
 struct SiftShared {
+    float kt[SIFT_KMAX];
     float mag[SIFT_WIN * SIFT_WIN];   // magROI
     float rowf[SIFT_WIN * SIFT_WIN];  // row-filtered ROI
     float mw[SIFT_WIN * SIFT_WIN];    // magWeighted
@@ -92,18 +94,51 @@ __device__ __forceinline__ void sift_one_keypoint(SiftShared& sh, const vslam_po
         sh.bin[t] = (uint8_t)min(max(index, 0), 7);
     }
     const int R = kn >> 1;
-    {   // row filter of ROI row i: s = k[0]*S[0]; s += k[m]*S[m], S = the row extended by reflect-101
-        const float* S = sh.mag + i * SIFT_WIN;
-        float s0 = k[0] * S[reflect101(j - R, SIFT_WIN)];
-        for (int m = 1; m < kn; ++m) s0 += k[m] * S[reflect101(j + m - R, SIFT_WIN)];
-        sh.rowf[t] = s0;
-    }
-    __syncthreads();
-    {   // symmetric column filter: s = k[R]*S(0); s += k[R+m]*(S(+m) + S(-m)), rows reflected likewise
-        float s0 = k[R] * sh.rowf[i * SIFT_WIN + j];
-        for (int m = 1; m <= R; ++m)
-            s0 += k[R + m] * (sh.rowf[reflect101(i + m, SIFT_WIN) * SIFT_WIN + j] + sh.rowf[reflect101(i - m, SIFT_WIN) * SIFT_WIN + j]);
-        sh.mw[t] = s0;
+    if (kn <= SIFT_KMAX) {
+        // Taps from LDS (read from memory inside the loops, every multiply waited for a load round trip), and the
+        // repeated reflect-101 of the 16-wide ROI as the triangle wave of period 30 it is, advanced by one per tap
+        // instead of a reflection loop per tap: position p -> q = p mod 30, index = q < 16 ? q : 30 - q.
+        constexpr int PER = 2 * (SIFT_WIN - 1);
+        for (int m = t; m < kn; m += 256) sh.kt[m] = k[m];
+        __syncthreads();
+        {   // row filter of ROI row i: s = k[0]*S[0]; s += k[m]*S[m], S = the row extended by reflect-101
+            const float* S = sh.mag + i * SIFT_WIN;
+            int q = (j - R) % PER;
+            q = q < 0 ? q + PER : q;
+            float s0 = sh.kt[0] * S[q < SIFT_WIN ? q : PER - q];
+#pragma unroll 4
+            for (int m = 1; m < kn; ++m) {
+                q = q + 1 == PER ? 0 : q + 1;
+                s0 += sh.kt[m] * S[q < SIFT_WIN ? q : PER - q];
+            }
+            sh.rowf[t] = s0;
+        }
+        __syncthreads();
+        {   // symmetric column filter: s = k[R]*S(0); s += k[R+m]*(S(+m) + S(-m)), rows reflected likewise
+            float s0 = sh.kt[R] * sh.rowf[i * SIFT_WIN + j];
+            int qp = i, qm = i;  // i is inside the ROI: 0 <= i < 16 < PER
+#pragma unroll 4
+            for (int m = 1; m <= R; ++m) {
+                qp = qp + 1 == PER ? 0 : qp + 1;
+                qm = qm == 0 ? PER - 1 : qm - 1;
+                s0 += sh.kt[R + m] * (sh.rowf[(qp < SIFT_WIN ? qp : PER - qp) * SIFT_WIN + j] + sh.rowf[(qm < SIFT_WIN ? qm : PER - qm) * SIFT_WIN + j]);
+            }
+            sh.mw[t] = s0;
+        }
+    } else {
+        {
+            const float* S = sh.mag + i * SIFT_WIN;
+            float s0 = k[0] * S[reflect101(j - R, SIFT_WIN)];
+            for (int m = 1; m < kn; ++m) s0 += k[m] * S[reflect101(j + m - R, SIFT_WIN)];
+            sh.rowf[t] = s0;
+        }
+        __syncthreads();
+        {
+            float s0 = k[R] * sh.rowf[i * SIFT_WIN + j];
+            for (int m = 1; m <= R; ++m)
+                s0 += k[R + m] * (sh.rowf[reflect101(i + m, SIFT_WIN) * SIFT_WIN + j] + sh.rowf[reflect101(i - m, SIFT_WIN) * SIFT_WIN + j]);
+            sh.mw[t] = s0;
+        }
     }
     __syncthreads();
     if (t < SIFT_DESC) {  // thread = (sub-region, bin); regions row-major, columns advance first (:637-652)

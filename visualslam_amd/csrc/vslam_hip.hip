@@ -1613,7 +1613,7 @@ static int make_orient_plan(vslam_ctx* c, const vslam_params& p, const vslam_bat
         for (int l = 1; l <= 3; ++l) {  // the levels initialKeypointDetection produces (Diff_of_Gauss.cpp:264)
             TRY(get_orient_taps(c, 1.5 * sigma_at(p.sigma0, o, l), &g.kern[o][l], &g.kn[o][l]));  // :346
             const int span = OR_WIN + 2 * (g.kn[o][l] / 2);
-            worst = std::max(worst, 2 * span + span * OR_WIN + span * span);
+            worst = std::max(worst, 3 * span + span * OR_WIN + span * span);  // maps + taps + strip + region (k_orient_survivors)
         }
         if (worst <= kSmallLds && split == L.n_octaves)
             need_lo = std::max(need_lo, worst);
@@ -1621,7 +1621,7 @@ static int make_orient_plan(vslam_ctx* c, const vslam_params& p, const vslam_bat
             split = std::min(split, o);
             // regions that exceed even the big budget are read tap by tap; the strip and the maps still need room
             int strip = 0;
-            for (int l = 1; l <= 3; ++l) strip = std::max(strip, (OR_WIN + 2 * (g.kn[o][l] / 2)) * (OR_WIN + 2));
+            for (int l = 1; l <= 3; ++l) strip = std::max(strip, (OR_WIN + 2 * (g.kn[o][l] / 2)) * (OR_WIN + 3));
             need_hi = std::max(need_hi, std::min(std::max(worst, strip), std::max(kBigLds, strip)));
         }
     }
