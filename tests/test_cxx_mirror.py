@@ -248,3 +248,43 @@ def test_stream_one_rank_over_rccl_matches_the_oracle(built, tmp_path, mode):
             assert td == len(want_p) and pt.tobytes() == want_p.tobytes(), f
     # the all-gathered totals (one rank: its own) are the sums of the per-frame counts
     assert line["keypoints_per_batch"] == {"harris": tot_h, "dog": tot_d} and line["rank0_counts"] == [tot_h, tot_d]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["device", "hostfed"])
+def test_stream_two_ranks_on_one_gpu_with_the_rehearsal_exchange(built, tmp_path, mode):
+    # N > 1 in the C++ host: RCCL refuses two ranks per device, so the rehearsal backend (VSLAM_COUNT_BACKEND=tcp: the
+    # same collectives through the rendezvous sockets) carries the counts of two processes that share the GPU - like
+    # tests/test_bench_ranks.py does for the Python host over gloo.  Rank r reads camera stream r: the all-gathered
+    # table must hold each rank's own totals, rank 0's line the whole-job sums, and rank 1's frames the oracle's lists.
+    import numpy as np
+
+    import oracle
+    from visualslam_amd import synth
+
+    rows, cols, n, world = 135, 240, 5, 2
+    procs = []
+    for r in reversed(range(world)):
+        env = dict(_rank_env(r, world, 29930 + (mode == "hostfed")), VSLAM_COUNT_BACKEND="tcp")
+        procs.append((r, subprocess.Popen([os.path.join(built, "Stream"), "--mode", mode, "--frames", str(n), "--batches", "3", "--warmup", "1", "--rows", str(rows),
+                                           "--cols", str(cols), "--dump", str(tmp_path / f"lists{r}.bin")], env=env, stdout=subprocess.PIPE,
+                                          stderr=subprocess.PIPE, text=True)))
+    outs = {r: p.communicate(timeout=600) for r, p in procs}
+    assert all(p.returncode == 0 for _, p in procs), outs
+    line = json.loads(outs[0][0].strip().splitlines()[-1])
+    assert line["n_gpus"] == world and "rehearsal" in line["host"] and line["mode"] == mode
+    assert outs[1][0].strip() == "" or "frames_per_sec" not in outs[1][0]  # only rank 0 prints the job's line
+    by_rank = line["counts_by_rank"]
+    assert len(by_rank) == world and by_rank[0] != by_rank[1]  # different camera streams
+    assert line["keypoints_per_batch"] == {"harris": by_rank[0][0] + by_rank[1][0], "dog": by_rank[0][1] + by_rank[1][1]}
+    for r in range(world):
+        gr, gc, frames = _read_dump(tmp_path / f"lists{r}.bin")
+        assert (gr, gc, len(frames)) == (rows, cols, n)
+        assert [sum(f[2] for f in frames), sum(f[3] for f in frames)] == by_rank[r]
+        img = synth.frame_np(rows, cols, 2, r)  # frame 2 of camera stream r
+        kp, pt, th, td = frames[2]
+        want_k = oracle.harris_keypoints(oracle.nms2(oracle.harris_response(img), 5)[0])
+        pyr = oracle.Pyramid(img, 4, 1.6)
+        want_p = np.concatenate([pyr.extrema(o, 3, 8)[1] for o in range(4)])
+        pyr.close()
+        assert kp.tobytes() == want_k.tobytes() and pt.tobytes() == want_p.tobytes(), r

@@ -186,7 +186,7 @@ int main(int argc, char** argv) {
             if (env.world != 1) throw std::runtime_error("--no-rccl is for single-rank runs");
             if (hipMalloc((void**)&ex.d_one, 16) != hipSuccess || hipMemset(ex.d_one, 0, 16) != hipSuccess) throw std::runtime_error("hipMalloc");
         } else {
-            ex.cx = std::make_unique<vslam::CountExchange>(env, device);
+            ex.cx = std::make_unique<vslam::CountExchange>(env, device, vslam::CountExchange::backend_from_environment());
         }
         const hipStream_t cs = (hipStream_t)det.stream();
 
@@ -288,15 +288,21 @@ int main(int argc, char** argv) {
         if (!a.dump.empty() && last) dump_lists(a.dump, a.rows, a.cols, *last);
         uint64_t gh = 0, gd = 0;
         for (int r = 0; r < env.world; ++r) gh += all[2 * r], gd += all[2 * r + 1];
+        const bool tcp = ex.cx && ex.cx->backend() == vslam::CountExchange::Backend::Tcp;
+        std::string by_rank = "[";
+        for (int r = 0; r < env.world; ++r)
+            by_rank += (r ? ", [" : "[") + std::to_string(all[2 * r]) + ", " + std::to_string(all[2 * r + 1]) + "]";
+        by_rank += "]";
         if (env.rank == 0) {
             const double fps = (double)a.frames * a.batches * env.world / dt_max;
-            std::printf("{\"exe\": \"Stream\", \"host\": \"C++ (BatchDetector) + RCCL ncclAllGather\", \"mode\": \"%s\", \"n_gpus\": %d, \"frames_per_batch\": %d, "
+            std::printf("{\"exe\": \"Stream\", \"host\": \"C++ (BatchDetector) + %s\", \"mode\": \"%s\", \"n_gpus\": %d, \"frames_per_batch\": %d, "
                         "\"batches\": %d, \"warmup\": %d, \"rows\": %d, \"cols\": %d, \"octaves\": %d, \"frames_per_sec\": %.2f, \"ms_per_batch\": %.4f, "
                         "\"keypoints_per_batch\": {\"harris\": %llu, \"dog\": %llu}, \"keypoints_per_sec\": %.1f, \"rank0_counts\": [%llu, %llu], "
-                        "\"steady_ms_per_batch\": %.4f, \"steady_frames_per_sec\": %.2f}\n",
-                        a.mode.c_str(), env.world, a.frames, a.batches, a.warmup, a.rows, a.cols, det.params().n_octaves, fps, dt_max / a.batches * 1e3,
+                        "\"steady_ms_per_batch\": %.4f, \"steady_frames_per_sec\": %.2f, \"counts_by_rank\": %s}\n",
+                        a.no_rccl ? "no communicator (--no-rccl)" : tcp ? "TCP rehearsal exchange (VSLAM_COUNT_BACKEND=tcp)" : "RCCL ncclAllGather", a.mode.c_str(),
+                        env.world, a.frames, a.batches, a.warmup, a.rows, a.cols, det.params().n_octaves, fps, dt_max / a.batches * 1e3,
                         (unsigned long long)gh, (unsigned long long)gd, (double)(gh + gd) * a.batches / dt_max, (unsigned long long)all[0],
-                        (unsigned long long)all[1], steady_ms, steady_ms > 0 ? a.frames * 1e3 / steady_ms * env.world : 0.0);
+                        (unsigned long long)all[1], steady_ms, steady_ms > 0 ? a.frames * 1e3 / steady_ms * env.world : 0.0, by_rank.c_str());
         }
         vslam::BatchDetector::free_pinned(h_frames);
         return 0;

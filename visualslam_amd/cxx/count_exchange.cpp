@@ -66,7 +66,13 @@ RankEnv RankEnv::from_environment() {
     return e;
 }
 
-void tcp_broadcast_from_rank0(const RankEnv& env, void* bytes, size_t n) {
+// The rendezvous itself; keep != nullptr: the connections stay open (rank 0: keep[rank] = socket of that peer, others:
+// keep[0] = the socket to rank 0) instead of being closed after the hand-off.
+static void tcp_rendezvous(const RankEnv& env, void* bytes, size_t n, std::vector<int>* keep);
+void tcp_broadcast_from_rank0(const RankEnv& env, void* bytes, size_t n) { tcp_rendezvous(env, bytes, n, nullptr); }
+
+static void tcp_rendezvous(const RankEnv& env, void* bytes, size_t n, std::vector<int>* keep) {
+    if (keep) keep->assign(env.rank == 0 ? env.world : 1, -1);
     if (env.world <= 1) return;
     sockaddr_in sa{};
     sa.sin_family = AF_INET;
@@ -97,10 +103,17 @@ void tcp_broadcast_from_rank0(const RankEnv& env, void* bytes, size_t n) {
             }
             int32_t peer = -1;
             const bool ok = io_all(fd, &peer, sizeof(peer), false) && peer > 0 && peer < env.world && !seen[peer] && io_all(fd, bytes, n, true);
-            ::close(fd);
             if (!ok) {
+                ::close(fd);
                 ::close(ls);
                 fail("rendezvous: bad or duplicate peer (rank " + std::to_string(peer) + ")");
+            }
+            if (keep) {
+                const int one_ = 1;
+                ::setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one_, sizeof(one_));
+                (*keep)[peer] = fd;
+            } else {
+                ::close(fd);
             }
             seen[peer] = 1;
         }
@@ -113,8 +126,17 @@ void tcp_broadcast_from_rank0(const RankEnv& env, void* bytes, size_t n) {
             if (::connect(fd, reinterpret_cast<sockaddr*>(&sa), sizeof(sa)) == 0) {
                 int32_t me = env.rank;
                 const bool ok = io_all(fd, &me, sizeof(me), true) && io_all(fd, bytes, n, false);
-                ::close(fd);
-                if (!ok) fail("rendezvous: rank " + std::to_string(env.rank) + " lost the connection to rank 0");
+                if (!ok) {
+                    ::close(fd);
+                    fail("rendezvous: rank " + std::to_string(env.rank) + " lost the connection to rank 0");
+                }
+                if (keep) {
+                    const int one_ = 1;
+                    ::setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one_, sizeof(one_));
+                    (*keep)[0] = fd;
+                } else {
+                    ::close(fd);
+                }
                 return;
             }
             ::close(fd);
@@ -125,15 +147,25 @@ void tcp_broadcast_from_rank0(const RankEnv& env, void* bytes, size_t n) {
     }
 }
 
-CountExchange::CountExchange(const RankEnv& env, int device) : env_(env), device_(device) {
+CountExchange::Backend CountExchange::backend_from_environment() {
+    const char* e = std::getenv("VSLAM_COUNT_BACKEND");
+    return e && std::string(e) == "tcp" ? Backend::Tcp : Backend::Rccl;
+}
+
+CountExchange::CountExchange(const RankEnv& env, int device, Backend backend) : env_(env), device_(device), backend_(backend) {
     HIPX(hipSetDevice(device_));
-    ncclUniqueId id;
-    std::memset(&id, 0, sizeof(id));
-    if (env_.rank == 0) NCCLX(ncclGetUniqueId(&id));
-    tcp_broadcast_from_rank0(env_, &id, sizeof(id));
-    ncclComm_t comm;
-    NCCLX(ncclCommInitRank(&comm, env_.world, id, env_.rank));
-    comm_ = comm;
+    if (backend_ == Backend::Rccl) {
+        ncclUniqueId id;
+        std::memset(&id, 0, sizeof(id));
+        if (env_.rank == 0) NCCLX(ncclGetUniqueId(&id));
+        tcp_broadcast_from_rank0(env_, &id, sizeof(id));
+        ncclComm_t comm;
+        NCCLX(ncclCommInitRank(&comm, env_.world, id, env_.rank));
+        comm_ = comm;
+    } else {
+        char hello[8] = "vslamrh";  // same hand-off as the RCCL id, the sockets stay open for the rounds
+        tcp_rendezvous(env_, hello, sizeof(hello), &fds_);
+    }
     HIPX(hipMalloc((void**)&d_all_, sizeof(uint64_t) * 2 * (size_t)env_.world));
     HIPX(hipMemset(d_all_, 0, sizeof(uint64_t) * 2 * (size_t)env_.world));
     HIPX(hipMalloc((void**)&d_scratch_, 2 * sizeof(double)));
@@ -143,12 +175,40 @@ CountExchange::~CountExchange() {
     (void)hipSetDevice(device_);
     (void)hipDeviceSynchronize();
     if (comm_) (void)ncclCommDestroy((ncclComm_t)comm_);
+    for (int fd : fds_)
+        if (fd >= 0) ::close(fd);
     if (d_all_) (void)hipFree(d_all_);
     if (d_scratch_) (void)hipFree(d_scratch_);
 }
 
+void CountExchange::tcp_round(const void* mine, size_t n, void* table) {
+    char* T = static_cast<char*>(table);
+    if (env_.rank == 0) {
+        std::memcpy(T, mine, n);
+        for (int r = 1; r < env_.world; ++r)
+            if (!io_all(fds_[r], T + (size_t)r * n, n, false)) fail("tcp exchange: lost rank " + std::to_string(r));
+        for (int r = 1; r < env_.world; ++r)
+            if (!io_all(fds_[r], T, n * (size_t)env_.world, true)) fail("tcp exchange: lost rank " + std::to_string(r));
+    } else if (env_.world > 1) {
+        if (!io_all(fds_[0], const_cast<void*>(mine), n, true) || !io_all(fds_[0], T, n * (size_t)env_.world, false)) fail("tcp exchange: lost rank 0");
+    } else {
+        std::memcpy(T, mine, n);
+    }
+}
+
 void CountExchange::all_gather_async(const uint64_t* d_local, void* stream) {
-    NCCLX(ncclAllGather(d_local, d_all_, 2, ncclUint64, (ncclComm_t)comm_, (hipStream_t)stream));
+    if (backend_ == Backend::Rccl) {
+        NCCLX(ncclAllGather(d_local, d_all_, 2, ncclUint64, (ncclComm_t)comm_, (hipStream_t)stream));
+        return;
+    }
+    // rehearsal backend: through the host, synchronous
+    uint64_t mine[2];
+    HIPX(hipMemcpyAsync(mine, d_local, 16, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPX(hipStreamSynchronize((hipStream_t)stream));
+    std::vector<uint64_t> table(2 * (size_t)env_.world);
+    tcp_round(mine, 16, table.data());
+    HIPX(hipMemcpyAsync(d_all_, table.data(), table.size() * 8, hipMemcpyHostToDevice, (hipStream_t)stream));
+    HIPX(hipStreamSynchronize((hipStream_t)stream));
 }
 
 std::vector<uint64_t> CountExchange::fetch(void* stream) {
@@ -160,6 +220,14 @@ std::vector<uint64_t> CountExchange::fetch(void* stream) {
 
 double CountExchange::max_over_ranks(double v, void* stream) {
     const hipStream_t s = (hipStream_t)stream;
+    if (backend_ == Backend::Tcp) {
+        HIPX(hipStreamSynchronize(s));
+        std::vector<double> table((size_t)env_.world);
+        tcp_round(&v, sizeof(double), table.data());
+        double m = table[0];
+        for (double x : table) m = x > m ? x : m;
+        return m;
+    }
     HIPX(hipMemcpyAsync(d_scratch_, &v, sizeof(double), hipMemcpyHostToDevice, s));
     NCCLX(ncclAllReduce(d_scratch_, d_scratch_ + 1, 1, ncclDouble, ncclMax, (ncclComm_t)comm_, s));
     double out = v;

@@ -28,11 +28,17 @@ void tcp_broadcast_from_rank0(const RankEnv& env, void* bytes, size_t n);
 
 class CountExchange {
 public:
+    // RCCL: the product path.  Tcp: REHEARSAL ONLY (VSLAM_COUNT_BACKEND=tcp, like bench.py's VSLAM_BENCH_BACKEND=gloo):
+    // the same collectives carried by the rendezvous sockets through rank 0, host side, so that the N > 1 logic
+    // (rank environment, totals, max over ranks) can run with several ranks on ONE GPU, which RCCL refuses.
+    enum class Backend { Rccl, Tcp };
+    static Backend backend_from_environment();
     // Collective over all ranks (also with world = 1: the communicator is then a single-rank RCCL one).
-    CountExchange(const RankEnv& env, int device);
+    CountExchange(const RankEnv& env, int device, Backend backend = Backend::Rccl);
     ~CountExchange();
     CountExchange(const CountExchange&) = delete;
     CountExchange& operator=(const CountExchange&) = delete;
+    Backend backend() const { return backend_; }
     int rank() const { return env_.rank; }
     int world() const { return env_.world; }
     // ncclAllGather of d_local (2 x uint64, device memory) into the object's device buffer, asynchronous on
@@ -45,8 +51,11 @@ public:
     void barrier(void* stream);
 
 private:
+    void tcp_round(const void* mine, size_t n, void* table);  // every rank's n bytes -> rank 0 -> the whole table back to every rank
     RankEnv env_;
     int device_ = 0;
+    Backend backend_ = Backend::Rccl;
+    std::vector<int> fds_;     // Tcp: rank 0: one socket per peer (index = rank); others: fds_[0] = the socket to rank 0
     void* comm_ = nullptr;     // ncclComm_t
     uint64_t* d_all_ = nullptr;  // [world][2]
     double* d_scratch_ = nullptr;
