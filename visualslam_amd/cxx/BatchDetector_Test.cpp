@@ -5,6 +5,8 @@
 //   2. those lists equal what the per-image API of vslam_cxx.hpp produces for the same frame
 //      (HarrisKeypoints; GaussPyramid + scaleSpaceCandidates per octave) - the drop-in functions and the
 //      batched path are the same detector;
+//   2b. with Options::describe the batch runs the rest of the DoG executable (FeaturePointLocalization, filterKeypoints,
+//      SIFT) and returns per frame exactly what the per-image functions return, descriptors bit for bit;
 //   3. the C ABI refuses an undersized output buffer with VSLAM_ERR_INVALID before launching anything
 //      (include/vslam.h: vslam_batch_out carries buffer sizes), and a struct without struct_size.
 //   usage: BatchDetector_Test [WxH] [frames]
@@ -112,6 +114,58 @@ int main(int argc, char** argv) {
             for (int oc = 0; oc < pyramid.getNumOctaves(); ++oc) scaleSpaceCandidates(cand, pyramid, oc, p.extrema_window, p.min_contrast);
             EXPECT(cand.size() == doff[f + 1] - doff[f]);
             EXPECT(cand.empty() || std::memcmp(cand.data(), pt0.data() + doff[f], cand.size() * sizeof(vslam_point)) == 0);
+        }
+
+        // ---- 2b. the rest of the DoG executable in the batch (Options::describe: localize + filterKeypoints + SIFT):
+        //          frame by frame the same oriented points, descriptors and defined flags as the per-image functions
+        {
+            const int m = 3;
+            std::vector<cv::Mat> im2;
+            uint8_t* h2 = (uint8_t*)vslam::BatchDetector::alloc_pinned((size_t)m * N);
+            for (int f = 0; f < m; ++f) {
+                cv::Mat a = imgio::synthetic(rows, cols, f, 9);
+                if (f == 1)  // a uniform-noise frame: thousands of oriented points (the checkerboard has a few dozen)
+                    for (int r = 0; r < rows; ++r)
+                        for (int c = 0; c < cols; ++c) a.at<cv::uchar>(r, c) = (cv::uchar)(imgio::splitmix64(0x5EED0009ull ^ (uint64_t)((uint64_t)r * cols + c)) & 255);
+                im2.push_back(a);
+                std::memcpy(h2 + (size_t)f * N, a.data, N);
+            }
+            vslam::BatchDetector::Options o2 = opt;
+            o2.batch = m, o2.describe = true, o2.slots = 2;
+            o2.host_oriented_per_frame = (size_t)1 << 16, o2.host_descriptors_per_frame = (size_t)1 << 16;
+            vslam::BatchDetector d2(o2);
+            EXPECT(d2.params().localize == 1 && d2.params().orient == 1);
+            d2.submit(h2, m);
+            const vslam::BatchResult& r2 = d2.collect();
+            EXPECT(r2.n_frames == m && !r2.truncated && r2.oriented_records > 1000 && r2.descriptor_records == r2.oriented_records);
+            for (int f = 0; f < m; ++f) {
+                const vslam::FrameKeypoints k = r2.frame(f);
+                GaussPyramid pyramid{im2[f], d2.params().n_octaves, d2.params().sigma0};
+                std::vector<SLAM::point> kps_all, ori_all;
+                std::vector<std::vector<float>> desc_all;
+                std::vector<unsigned char> def_all;
+                for (int oc = 0; oc < pyramid.getNumOctaves(); ++oc) {
+                    std::vector<SLAM::point> kps, ori;
+                    initialKeypointDetection(kps, pyramid, oc, d2.params().extrema_window);  // :785
+                    filterKeypoints(pyramid, oc, kps, ori);                                  // :787
+                    std::vector<unsigned char> def;
+                    SIFT(ori, desc_all, pyramid, oc, &def);                                  // :791
+                    kps_all.insert(kps_all.end(), kps.begin(), kps.end());
+                    ori_all.insert(ori_all.end(), ori.begin(), ori.end());
+                    def_all.insert(def_all.end(), def.begin(), def.end());
+                }
+                EXPECT(k.n_dog == kps_all.size() && (kps_all.empty() || std::memcmp(k.dog, kps_all.data(), kps_all.size() * sizeof(vslam_point)) == 0));
+                EXPECT(k.n_oriented == ori_all.size() && k.oriented_total == ori_all.size());
+                EXPECT(ori_all.empty() || std::memcmp(k.oriented, ori_all.data(), ori_all.size() * sizeof(vslam_point)) == 0);
+                EXPECT(k.descriptors != nullptr && k.descriptor_defined != nullptr && desc_all.size() == ori_all.size());
+                size_t bad = 0;
+                for (size_t q = 0; q < ori_all.size() && k.descriptors; ++q) {
+                    bad += (k.descriptor_defined[q] != 0) != (def_all[q] != 0);
+                    bad += std::memcmp(k.descriptors + q * 128, desc_all[q].data(), 128 * sizeof(float)) != 0;  // bit patterns (NaN descriptors included)
+                }
+                EXPECT(bad == 0);
+            }
+            vslam::BatchDetector::free_pinned(h2);
         }
 
         // ---- 3. undersized buffers are refused by the C ABI itself

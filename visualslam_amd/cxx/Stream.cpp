@@ -5,6 +5,8 @@
 //
 //   Stream [--mode device|hostfed] [--frames 256] [--batches 8] [--warmup 2] [--rows 1080 --cols 1920]
 //          [--octaves 4] [--source synth|<file of raw 8-bit frames>] [--dump <file>] [--rdv-selftest]
+//          [--lists candidates|localize|orient|describe]   (how much of the DoG executable runs per frame:
+//           the contrast-8 candidate list, + FeaturePointLocalization, + filterKeypoints, + SIFT descriptors)
 //
 //   device   frames are uploaded once and stay in HBM; every step = BatchDetector::detect_device +
 //            the RCCL all-gather of the {harris, dog} counts on the same stream (what bench.py times);
@@ -39,7 +41,7 @@
 namespace {
 
 struct Args {
-    std::string mode = "device", source = "synth", dump;
+    std::string mode = "device", source = "synth", dump, lists = "candidates";
     int frames = 256, batches = 8, warmup = 2, rows = 1080, cols = 1920, octaves = 4;
     bool rdv_selftest = false, no_allgather = false, no_rccl = false;
 };
@@ -61,12 +63,13 @@ Args parse(int argc, char** argv) {
         else if (k == "--octaves") a.octaves = std::stoi(val());
         else if (k == "--source") a.source = val();
         else if (k == "--dump") a.dump = val();
+        else if (k == "--lists") a.lists = val();  // candidates (default) | localize | orient | describe: how much of the DoG executable runs per frame
         else if (k == "--rdv-selftest") a.rdv_selftest = true;
         else if (k == "--no-allgather") a.no_allgather = true;  // diagnosis only: the per-step collective left out
         else if (k == "--no-rccl") a.no_rccl = true;            // diagnosis only: single rank without a communicator
         else throw std::runtime_error("unknown argument " + k);
     }
-    if ((a.mode != "device" && a.mode != "hostfed") || a.frames <= 0 || a.batches <= 0 || a.warmup < 0 || a.rows <= 0 || a.cols <= 0 || a.octaves < 0)
+    if ((a.lists != "candidates" && a.lists != "localize" && a.lists != "orient" && a.lists != "describe") || (a.mode != "device" && a.mode != "hostfed") || a.frames <= 0 || a.batches <= 0 || a.warmup < 0 || a.rows <= 0 || a.cols <= 0 || a.octaves < 0)
         throw std::runtime_error("bad arguments");
     return a;
 }
@@ -153,6 +156,7 @@ int main(int argc, char** argv) {
         opt.device = device;
         opt.rows = a.rows, opt.cols = a.cols, opt.batch = a.frames;
         opt.host_fed = hostfed;
+        opt.localize = a.lists != "candidates", opt.orient = a.lists == "orient" || a.lists == "describe", opt.describe = a.lists == "describe";
         if (a.octaves != 4) {
             opt.custom_params = true;
             vslam_params_default(&opt.params, a.rows, a.cols);
@@ -284,6 +288,16 @@ int main(int argc, char** argv) {
                 steady_ms = d[d.size() / 2] * 1e3;
             }
         }
+        unsigned long long oriented_rank = 0;  // this rank's oriented points of the last batch (reported, not all-gathered)
+        if (opt.orient) {
+            if (hostfed && last && last->oriented_counts) {
+                for (int f = 0; f < last->n_frames; ++f) oriented_rank += last->oriented_counts[f];
+            } else if (!hostfed && det.device_outputs().oriented_counts) {
+                std::vector<uint32_t> oc(a.frames);
+                (void)hipMemcpy(oc.data(), det.device_outputs().oriented_counts, 4 * (size_t)a.frames, hipMemcpyDeviceToHost);
+                for (uint32_t v : oc) oriented_rank += v;
+            }
+        }
         const double dt_max = ex.max_over_ranks(dt, cs);
         if (!a.dump.empty() && last) dump_lists(a.dump, a.rows, a.cols, *last);
         uint64_t gh = 0, gd = 0;
@@ -298,11 +312,11 @@ int main(int argc, char** argv) {
             std::printf("{\"exe\": \"Stream\", \"host\": \"C++ (BatchDetector) + %s\", \"mode\": \"%s\", \"n_gpus\": %d, \"frames_per_batch\": %d, "
                         "\"batches\": %d, \"warmup\": %d, \"rows\": %d, \"cols\": %d, \"octaves\": %d, \"frames_per_sec\": %.2f, \"ms_per_batch\": %.4f, "
                         "\"keypoints_per_batch\": {\"harris\": %llu, \"dog\": %llu}, \"keypoints_per_sec\": %.1f, \"rank0_counts\": [%llu, %llu], "
-                        "\"steady_ms_per_batch\": %.4f, \"steady_frames_per_sec\": %.2f, \"counts_by_rank\": %s}\n",
+                        "\"steady_ms_per_batch\": %.4f, \"steady_frames_per_sec\": %.2f, \"counts_by_rank\": %s, \"lists\": \"%s\", \"oriented_points_rank0_last_batch\": %llu}\n",
                         a.no_rccl ? "no communicator (--no-rccl)" : tcp ? "TCP rehearsal exchange (VSLAM_COUNT_BACKEND=tcp)" : "RCCL ncclAllGather", a.mode.c_str(),
                         env.world, a.frames, a.batches, a.warmup, a.rows, a.cols, det.params().n_octaves, fps, dt_max / a.batches * 1e3,
                         (unsigned long long)gh, (unsigned long long)gd, (double)(gh + gd) * a.batches / dt_max, (unsigned long long)all[0],
-                        (unsigned long long)all[1], steady_ms, steady_ms > 0 ? a.frames * 1e3 / steady_ms * env.world : 0.0, by_rank.c_str());
+                        (unsigned long long)all[1], steady_ms, steady_ms > 0 ? a.frames * 1e3 / steady_ms * env.world : 0.0, by_rank.c_str(), a.lists.c_str(), oriented_rank);
         }
         vslam::BatchDetector::free_pinned(h_frames);
         return 0;

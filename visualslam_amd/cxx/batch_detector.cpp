@@ -30,6 +30,15 @@ FrameKeypoints BatchResult::frame(int f) const {
     k.n_dog = (size_t)(d1 - d0);
     k.harris_total = harris_counts[f];
     k.dog_total = dog_counts[f];
+    if (oriented_offsets) {
+        const uint64_t o0 = std::min(oriented_offsets[f], oriented_records), o1 = std::min(oriented_offsets[f + 1], oriented_records);
+        k.oriented = oriented + o0;
+        k.n_oriented = (size_t)(o1 - o0);
+        k.oriented_total = oriented_counts[f];
+        k.oriented_survivors = oriented_survivors[f];
+        if (descriptors && o1 <= descriptor_records) k.descriptors = descriptors + o0 * 128;
+        if (descriptor_defined) k.descriptor_defined = descriptor_defined + (size_t)f * oriented_cap;
+    }
     return k;
 }
 
@@ -50,6 +59,10 @@ BatchDetector::BatchDetector(const Options& opt) : opt_(opt) {
         vslam_params_default(&p_, opt.rows, opt.cols);
     p_.rows = opt.rows;
     p_.cols = opt.cols;
+    if (opt.describe) opt_.orient = true;
+    if (opt_.orient) opt_.localize = true;
+    if (opt_.localize) p_.localize = 1;
+    if (opt_.orient) p_.orient = 1;
     int rc = vslam_batch_layout_query(&p_, &L_);
     if (rc != VSLAM_OK) throw Error(rc, "BatchDetector: vslam_batch_layout_query rejected the parameters");
     HIPX(hipSetDevice(opt.device));
@@ -98,6 +111,9 @@ BatchDetector::BatchDetector(const Options& opt) : opt_(opt) {
     const size_t n = (size_t)opt.batch;
     packed_cap_h_ = std::min<size_t>(n * p_.harris_cap, n * opt.host_records_per_frame);
     packed_cap_p_ = std::min<size_t>(n * p_.dog_cap, n * opt.host_records_per_frame);
+    packed_cap_o_ = std::min<size_t>(n * p_.oriented_cap, n * opt.host_oriented_per_frame);
+    packed_cap_d_ = std::min<size_t>(n * p_.oriented_cap, n * opt.host_descriptors_per_frame);
+    const bool orient = dog && opt_.orient, describe = orient && opt_.describe;
     slots_.resize(nslots);
     for (Slot& s : slots_) {
         s.out = img;
@@ -111,6 +127,17 @@ BatchDetector::BatchDetector(const Options& opt) : opt_(opt) {
             s.out.dog_counts = (uint32_t*)dmalloc(need.dog_counts_bytes), s.out.dog_counts_bytes = need.dog_counts_bytes;
             HIPX(hipMemset(s.out.dog_counts, 0, need.dog_counts_bytes));
         }
+        if (orient) {
+            s.out.oriented_points = (vslam_point*)dmalloc(need.oriented_points_bytes), s.out.oriented_points_bytes = need.oriented_points_bytes;
+            s.out.oriented_counts = (uint32_t*)dmalloc(need.oriented_counts_bytes), s.out.oriented_counts_bytes = need.oriented_counts_bytes;
+            s.out.oriented_survivors = (uint32_t*)dmalloc(need.oriented_survivors_bytes), s.out.oriented_survivors_bytes = need.oriented_survivors_bytes;
+            HIPX(hipMemset(s.out.oriented_counts, 0, need.oriented_counts_bytes));
+            HIPX(hipMemset(s.out.oriented_survivors, 0, need.oriented_survivors_bytes));
+        }
+        if (describe) {
+            s.out.descriptors = (float*)dmalloc(need.descriptors_bytes), s.out.descriptors_bytes = need.descriptors_bytes;
+            s.out.descriptor_defined = (uint8_t*)dmalloc(need.descriptor_defined_bytes), s.out.descriptor_defined_bytes = need.descriptor_defined_bytes;
+        }
         hipEvent_t e;
         HIPX(hipEventCreateWithFlags(&e, hipEventDisableTiming)), s.up_done = e;
         HIPX(hipEventCreateWithFlags(&e, hipEventDisableTiming)), s.comp_done = e;
@@ -119,12 +146,21 @@ BatchDetector::BatchDetector(const Options& opt) : opt_(opt) {
         s.d_frames = (uint8_t*)dmalloc(n * (size_t)p_.rows * p_.cols);
         s.d_hpacked = (vslam_kp*)dmalloc(packed_cap_h_ * sizeof(vslam_kp));
         s.d_ppacked = (vslam_point*)dmalloc(packed_cap_p_ * sizeof(vslam_point));
-        s.d_off = (uint64_t*)dmalloc(2 * (n + 1) * sizeof(uint64_t));
-        HIPX(hipMemset(s.d_off, 0, 2 * (n + 1) * sizeof(uint64_t)));
-        s.h_off = (uint64_t*)pinned(2 * (n + 1) * sizeof(uint64_t));
-        s.h_cnt = (uint32_t*)pinned(2 * n * sizeof(uint32_t));
-        std::memset(s.h_off, 0, 2 * (n + 1) * sizeof(uint64_t));
-        std::memset(s.h_cnt, 0, 2 * n * sizeof(uint32_t));
+        s.d_off = (uint64_t*)dmalloc(3 * (n + 1) * sizeof(uint64_t));
+        HIPX(hipMemset(s.d_off, 0, 3 * (n + 1) * sizeof(uint64_t)));
+        s.h_off = (uint64_t*)pinned(3 * (n + 1) * sizeof(uint64_t));
+        s.h_cnt = (uint32_t*)pinned(4 * n * sizeof(uint32_t));
+        std::memset(s.h_off, 0, 3 * (n + 1) * sizeof(uint64_t));
+        std::memset(s.h_cnt, 0, 4 * n * sizeof(uint32_t));
+        if (orient) {
+            s.d_opacked = (vslam_point*)dmalloc(packed_cap_o_ * sizeof(vslam_point));
+            s.h_opacked = (vslam_point*)pinned(packed_cap_o_ * sizeof(vslam_point));
+        }
+        if (describe) {
+            s.d_dpacked = (float*)dmalloc(packed_cap_d_ * 128 * sizeof(float));
+            s.h_dpacked = (float*)pinned(packed_cap_d_ * 128 * sizeof(float));
+            s.h_defined = (uint8_t*)pinned(n * p_.oriented_cap);
+        }
         s.h_hpacked = (vslam_kp*)pinned(packed_cap_h_ * sizeof(vslam_kp));
         s.h_ppacked = (vslam_point*)pinned(packed_cap_p_ * sizeof(vslam_point));
     }
@@ -192,8 +228,18 @@ void BatchDetector::submit(const uint8_t* host_frames, int n) {
         check(vslam_pack_lists_dev(ctx_, s.out.dog_points, sizeof(vslam_point), p_.dog_cap, s.out.dog_counts, n, s.d_ppacked,
                                    packed_cap_p_ * sizeof(vslam_point), s.d_off + (nb + 1)),
               ctx_, "vslam_pack_lists_dev (dog)");
+    if (s.out.oriented_points)
+        check(vslam_pack_lists_dev(ctx_, s.out.oriented_points, sizeof(vslam_point), p_.oriented_cap, s.out.oriented_counts, n, s.d_opacked,
+                                   packed_cap_o_ * sizeof(vslam_point), s.d_off + 2 * (nb + 1)),
+              ctx_, "vslam_pack_lists_dev (oriented)");
+    if (s.out.descriptors)  // same counts, same capacity: the same offsets, 512-byte records
+        check(vslam_pack_lists_dev(ctx_, s.out.descriptors, 128 * sizeof(float), p_.oriented_cap, s.out.oriented_counts, n, s.d_dpacked,
+                                   packed_cap_d_ * 128 * sizeof(float), s.d_off + 2 * (nb + 1)),
+              ctx_, "vslam_pack_lists_dev (descriptors)");
     // the small things travel on the compute stream right behind the kernels: offsets and true counts
-    HIPX(hipMemcpyAsync(s.h_off, s.d_off, 2 * (nb + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, cs));
+    HIPX(hipMemcpyAsync(s.h_off, s.d_off, 3 * (nb + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, cs));
+    if (s.out.oriented_counts) HIPX(hipMemcpyAsync(s.h_cnt + 2 * nb, s.out.oriented_counts, (size_t)n * 4, hipMemcpyDeviceToHost, cs));
+    if (s.out.oriented_survivors) HIPX(hipMemcpyAsync(s.h_cnt + 3 * nb, s.out.oriented_survivors, (size_t)n * 4, hipMemcpyDeviceToHost, cs));
     if (s.out.harris_counts) HIPX(hipMemcpyAsync(s.h_cnt, s.out.harris_counts, (size_t)n * 4, hipMemcpyDeviceToHost, cs));
     if (s.out.dog_counts) HIPX(hipMemcpyAsync(s.h_cnt + nb, s.out.dog_counts, (size_t)n * 4, hipMemcpyDeviceToHost, cs));
     HIPX(hipEventRecord((hipEvent_t)s.comp_done, cs));
@@ -227,6 +273,27 @@ const BatchResult& BatchDetector::collect() {
         HIPX(hipMemcpyAsync(s.h_hpacked, s.d_hpacked, r.harris_records * sizeof(vslam_kp), hipMemcpyDeviceToHost, ds));
     if (r.dog_records)
         HIPX(hipMemcpyAsync(s.h_ppacked, s.d_ppacked, r.dog_records * sizeof(vslam_point), hipMemcpyDeviceToHost, ds));
+    if (s.out.oriented_points) {
+        r.oriented_offsets = s.h_off + 2 * (nb + 1);
+        r.oriented = s.h_opacked;
+        r.oriented_counts = s.h_cnt + 2 * nb;
+        r.oriented_survivors = s.h_cnt + 3 * nb;
+        r.oriented_cap = p_.oriented_cap;
+        const uint64_t to = r.oriented_offsets[s.n];
+        r.oriented_records = std::min<uint64_t>(to, packed_cap_o_);
+        r.truncated = r.truncated || to > packed_cap_o_;
+        for (int f = 0; f < s.n && !r.truncated; ++f) r.truncated = r.oriented_survivors[f] > p_.oriented_cap || r.oriented_counts[f] > p_.oriented_cap;
+        if (r.oriented_records)
+            HIPX(hipMemcpyAsync(s.h_opacked, s.d_opacked, r.oriented_records * sizeof(vslam_point), hipMemcpyDeviceToHost, ds));
+        if (s.out.descriptors) {
+            r.descriptors = s.h_dpacked;
+            r.descriptor_defined = s.h_defined;
+            r.descriptor_records = std::min<uint64_t>(to, packed_cap_d_);  // descriptors beyond the host budget stay on the device
+            if (r.descriptor_records)
+                HIPX(hipMemcpyAsync(s.h_dpacked, s.d_dpacked, r.descriptor_records * 128 * sizeof(float), hipMemcpyDeviceToHost, ds));
+            HIPX(hipMemcpyAsync(s.h_defined, s.out.descriptor_defined, (size_t)s.n * p_.oriented_cap, hipMemcpyDeviceToHost, ds));
+        }
+    }
     HIPX(hipEventRecord((hipEvent_t)s.down_done, ds));
     HIPX(hipEventSynchronize((hipEvent_t)s.down_done));
     ++collected_;

@@ -32,6 +32,14 @@ struct FrameKeypoints {
     const vslam_point* dog = nullptr;   // (octave, level, i, j) order, SLAM::point layout
     size_t n_dog = 0;
     uint32_t harris_total = 0, dog_total = 0;  // what the frame really has (may exceed the caps)
+    // Options::orient: filterKeypoints' output {row, col, angle, 0, octave, level}, (octave, keypoint, bin) order
+    const vslam_point* oriented = nullptr;
+    size_t n_oriented = 0;
+    uint32_t oriented_total = 0, oriented_survivors = 0;  // survivors > oriented_cap: the frame's list is truncated
+    // Options::describe: SIFT() descriptors of the oriented points (n_oriented rows of 128 floats) and, per point,
+    // whether its rotated window was defined (include/vslam.h: vslam_sift_descriptors); may be null
+    const float* descriptors = nullptr;
+    const uint8_t* descriptor_defined = nullptr;
 };
 
 struct BatchResult {
@@ -43,6 +51,15 @@ struct BatchResult {
     const uint32_t* harris_counts = nullptr;   // [n_frames] true totals
     const uint32_t* dog_counts = nullptr;
     uint64_t harris_records = 0, dog_records = 0;  // records present in the packed lists
+    // orientation / descriptor stage (Options::orient / describe), same packing
+    const uint64_t* oriented_offsets = nullptr;
+    const vslam_point* oriented = nullptr;
+    const float* descriptors = nullptr;          // [oriented_records][128]
+    const uint8_t* descriptor_defined = nullptr; // [n_frames][oriented_cap] (not packed)
+    const uint32_t* oriented_counts = nullptr;
+    const uint32_t* oriented_survivors = nullptr;
+    uint64_t oriented_records = 0, descriptor_records = 0;
+    uint32_t oriented_cap = 0;
     bool truncated = false;  // a frame exceeded its cap, or the batch the host budget (records beyond it are missing)
     FrameKeypoints frame(int f) const;
 };
@@ -58,6 +75,12 @@ public:
         int slots = 3;                   // host-fed batches in flight (>= 1); device buffers of frames + lists per slot
         size_t host_records_per_frame = (size_t)1 << 17;  // pinned host budget per list, averaged over the batch
         bool host_fed = true;            // false: no frame / list staging buffers at all (device-resident use only)
+        // The rest of the reference's DoG executable for every frame of the batch (Diff_of_Gauss.cpp:785-791):
+        // localize: the DoG list = FeaturePointLocalization survivors instead of the contrast-8 candidates;
+        // orient: + filterKeypoints (implies localize); describe: + SIFT descriptors (implies orient)
+        bool localize = false, orient = false, describe = false;
+        size_t host_oriented_per_frame = (size_t)1 << 14;    // pinned host budget of the oriented list, averaged over the batch
+        size_t host_descriptors_per_frame = (size_t)1 << 11; // ... of the descriptors (512 bytes each)
     };
     explicit BatchDetector(const Options& opt);
     ~BatchDetector();
@@ -98,9 +121,14 @@ private:
         uint8_t* d_frames = nullptr;
         vslam_kp* d_hpacked = nullptr;
         vslam_point* d_ppacked = nullptr;
-        uint64_t* d_off = nullptr;      // [2][batch + 1]
+        uint64_t* d_off = nullptr;      // [3][batch + 1]: harris, dog, oriented
         uint64_t* h_off = nullptr;      // pinned
-        uint32_t* h_cnt = nullptr;      // pinned [2][batch]
+        uint32_t* h_cnt = nullptr;      // pinned [4][batch]: harris, dog, oriented counts, oriented survivors
+        vslam_point* d_opacked = nullptr;
+        float* d_dpacked = nullptr;
+        vslam_point* h_opacked = nullptr;  // pinned
+        float* h_dpacked = nullptr;
+        uint8_t* h_defined = nullptr;
         vslam_kp* h_hpacked = nullptr;  // pinned
         vslam_point* h_ppacked = nullptr;
         void *up_done = nullptr, *comp_done = nullptr, *down_done = nullptr;  // hipEvent_t
@@ -116,7 +144,7 @@ private:
     std::vector<Slot> slots_;
     std::vector<void*> dev_allocs_, pinned_allocs_;
     uint64_t *d_totals_ = nullptr, *d_totals_all_ = nullptr;
-    size_t packed_cap_h_ = 0, packed_cap_p_ = 0;  // records
+    size_t packed_cap_h_ = 0, packed_cap_p_ = 0, packed_cap_o_ = 0, packed_cap_d_ = 0;  // records
     uint64_t submitted_ = 0, collected_ = 0;
 };
 
