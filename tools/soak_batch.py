@@ -18,5 +18,33 @@ while time.time() - t0 < (float(sys.argv[2]) if len(sys.argv) > 2 else 120):
     p, L, out = run_batch(ctx, torch, frames, n_octaves=n_oct, harris_cap=4096, dog_cap=16384, localize=int(mode >= 1), orient=int(mode == 2), with_nms2=bool(rng.integers(0, 2)))
     for f in sorted(set([0, n // 2 - 1 if n > 1 else 0, n // 2, n - 1])):
         check_frame(p, L, out, f, frames[f], n_oct)
+    if it % 4 == 0:  # the packed form of the DoG list (vslam_pack_lists_dev) = the per-frame lists back to back
+        dev = "cuda:0"
+        lists, counts = torch.from_numpy(out["dog_points"]).to(dev), torch.from_numpy(out["dog_counts"]).to(dev)
+        m = np.minimum(out["dog_counts"], p.dog_cap).astype(np.int64)
+        packed = torch.zeros((int(m.sum()) + 1, 6), dtype=torch.int32, device=dev)
+        off = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+        ctx.pack_lists(lists, counts, packed, off)
+        torch.cuda.synchronize()
+        assert (off.cpu().numpy() == np.concatenate([[0], np.cumsum(m)])).all()
+        want = np.concatenate([out["dog_points"][f][: m[f]] for f in range(n)])
+        assert (packed.cpu().numpy()[: len(want)] == want).all()
+    if it % 5 == 0 and mode == 0:  # the dense 3x3x3 extension in the batch, two frames against the oracle
+        import oracle
+        pd = capi.default_params(rows, cols, n_octaves=n_oct, extrema_dense=1, dog_cap=1 << 17)
+        Ld = capi.batch_layout(pd)
+        dev = "cuda:0"
+        o = dict(pyramid=torch.empty((n, Ld.pyramid_frame_bytes), dtype=torch.uint8, device=dev),
+                 extrema_bits=torch.zeros((n, Ld.bits_frame_words), dtype=torch.int64, device=dev),
+                 dog_points=torch.zeros((n, pd.dog_cap, 6), dtype=torch.int32, device=dev), dog_counts=torch.zeros(n, dtype=torch.int32, device=dev))
+        ctx.detect_batch(pd, torch.from_numpy(frames).to(dev), **o)
+        torch.cuda.synchronize()
+        for f in sorted(set([0, n - 1])):
+            w = oracle.Pyramid(frames[f], n_oct)
+            allp = np.concatenate([w.extrema_dense(oc, 8)[1] for oc in range(n_oct)])
+            w.close()
+            assert int(o["dog_counts"][f]) == len(allp)
+            k = min(len(allp), pd.dog_cap)
+            assert o["dog_points"][f][:k].cpu().numpy().view(capi.POINT_DTYPE).reshape(-1).tobytes() == allp[:k].tobytes()
     it += 1
 print("soak ok", it, "cases")

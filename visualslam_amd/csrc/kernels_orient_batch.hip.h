@@ -80,22 +80,47 @@ __device__ __forceinline__ float magnitude_at(const uint8_t* __restrict__ G, int
     return sqrt_rn_small(xx + yy);  // correctly rounded f32 square root
 }
 
-// grid = (G, frames), 256 threads, dynamic LDS = lds_floats * 4 bytes (row / column maps + strip + region);
-// survivors of octaves outside [oct_lo, oct_hi) are left to the launch with the other LDS budget.
+// The survivor list of a frame is in list order, i.e. octave by octave: ranges[f][o] = index of the first survivor whose
+// octave is >= o (o = 0 .. n_oct; ranges[f][n_oct] = the survivor count).  grid = (frames), 64 threads: lane o searches
+// boundary o.  One launch of k_orient_survivors per octave then takes exactly its own survivors with the LDS budget of
+// that octave (round 2 ran two launches that each walked the whole list and skipped the other's octaves - two dependent
+// loads per skipped survivor - and gave octave 0 the LDS footprint of octave 1: 3 workgroups per CU instead of 8).
+__global__ __launch_bounds__(64) void k_survivor_ranges(const vslam_point* __restrict__ pts, unsigned int cap, const unsigned int* __restrict__ surv,
+                                                         const unsigned int* __restrict__ scounts, unsigned int scap, int n_oct,
+                                                         unsigned int* __restrict__ ranges) {
+    const int f = blockIdx.x, o = threadIdx.x;
+    if (o > n_oct) return;
+    const unsigned int ns = min(scounts[f], scap);
+    unsigned int lo = 0, hi = ns;  // first index with octave >= o
+    while (lo < hi) {
+        const unsigned int mid = (lo + hi) >> 1;
+        if (pts[(size_t)f * cap + surv[(size_t)f * scap + mid]].octave >= o)
+            hi = mid;
+        else
+            lo = mid + 1;
+    }
+    ranges[(size_t)f * (VSLAM_MAX_OCTAVES + 1) + o] = lo;
+}
+
+// grid = (G, frames), 256 threads, dynamic LDS = lds_floats * 4 bytes (row / column maps + taps + strip + region + patch);
+// the survivors of octave `oct` (ranges, k_survivor_ranges).
 __global__ __launch_bounds__(256) void k_orient_survivors(const vslam_point* __restrict__ pts, unsigned int cap,
-                                                           const unsigned int* __restrict__ surv, const unsigned int* __restrict__ scounts,
+                                                           const unsigned int* __restrict__ surv, const unsigned int* __restrict__ ranges,
                                                            unsigned int scap, const uint8_t* __restrict__ pyr, size_t pframe,
-                                                           OrientBatchGeom g, int lds_floats, int oct_lo, int oct_hi,
+                                                           OrientBatchGeom g, int lds_floats, int oct,
                                                            unsigned long long* __restrict__ masks) {
     extern __shared__ __attribute__((aligned(16))) float orient_smem[];
     __shared__ float mw[OR_WIN * OR_WIN];
     __shared__ unsigned long long binmask[OR_BINS][4];  // per bin, per wave: which of the wave's 64 pixels fall into it
     const int f = blockIdx.y;
-    const unsigned int ns = min(scounts[f], scap);
-    for (unsigned int k = blockIdx.x; k < ns; k += gridDim.x) {
-        const vslam_point kp = pts[(size_t)f * cap + surv[(size_t)f * scap + k]];
-        const int o = kp.octave, level = kp.level, x = kp.col, y = kp.row;
-        if (o < oct_lo || o >= oct_hi) continue;  // this launch's LDS budget is for octaves [oct_lo, oct_hi): workgroup-uniform
+    const unsigned int k_begin = ranges[(size_t)f * (VSLAM_MAX_OCTAVES + 1) + oct], k_end = ranges[(size_t)f * (VSLAM_MAX_OCTAVES + 1) + oct + 1];
+    // the next survivor's record is fetched while the current one is processed (two dependent loads: index, record)
+    vslam_point kp_next{};
+    if (k_begin + blockIdx.x < k_end) kp_next = pts[(size_t)f * cap + surv[(size_t)f * scap + k_begin + blockIdx.x]];
+    for (unsigned int k = k_begin + blockIdx.x; k < k_end; k += gridDim.x) {
+        const vslam_point kp = kp_next;
+        if (k + gridDim.x < k_end) kp_next = pts[(size_t)f * cap + surv[(size_t)f * scap + k + gridDim.x]];
+        const int o = oct, level = kp.level, x = kp.col, y = kp.row;
         const int rows = g.rows[o], cols = g.cols[o], gpitch = g.pitch[o];
         const uint8_t* __restrict__ G = pyr + f * pframe + g.oct_off[o] + (size_t)level * rows * gpitch;
         const int kn = g.kn[o][level], R = kn >> 1;

@@ -99,7 +99,7 @@ static int fail(vslam_ctx* c, int code, const std::string& msg) {
 static const char* const kKernelNames =
     "k_resize_linear2x\nk_blur_h_generic\nk_blur_v_generic\n"
     "k_dog5\nk_resize_nearest_half\nk_extrema\nk_pyr_octave\n"
-    "k_gauss_v_strip\nk_gauss_h_strip\nk_gauss_band\nk_resize_linear2x_slide\nk_resize_nearest_half_v4\nk_extrema_w3\nk_extrema_dense\nk_localize_points\nk_orient_keypoints\nk_edge_response_windows\nk_level_gradients\nk_pack_rows\nk_edge_flags\nk_orient_survivors\n"
+    "k_gauss_v_strip\nk_gauss_h_strip\nk_gauss_band\nk_resize_linear2x_slide\nk_resize_nearest_half_v4\nk_extrema_w3\nk_extrema_dense\nk_localize_points\nk_orient_keypoints\nk_edge_response_windows\nk_level_gradients\nk_pack_rows\nk_edge_flags\nk_survivor_ranges\nk_orient_survivors\n"
     "k_harris_strip\nk_flag_count\nk_chunk_scan\nk_flag_scatter\nk_level_gradients\nk_sift_descriptors\nk_pack_offsets\nk_pack_copy\nk_count_totals";
 
 static std::pair<hipEvent_t, hipEvent_t>* timing_slot(vslam_ctx* c);
@@ -1566,6 +1566,7 @@ struct OrientScratch {
     unsigned long long* masks = nullptr;  // [nf][scap] histogram-peak masks
     unsigned int* cws = nullptr;          // compaction scratch
     unsigned int* obegin = nullptr;       // [nf] list length after octave 0 (the early edge-test launch covers [0, obegin))
+    unsigned int* ranges = nullptr;       // [nf][VSLAM_MAX_OCTAVES + 1] first survivor of each octave (k_survivor_ranges)
     bool early_done = false;              // the early launch has been enqueued for this chunk
     bool early_forked = false;            // ... on another stream: ev_edge marks its end
     size_t fwords = 0;
@@ -1573,6 +1574,7 @@ struct OrientScratch {
 static size_t orient_scratch_bytes(const vslam_params& p, int nf) {
     const size_t fwords = ((size_t)p.dog_cap + 63) / 64, scap = p.oriented_cap;
     return ws_need((size_t)nf * fwords * 8) + ws_need((size_t)nf * scap * 4) + 2 * ws_need((size_t)nf * 4) + ws_need((size_t)nf * scap * 8) +
+           ws_need((size_t)nf * (VSLAM_MAX_OCTAVES + 1) * 4) +
            ws_need(4 * compaction_ws_elems(std::max(fwords, scap), nf));
 }
 static int orient_scratch_take(vslam_ctx* c, const vslam_params& p, int nf, OrientScratch& s) {
@@ -1582,48 +1584,39 @@ static int orient_scratch_take(vslam_ctx* c, const vslam_params& p, int nf, Orie
     s.surv = ws_take<unsigned int>(c, (size_t)nf * scap);
     s.scounts = ws_take<unsigned int>(c, nf);
     s.obegin = ws_take<unsigned int>(c, nf);
+    s.ranges = ws_take<unsigned int>(c, (size_t)nf * (VSLAM_MAX_OCTAVES + 1));
     s.early_done = false;
     s.masks = ws_take<unsigned long long>(c, (size_t)nf * scap);
     s.cws = ws_take<unsigned int>(c, compaction_ws_elems(std::max(s.fwords, scap), nf));
-    if (!s.flags || !s.surv || !s.scounts || !s.obegin || !s.masks || !s.cws) return fail(c, VSLAM_ERR_NOMEM, "workspace sizing error (orient)");
+    if (!s.flags || !s.surv || !s.scounts || !s.obegin || !s.ranges || !s.masks || !s.cws) return fail(c, VSLAM_ERR_NOMEM, "workspace sizing error (orient)");
     return VSLAM_OK;
 }
 
-// Geometry / blur taps of the batched filterKeypoints and the LDS budgets of its two launches.
+// Geometry / blur taps of the batched filterKeypoints and the LDS budget of each octave's launch.
 struct OrientPlan {
     OrientBatchGeom g;
-    int need_lo = 0, need_hi = 0;  // LDS floats for the octaves whose magnitude region fits beside 3-4 other workgroups / at all
-    int split = 0;                 // first octave handled by the big-LDS launch
+    int need[VSLAM_MAX_OCTAVES] = {};  // LDS floats of octave o's launch of k_orient_survivors
 };
 static int make_orient_plan(vslam_ctx* c, const vslam_params& p, const vslam_batch_layout& L, OrientPlan& pl) {
     OrientBatchGeom& g = pl.g;
     std::memset(&g, 0, sizeof(g));
     g.n_oct = L.n_octaves;
-    int& need_lo = pl.need_lo;
-    int& need_hi = pl.need_hi;
-    constexpr int kSmallLds = 10 * 1024 + 512, kBigLds = 36 * 1024;  // floats: 42 KB, 144 KB
-    int& split = pl.split;
-    split = L.n_octaves;
+    constexpr int kBigLds = 36 * 1024;  // floats: 144 KB
     for (int o = 0; o < L.n_octaves; ++o) {
         g.rows[o] = L.rows[o];
         g.cols[o] = L.cols[o];
         g.pitch[o] = L.pitch[o];
         g.oct_off[o] = L.octave_offset[o];
-        int worst = 0;
+        int worst = 0, strip = 0;
         for (int l = 1; l <= 3; ++l) {  // the levels initialKeypointDetection produces (Diff_of_Gauss.cpp:264)
             TRY(get_orient_taps(c, 1.5 * sigma_at(p.sigma0, o, l), &g.kern[o][l], &g.kn[o][l]));  // :346
             const int span = OR_WIN + 2 * (g.kn[o][l] / 2);
-            worst = std::max(worst, 3 * span + span * OR_WIN + span * span);  // maps + taps + strip + region (k_orient_survivors)
+            // maps + taps + strip + region + the u8 patch of interior survivors (k_orient_survivors)
+            worst = std::max(worst, 3 * span + span * OR_WIN + span * span + (span + 2) * ((span + 8) >> 2));
+            strip = std::max(strip, span * (OR_WIN + 3));
         }
-        if (worst <= kSmallLds && split == L.n_octaves)
-            need_lo = std::max(need_lo, worst);
-        else {
-            split = std::min(split, o);
-            // regions that exceed even the big budget are read tap by tap; the strip and the maps still need room
-            int strip = 0;
-            for (int l = 1; l <= 3; ++l) strip = std::max(strip, (OR_WIN + 2 * (g.kn[o][l] / 2)) * (OR_WIN + 3));
-            need_hi = std::max(need_hi, std::min(std::max(worst, strip), std::max(kBigLds, strip)));
-        }
+        // regions that exceed even the big budget are read tap by tap; the strip, the maps and the taps still need room
+        pl.need[o] = worst <= kBigLds ? worst : std::max(strip, std::min(worst, kBigLds));
     }
     return VSLAM_OK;
 }
@@ -1657,7 +1650,6 @@ static int enqueue_orient_batch(vslam_ctx* c, const vslam_params& p, const vslam
                                 size_t pframe, const vslam_point* points, const unsigned int* counts, OrientScratch& s,
                                 vslam_point* oriented, unsigned int* oriented_counts) {
     const OrientBatchGeom& g = pl.g;
-    const int need_lo = pl.need_lo, need_hi = pl.need_hi, split = pl.split;
     const size_t scap = p.oriented_cap;
     const size_t fw = s.fwords;
     if (s.early_done && s.early_forked) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_edge, 0));  // the two launches share a flag word
@@ -1665,18 +1657,13 @@ static int enqueue_orient_batch(vslam_ctx* c, const vslam_params& p, const vslam
            (const unsigned int*)(s.early_done ? s.obegin : nullptr), counts, p.dog_cap, pyr, pframe, g, s.flags, fw);
     SurvivorEntries se{s.flags, fw, s.surv};
     TRY(enqueue_compaction(c, se, fw, nf, s.cws, (unsigned int)scap, s.scounts, 0));
+    LAUNCH(c, "k_survivor_ranges", k_survivor_ranges, dim3(nf), dim3(64), points, p.dog_cap, s.surv, s.scounts, (unsigned int)scap, L.n_octaves, s.ranges);
     TRY(raise_dyn_lds(c, reinterpret_cast<const void*>(&k_orient_survivors)));
     const int gwg = (int)std::min<long>(1024, std::max<long>(16, 8192 / nf));
-    if (split > 0) {
+    for (int o = 0; o < L.n_octaves; ++o) {  // one launch per octave: its own survivors, its own LDS footprint
         TimedScope ts(c, "k_orient_survivors");
-        hipLaunchKernelGGL(k_orient_survivors, dim3(gwg, nf), dim3(256), (size_t)need_lo * 4, c->stream, points, p.dog_cap, s.surv, s.scounts,
-                           (unsigned int)scap, pyr, pframe, g, need_lo, 0, split, s.masks);
-    }
-    HIPCHK(c, hipGetLastError());
-    if (split < L.n_octaves) {
-        TimedScope ts(c, "k_orient_survivors");
-        hipLaunchKernelGGL(k_orient_survivors, dim3(gwg, nf), dim3(256), (size_t)need_hi * 4, c->stream, points, p.dog_cap, s.surv, s.scounts,
-                           (unsigned int)scap, pyr, pframe, g, need_hi, split, L.n_octaves, s.masks);
+        hipLaunchKernelGGL(k_orient_survivors, dim3(gwg, nf), dim3(256), (size_t)pl.need[o] * 4, c->stream, points, p.dog_cap, s.surv, s.ranges,
+                           (unsigned int)scap, pyr, pframe, g, pl.need[o], o, s.masks);
     }
     HIPCHK(c, hipGetLastError());
     OrientBatchEntries oe{s.masks, s.surv, s.scounts, (unsigned int)scap, points, p.dog_cap, oriented};
