@@ -48,6 +48,7 @@ struct SiftShared {
     float mw[SIFT_WIN * SIFT_WIN];    // magWeighted
     float d[SIFT_DESC];
     uint8_t bin[SIFT_WIN * SIFT_WIN];
+    float wmax[2], first;  // max_element over the 128 histogram values: per-wave maxima, element 0
     int bad;
 };
 
@@ -151,23 +152,30 @@ __device__ __forceinline__ void sift_one_keypoint(SiftShared& sh, const vslam_po
         sh.d[t] = h;
     }
     __syncthreads();
-    // *max_element (operator< scan: a NaN first element stays), c / max, min(c, 0.2f) as std::min,
-    // again c / max (:659-675).  Every thread scans the 128 values itself: same result everywhere.
-    float v = 0.0f;
-    if (t < SIFT_DESC) {
-        float mx = sh.d[0];
-        for (int b = 1; b < SIFT_DESC; ++b) mx = mx < sh.d[b] ? sh.d[b] : mx;
-        v = sh.d[t] / mx;
-        v = 0.2f < v ? 0.2f : v;
-    }
-    __syncthreads();
-    if (t < SIFT_DESC) sh.d[t] = v;
-    __syncthreads();
-    if (t < SIFT_DESC) {
-        float mx = sh.d[0];
-        for (int b = 1; b < SIFT_DESC; ++b) mx = mx < sh.d[b] ? sh.d[b] : mx;
-        desc[t] = v / mx;
-    }
+    // *max_element (operator< scan), c / max, min(c, 0.2f) as std::min, again c / max (:659-675).  The scan keeps a NaN
+    // first element and skips every later NaN, i.e. its result is d[0] if that is NaN and otherwise the IEEE maxNum of all
+    // elements (v_max_f32 ignores a NaN operand; the values are sums of non-negative products, so no -0 can decide a tie).
+    // Round 2 let each of the 128 threads scan all 128 values, twice (two fifths of the kernel's instructions); now the
+    // two waves that hold the values reduce them with lane exchanges and meet through two LDS words.
+    auto max_element128 = [&](float val) -> float {  // val: this thread's element (t < 128); every thread returns the maximum
+        float m = t < SIFT_DESC ? val : -INFINITY;
+        if (t < SIFT_DESC && val != val) m = -INFINITY;  // NaNs do not take part; d[0]'s NaN is handled below
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+        if ((t & 63) == 0 && t < SIFT_DESC) sh.wmax[t >> 6] = m;
+        if (t == 0) sh.first = val;
+        __syncthreads();
+        const float first = sh.first;
+        const float r = first != first ? first : fmaxf(sh.wmax[0], sh.wmax[1]);
+        __syncthreads();  // wmax / first are free again
+        return r;
+    };
+    const float d_t = t < SIFT_DESC ? sh.d[t] : 0.0f;
+    const float mx1 = max_element128(d_t);
+    float v = d_t / mx1;
+    v = 0.2f < v ? 0.2f : v;
+    const float mx2 = max_element128(v);
+    if (t < SIFT_DESC) desc[t] = v / mx2;
     if (t == 0 && defined) *defined = 1;
     __syncthreads();
 }
@@ -202,8 +210,11 @@ __global__ __launch_bounds__(256) void k_sift_descriptors_batch(const vslam_poin
     __shared__ SiftShared sh;
     const int f = blockIdx.y;
     const unsigned int n = min(counts[f], cap);
+    vslam_point kp_next{};  // the next record is fetched while the current descriptor is computed
+    if (blockIdx.x < n) kp_next = oriented[(size_t)f * cap + blockIdx.x];
     for (unsigned int q = blockIdx.x; q < n; q += gridDim.x) {
-        const vslam_point kp = oriented[(size_t)f * cap + q];
+        const vslam_point kp = kp_next;
+        if (q + gridDim.x < n) kp_next = oriented[(size_t)f * cap + q + gridDim.x];
         const int o = kp.octave;
         const uint8_t* G = pyr + f * pframe + g.oct_off[o] + (size_t)kp.level * g.rows[o] * g.pitch[o];
         const unsigned int b = (unsigned int)kp.value / 10u;
