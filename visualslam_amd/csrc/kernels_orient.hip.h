@@ -57,8 +57,7 @@ __global__ __launch_bounds__(256) void k_orient_keypoints(const vslam_point* __r
                                                            unsigned long long* __restrict__ masks) {
     extern __shared__ __attribute__((aligned(16))) float orient_smem[];
     __shared__ float mw[OR_WIN * OR_WIN];
-    __shared__ uint8_t bin[OR_WIN * OR_WIN];
-    __shared__ float histo[OR_BINS];
+    __shared__ unsigned long long binmask[OR_BINS][4];  // per bin, per wave: the wave's pixels that fall into it
     __shared__ int keep_s;
     const int q = blockIdx.x;
     const vslam_point kp = kps[q];
@@ -96,6 +95,7 @@ __global__ __launch_bounds__(256) void k_orient_keypoints(const vslam_point* __r
         rb[it] = s0;
     }
     __syncthreads();
+    int bin_of;
     {
         const int i = threadIdx.x >> 4, j = threadIdx.x & 15;
         float s0 = kl[R] * rb[(i + R) * OR_WIN + j];
@@ -105,21 +105,33 @@ __global__ __launch_bounds__(256) void k_orient_keypoints(const vslam_point* __r
         const float reductionCoeff = (float)OR_BINS / 360.0f;  // :114
         const float o = lv.orient[level][(size_t)clampi(y + i - OR_PAD, 0, rows - 1) * cols + clampi(x + j - OR_PAD, 0, cols - 1)];
         const int index = (int)(o * reductionCoeff);  // :126; fastAtan2 on integer gradients stays below 359.8
-        bin[threadIdx.x] = (uint8_t)min(max(index, 0), OR_BINS - 1);
+        bin_of = min(max(index, 0), OR_BINS - 1);
     }
-    __syncthreads();
-    if (threadIdx.x < OR_BINS) {  // one lane per bin, pixels in row-major order: the reference's += order
-        float h = 0.0f;
-        for (int p = 0; p < OR_WIN * OR_WIN; ++p)
-            if (bin[p] == threadIdx.x) h += mw[p];
-        histo[threadIdx.x] = h;
+    // histogram (:112-133): a bin's magnitudes in pixel order.  Every wave ballots its 64 pixels bin by bin, the bin's
+    // lane then adds only its own pixels (ascending bit = ascending pixel index) - as in k_orient_survivors
+#pragma unroll 4
+    for (int b = 0; b < OR_BINS; ++b) {
+        const unsigned long long m = __ballot(bin_of == b);
+        if ((threadIdx.x & 63) == 0) binmask[b][threadIdx.x >> 6] = m;
     }
     __syncthreads();
     if (threadIdx.x < 64) {
-        float mx = histo[0];
-        for (int b = 1; b < OR_BINS; ++b) mx = fmaxf(mx, histo[b]);
-        const float peakThreshold = mx * 0.8f;  // :358
-        const bool peak = threadIdx.x < OR_BINS && histo[threadIdx.x] > peakThreshold;  // :362
+        float h = 0.0f;
+        if (threadIdx.x < OR_BINS) {
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                unsigned long long m = binmask[threadIdx.x][w];
+                while (m) {
+                    h += mw[64 * w + __builtin_ctzll(m)];
+                    m &= m - 1;
+                }
+            }
+        }
+        float mx = threadIdx.x < OR_BINS ? h : 0.0f;  // sums of non-negative weights: 0 is neutral
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+        const float peakThreshold = mx * 0.8f;                          // :358
+        const bool peak = threadIdx.x < OR_BINS && h > peakThreshold;  // :362
         const unsigned long long m = __ballot(peak);
         if (threadIdx.x == 0) masks[q] = m;
     }
