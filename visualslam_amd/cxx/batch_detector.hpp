@@ -131,7 +131,7 @@ private:
         uint8_t* h_defined = nullptr;
         vslam_kp* h_hpacked = nullptr;  // pinned
         vslam_point* h_ppacked = nullptr;
-        void *up_done = nullptr, *comp_done = nullptr, *down_done = nullptr;  // hipEvent_t
+        void *up_done = nullptr, *comp_done = nullptr, *down_done = nullptr, *det_done = nullptr;  // hipEvent_t
         int n = 0;
         BatchResult res;
     };
@@ -140,7 +140,8 @@ private:
     vslam_batch_layout L_{};
     Options opt_;
     vslam_ctx* ctx_ = nullptr;
-    void *compute_ = nullptr, *up_ = nullptr, *down_ = nullptr;  // hipStream_t
+    vslam_ctx* ctx_pack_ = nullptr;  // a second context on the pack stream: the list packing of batch k runs beside the kernels of batch k+1
+    void *compute_ = nullptr, *up_ = nullptr, *down_ = nullptr, *pack_ = nullptr;  // hipStream_t
     std::vector<Slot> slots_;
     std::vector<void*> dev_allocs_, pinned_allocs_;
     uint64_t *d_totals_ = nullptr, *d_totals_all_ = nullptr;
