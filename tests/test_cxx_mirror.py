@@ -288,3 +288,32 @@ def test_stream_two_ranks_on_one_gpu_with_the_rehearsal_exchange(built, tmp_path
         want_p = np.concatenate([pyr.extrema(o, 3, 8)[1] for o in range(4)])
         pyr.close()
         assert kp.tobytes() == want_k.tobytes() and pt.tobytes() == want_p.tobytes(), r
+
+
+@pytest.mark.gpu
+def test_stream_reads_a_raw_frame_file(built, tmp_path):
+    # --source <file>: a camera stream recorded as raw 8-bit frames (rows x cols bytes each), read cyclically
+    import numpy as np
+
+    import oracle
+    from visualslam_amd import synth
+
+    rows, cols = 96, 160
+    rec = np.stack([synth.frame_np(rows, cols, f, 3, "noise" if f == 1 else "checker") for f in range(3)])
+    raw = tmp_path / "camera.y8"
+    rec.tofile(raw)
+    dump = tmp_path / "lists.bin"
+    r = subprocess.run([os.path.join(built, "Stream"), "--mode", "hostfed", "--frames", "5", "--batches", "2", "--warmup", "0", "--rows", str(rows), "--cols", str(cols),
+                        "--octaves", "3", "--source", str(raw), "--dump", str(dump)], capture_output=True, text=True, timeout=600, env=_rank_env(0, 1, 29950))
+    assert r.returncode == 0, r.stdout + r.stderr
+    _, _, frames = _read_dump(dump)
+    assert len(frames) == 5
+    for f in range(5):  # frame f of the batch is frame f % 3 of the file
+        img = rec[f % 3]
+        kp, pt, th, td = frames[f]
+        want_k = oracle.harris_keypoints(oracle.nms2(oracle.harris_response(img), 5)[0])
+        pyr = oracle.Pyramid(img, 3, 1.6)
+        want_p = np.concatenate([pyr.extrema(o, 3, 8)[1] for o in range(3)])
+        pyr.close()
+        assert th == len(want_k) and kp.tobytes() == want_k.tobytes(), f
+        assert td == len(want_p) and pt.tobytes() == want_p.tobytes(), f

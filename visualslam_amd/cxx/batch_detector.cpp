@@ -52,6 +52,15 @@ void BatchDetector::free_pinned(void* p) {
 }
 
 BatchDetector::BatchDetector(const Options& opt) : opt_(opt) {
+    try {
+        init(opt);
+    } catch (...) {  // a constructor that throws runs no destructor: give back what was allocated so far
+        release();
+        throw;
+    }
+}
+
+void BatchDetector::init(const Options& opt) {
     if (opt.batch <= 0 || opt.rows <= 0 || opt.cols <= 0 || opt.slots < 1) throw Error(VSLAM_ERR_INVALID, "BatchDetector: bad options");
     if (opt.custom_params)
         p_ = opt.params;
@@ -173,18 +182,26 @@ BatchDetector::BatchDetector(const Options& opt) : opt_(opt) {
     HIPX(hipDeviceSynchronize());
 }
 
-BatchDetector::~BatchDetector() {
+BatchDetector::~BatchDetector() { release(); }
+
+void BatchDetector::release() {
     (void)hipSetDevice(opt_.device);
     (void)hipDeviceSynchronize();
     if (ctx_pack_) (void)vslam_ctx_destroy(ctx_pack_);
     if (ctx_) (void)vslam_ctx_destroy(ctx_);
+    ctx_pack_ = ctx_ = nullptr;
     for (Slot& s : slots_)
         for (void* e : {s.up_done, s.comp_done, s.down_done, s.det_done})
             if (e) (void)hipEventDestroy((hipEvent_t)e);
+    slots_.clear();
     for (void* p : dev_allocs_) (void)hipFree(p);
     for (void* p : pinned_allocs_) (void)hipHostFree(p);
-    for (void* s : {up_, down_, pack_, compute_})
-        if (s) (void)hipStreamDestroy((hipStream_t)s);
+    dev_allocs_.clear();
+    pinned_allocs_.clear();
+    for (void** s : {&up_, &down_, &pack_, &compute_}) {
+        if (*s) (void)hipStreamDestroy((hipStream_t)*s);
+        *s = nullptr;
+    }
 }
 
 void BatchDetector::sync() {

@@ -135,6 +135,8 @@ private:
         int n = 0;
         BatchResult res;
     };
+    void init(const Options& opt);
+    void release();
     void run_on_slot(Slot& s, const uint8_t* d_frames, size_t stride, int n);
     vslam_params p_{};
     vslam_batch_layout L_{};
