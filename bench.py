@@ -98,8 +98,12 @@ def cpu_baseline(rows, cols, n_oct, sample_frames, gpu_keypoints=None):
     }
 
 
-def cxx_host_runs(rows, cols, n, octaves):
-    """frames/s of the C++ throughput host on this workload: visualslam_amd/bin/Stream, one rank over RCCL."""
+def cxx_host_runs(rows, cols, n, octaves, rank=0, world=1, local_rank=0):
+    """frames/s of the C++ throughput host on this workload: visualslam_amd/bin/Stream, one process per rank, the
+    counts all-gathered through RCCL's C API.  With world > 1 every rank of this job starts one Stream process with
+    its own RANK / LOCAL_RANK (so the C++ processes form their own RCCL communicator over the same GPUs); rank 0's
+    child prints the job's line.  Device-resident mode always; host-fed only at N = 1 (it needs the host's memory
+    bandwidth to itself to mean anything)."""
     import subprocess
 
     exe = os.path.join(ROOT, "visualslam_amd", "bin", "Stream")
@@ -107,13 +111,22 @@ def cxx_host_runs(rows, cols, n, octaves):
         r = subprocess.run(["make", "-C", os.path.join(ROOT, "visualslam_amd", "cxx")], capture_output=True, text=True)
         if r.returncode != 0:
             return {"error": "building the C++ host failed: " + (r.stdout + r.stderr)[-400:]}
-    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK=os.environ.get("LOCAL_RANK", "0"), MASTER_ADDR="127.0.0.1")
+    port = int(os.environ.get("MASTER_PORT", "29533")) + 7  # the rendezvous of the C++ ranks (MASTER_PORT itself is torch's store)
+    env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(local_rank), MASTER_ADDR="127.0.0.1", VSLAM_RDV_PORT=str(port))
+    env.pop("VSLAM_COUNT_BACKEND", None)
+    if os.environ.get("VSLAM_BENCH_SHARE_GPU") == "1":  # rehearsal on one GPU (tests/test_bench_ranks.py): RCCL refuses two ranks per device
+        env["VSLAM_COUNT_BACKEND"] = "tcp"
     res = {}
-    for mode in ("device", "hostfed"):
+    for mode in (("device", "hostfed") if world == 1 else ("device",)):
         try:
             r = subprocess.run([exe, "--mode", mode, "--frames", str(n), "--batches", "30" if mode == "device" else "40", "--warmup", "6", "--rows", str(rows), "--cols", str(cols),
-                                "--octaves", str(octaves)], capture_output=True, text=True, timeout=600, env=env)
-            res[mode] = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {"error": (r.stdout + r.stderr)[-400:]}
+                                "--octaves", str(octaves)], capture_output=True, text=True, timeout=600 if world == 1 else 180, env=env)
+            if r.returncode != 0:
+                res[mode] = {"error": (r.stdout + r.stderr)[-400:]}
+            elif rank == 0:
+                res[mode] = json.loads(r.stdout.strip().splitlines()[-1])
+            else:
+                res[mode] = {"rank": rank, "ok": True}
         except Exception as e:
             res[mode] = {"error": repr(e)}
     return res
@@ -135,7 +148,7 @@ def main():
                     help="1: also run filterKeypoints on every frame's keypoint list (SURVEY 8f row 3); implies --localize 1")
     ap.add_argument("--cpu-sample", type=int, default=6, help="frames in the CPU baseline sample (0 = skip)")
     ap.add_argument("--modes", type=int, default=1, help="1: also time the localize / orient list modes (the `modes` object)")
-    ap.add_argument("--cxx-host", type=int, default=1, help="1: also run the C++ Stream executable on the same workload (N = 1 only)")
+    ap.add_argument("--cxx-host", type=int, default=1, help="1: also run the C++ Stream executable on the same workload (one process per rank, after the measurement)")
     ap.add_argument("--stream", choices=["side", "null"], default="side",
                     help="stream of the whole job: a torch side stream (default) or torch's default (NULL) stream")
     args = ap.parse_args()
@@ -400,13 +413,21 @@ def main():
     # The same workload driven by the C++ host (visualslam_amd/cxx: BatchDetector + Stream, RCCL from librccl,
     # no torch in that process): device-resident, and host-fed (pinned frames in, packed lists out).  Child
     # processes, after this process has released the GPU memory; N = 1 only; never part of `value`.
-    cxx_wanted = rank == 0 and world == 1 and args.cxx_host
+    # (under the rehearsal switches of tests/test_bench_ranks.py the ranks share one GPU, which RCCL refuses: the C++
+    # processes then exchange their counts over the TCP rehearsal backend)
+    cxx_wanted = bool(args.cxx_host) and (world == 1 or backend == "nccl" or os.environ.get("VSLAM_BENCH_SHARE_GPU") == "1")
     ctx.close()
     if cxx_wanted:
         shared.clear()
         del frames
         torch.cuda.empty_cache()
-        line["cxx_host"] = cxx_host_runs(rows, cols, n, args.octaves)
+        if use_dist:
+            dist.barrier()  # every rank has released its buffers and starts its C++ process now
+        cxx = cxx_host_runs(rows, cols, n, args.octaves, rank, world, local_rank_dev)
+        if use_dist:
+            dist.barrier()
+        if rank == 0:
+            line["cxx_host"] = cxx
     if rank == 0:
         print(json.dumps(line))
     if use_dist:

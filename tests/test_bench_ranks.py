@@ -28,6 +28,11 @@ def test_bench_two_ranks_share_one_gpu():
     assert len(lines) == 1, r.stdout  # rank 0 prints the one JSON line
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    # the C++ host after the measurement: one Stream process per rank, their own communicator (here the TCP rehearsal
+    # exchange), rank 0's child reports the job: two ranks, two different camera streams, the same totals as the Python ranks
+    cx = d["cxx_host"]["device"]
+    assert cx["n_gpus"] == 2 and cx["frames_per_sec"] > 0 and len(cx["counts_by_rank"]) == 2, cx
+    assert cx["keypoints_per_batch"] == {"harris": d["keypoints_per_step"]["harris"], "dog": d["keypoints_per_step"]["dog"]}
     # both ranks' streams are counted: the per-step totals are the sum over two different streams
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--frames", "4", "--rows", "240", "--cols", "320", "--steps", "2",
                           "--warmup", "1", "--cpu-sample", "0"], capture_output=True, text=True, timeout=600, cwd=ROOT)
@@ -59,6 +64,8 @@ def test_bench_one_rank_goes_through_rccl():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["value"] > 0
     assert d["distributed"] == {"initialized": True, "world_size": 1, "backend": "nccl", "ranks_gathered": 1}
+    assert d["cxx_host"]["device"]["frames_per_sec"] > 0 and "RCCL" in d["cxx_host"]["device"]["host"]
+    assert d["cxx_host"]["device"]["keypoints_per_batch"] == {"harris": d["keypoints_per_step"]["harris"], "dog": d["keypoints_per_step"]["dog"]}
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--frames", "8", "--rows", "240", "--cols", "320", "--steps", "2",
                           "--warmup", "1", "--cpu-sample", "0", "--modes", "0"], capture_output=True, text=True, timeout=600, cwd=ROOT)
     d1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][0])

@@ -317,3 +317,15 @@ def test_stream_reads_a_raw_frame_file(built, tmp_path):
         pyr.close()
         assert th == len(want_k) and kp.tobytes() == want_k.tobytes(), f
         assert td == len(want_p) and pt.tobytes() == want_p.tobytes(), f
+
+
+def test_stream_rendezvous_under_torchrun(built):
+    # torch.distributed.run --no-python sets RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* for a native program: the C++
+    # ranks find each other on MASTER_PORT + 1 (MASTER_PORT itself is torch's store)
+    import sys
+
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--no-python", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
+                        "--master-port", "29871", os.path.join(built, "Stream"), "--rdv-selftest"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert sorted(g["rank"] for g in got) == [0, 1, 2] and len({g["id_hash"] for g in got}) == 1
