@@ -1854,7 +1854,8 @@ int vslam_detect_batch_dev(vslam_ctx* c, const vslam_params* pp, const uint8_t* 
 int vslam_pack_lists_dev(vslam_ctx* c, const void* lists, size_t record_bytes, uint32_t cap, const uint32_t* counts, int n_frames,
                          void* packed, size_t packed_bytes, uint64_t* offsets) {
     TRY(bind_device(c));
-    ARGCHK(c, lists && counts && offsets && n_frames > 0 && cap > 0 && (packed || packed_bytes == 0), "pack_lists: bad arguments");
+    ARGCHK(c, lists && counts && offsets && n_frames > 0 && n_frames <= 65535 && cap > 0 && (packed || packed_bytes == 0),
+           "pack_lists: bad arguments (1 .. 65535 frames per call)");
     ARGCHK(c, record_bytes >= 4 && record_bytes % 4 == 0 && record_bytes <= 4096, "pack_lists: record_bytes must be a multiple of 4");
     const unsigned int rec_dw = (unsigned int)(record_bytes / 4);
     LAUNCH(c, "k_pack_offsets", k_pack_offsets, dim3(1), dim3(256), counts, cap, n_frames, (unsigned long long*)offsets);
