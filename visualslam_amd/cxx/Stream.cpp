@@ -132,9 +132,10 @@ double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock:
 int main(int argc, char** argv) {
     try {
         // The HIP runtime spreads a process's streams over 4 hardware queues by default; this process has the
-        // library's three side streams, the copy streams of the host-fed pipeline and RCCL's own.  Streams that
-        // share a queue serialise (measured: -2 % frames/s device-resident).  Must be set before HIP starts.
-        ::setenv("GPU_MAX_HW_QUEUES", "8", 0);
+        // library's three side streams, the upload / download / pack streams of the host-fed pipeline and RCCL's own.
+        // Streams that share a queue serialise (measured: -2 % frames/s device-resident with 4; host-fed 13.1 k
+        // steady state with 8, 13.2-13.4 k with 10-16).  Must be set before HIP starts.
+        ::setenv("GPU_MAX_HW_QUEUES", "12", 0);
         const Args a = parse(argc, argv);
         const vslam::RankEnv env = vslam::RankEnv::from_environment();
         if (a.rdv_selftest) {  // the TCP hand-off of the RCCL id alone (no GPU): rank 0's bytes must reach every rank
