@@ -329,3 +329,37 @@ def test_stream_rendezvous_under_torchrun(built):
     assert r.returncode == 0, r.stdout + r.stderr
     got = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
     assert sorted(g["rank"] for g in got) == [0, 1, 2] and len({g["id_hash"] for g in got}) == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["device", "hostfed"])
+def test_stream_list_modes_match_the_oracle_counts(built, mode):
+    # --lists orient: FeaturePointLocalization + filterKeypoints for every frame of the batch from the C++ host; a
+    # ragged frame size (pitched pyramid planes) and a camera file with a noise frame so that the stages have work
+    import numpy as np
+
+    import oracle
+    from visualslam_amd import synth
+
+    rows, cols, n = 150, 217, 4  # building.jpg's coarsest octave size: odd width, planes pitched to 224
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as td:
+        rec = np.stack([synth.frame_np(rows, cols, f, 4, "noise" if f == 2 else "checker") for f in range(n)])
+        raw = os.path.join(td, "cam.y8")
+        rec.tofile(raw)
+        dump = os.path.join(td, "l.bin")
+        r = subprocess.run([os.path.join(built, "Stream"), "--mode", mode, "--lists", "orient", "--frames", str(n), "--batches", "2", "--warmup", "0", "--rows", str(rows),
+                            "--cols", str(cols), "--octaves", "3", "--source", raw, "--dump", dump], capture_output=True, text=True, timeout=600, env=_rank_env(0, 1, 29960))
+        assert r.returncode == 0, r.stdout + r.stderr
+        line = json.loads(r.stdout.strip().splitlines()[-1])
+        _, _, frames = _read_dump(dump)
+    want_oriented = 0
+    for f in range(n):
+        pyr = oracle.Pyramid(rec[f], 3, 1.6)
+        kps = [pyr.keypoints(o, 3) for o in range(3)]
+        want_oriented += sum(len(pyr.filter_keypoints(o, kps[o])) for o in range(3))
+        pyr.close()
+        allk = np.concatenate(kps)
+        assert frames[f][3] == len(allk) and frames[f][1].tobytes() == allk.tobytes(), f  # the DoG list = the localized keypoints
+    assert line["lists"] == "orient" and line["oriented_points_rank0_last_batch"] == want_oriented > 100
