@@ -98,6 +98,52 @@ def cpu_baseline(rows, cols, n_oct, sample_frames, gpu_keypoints=None):
     }
 
 
+def live_traffic(kname, rows, cols, octaves, frames=64):
+    """HBM bytes per frame of kernel `kname`, MEASURED for this run's build on this box: two child runs of this
+    script under rocprofv3 (separate `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` passes, nothing else traced), a small
+    batch of the same frames; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950 (it counts 64 B of every
+    128-B request), both reported in KiB.  None when rocprofv3 is missing or a pass fails (the caller then falls back
+    to the committed profile and says so)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    prof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not prof:
+        return None
+    sums, launches = {}, 0
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            with tempfile.TemporaryDirectory(dir="/tmp") as td:
+                cmd = [prof, "--pmc", counter, "--output-format", "csv", "-d", td, "-o", "r", "--", sys.executable, os.path.join(ROOT, "bench.py"),
+                       "--frames", str(frames), "--steps", "1", "--warmup", "1", "--cpu-sample", "0", "--modes", "0", "--cxx-host", "0", "--live-traffic", "0",
+                       "--rows", str(rows), "--cols", str(cols), "--octaves", str(octaves)]
+                env = dict(os.environ, TMPDIR="/tmp")
+                for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+                    env.pop(k, None)
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd="/tmp", env=env)
+                files = glob.glob(td + "/**/*_counter_collection.csv", recursive=True)
+                if r.returncode != 0 or not files:
+                    return None
+                tot, n_l = 0.0, 0
+                for f in files:
+                    for row in csv.DictReader(open(f)):
+                        if kname in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                            tot += float(row["Counter_Value"])
+                            n_l += 1
+                if n_l == 0:
+                    return None
+                sums[counter], launches = tot, n_l
+    except Exception:
+        return None
+    batches = 2  # warm-up + the step
+    bytes_total = (2.0 * sums["FETCH_SIZE"] + sums["WRITE_SIZE"]) * 1024.0
+    return {"hbm_bytes_per_frame": bytes_total / (frames * batches), "frames_per_batch": frames, "batches": batches, "launches": launches,
+            "fetch_KiB": sums["FETCH_SIZE"], "write_KiB": sums["WRITE_SIZE"]}
+
+
 def cxx_host_runs(rows, cols, n, octaves, rank=0, world=1, local_rank=0):
     """frames/s of the C++ throughput host on this workload: visualslam_amd/bin/Stream, one process per rank, the
     counts all-gathered through RCCL's C API.  With world > 1 every rank of this job starts one Stream process with
@@ -148,6 +194,8 @@ def main():
                     help="1: also run filterKeypoints on every frame's keypoint list (SURVEY 8f row 3); implies --localize 1")
     ap.add_argument("--cpu-sample", type=int, default=6, help="frames in the CPU baseline sample (0 = skip)")
     ap.add_argument("--modes", type=int, default=1, help="1: also time the localize / orient list modes (the `modes` object)")
+    ap.add_argument("--live-traffic", type=int, default=1,
+                    help="1: measure roofline.traffic in this run (two rocprofv3 --pmc child passes on a 64-frame batch, N = 1 only); 0: the committed profile's figure")
     ap.add_argument("--cxx-host", type=int, default=1, help="1: also run the C++ Stream executable on the same workload (one process per rank, after the measurement)")
     ap.add_argument("--stream", choices=["side", "null"], default="side",
                     help="stream of the whole job: a torch side stream (default) or torch's default (NULL) stream")
@@ -340,7 +388,14 @@ def main():
             # so the figure is the committed profile's, scaled to this run's frames per launch
             traffic = tsrc = tprof = None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tpath):
+            # (not inside a profiler run of this script itself: tools/refresh_profiles.sh wraps it in rocprofv3 with --modes 0)
+            profiled = any("rocprof" in os.environ.get(k, "") for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD"))
+            lt = live_traffic(kname, rows, cols, args.octaves) if (args.live_traffic and args.modes and world == 1 and not profiled) else None
+            if lt:
+                traffic = lt["hbm_bytes_per_frame"] * n * args.steps / launches
+                tsrc = "measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child passes (separate), 2*FETCH_SIZE + WRITE_SIZE KiB"
+                tprof = dict(lt, live=True, scaled_to_frames_per_launch=n * args.steps / launches)
+            elif os.path.exists(tpath):
                 tj = json.load(open(tpath))
                 t = tj.get(kname)
                 if t:

@@ -21,7 +21,7 @@ def test_bench_two_ranks_share_one_gpu():
     env = dict(os.environ, VSLAM_BENCH_BACKEND="gloo", VSLAM_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--frames", "4", "--rows", "240", "--cols", "320",
-           "--steps", "2", "--warmup", "1", "--cpu-sample", "0"]
+           "--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--live-traffic", "0"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -35,7 +35,7 @@ def test_bench_two_ranks_share_one_gpu():
     assert cx["keypoints_per_batch"] == {"harris": d["keypoints_per_step"]["harris"], "dog": d["keypoints_per_step"]["dog"]}
     # both ranks' streams are counted: the per-step totals are the sum over two different streams
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--frames", "4", "--rows", "240", "--cols", "320", "--steps", "2",
-                          "--warmup", "1", "--cpu-sample", "0"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+                          "--warmup", "1", "--cpu-sample", "0", "--live-traffic", "0"], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert one.returncode == 0, one.stderr[-2000:]
     d1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][0])
     assert d["keypoints_per_step"]["harris"] > d1["keypoints_per_step"]["harris"]
@@ -56,7 +56,7 @@ def test_bench_one_rank_goes_through_rccl():
     env.pop("VSLAM_BENCH_SHARE_GPU", None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--frames", "8", "--rows", "240", "--cols", "320",
-           "--steps", "2", "--warmup", "1", "--cpu-sample", "0"]
+           "--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--live-traffic", "0"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -67,6 +67,24 @@ def test_bench_one_rank_goes_through_rccl():
     assert d["cxx_host"]["device"]["frames_per_sec"] > 0 and "RCCL" in d["cxx_host"]["device"]["host"]
     assert d["cxx_host"]["device"]["keypoints_per_batch"] == {"harris": d["keypoints_per_step"]["harris"], "dog": d["keypoints_per_step"]["dog"]}
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--frames", "8", "--rows", "240", "--cols", "320", "--steps", "2",
-                          "--warmup", "1", "--cpu-sample", "0", "--modes", "0"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+                          "--warmup", "1", "--cpu-sample", "0", "--modes", "0", "--live-traffic", "0"], capture_output=True, text=True, timeout=600, cwd=ROOT)
     d1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][0])
     assert d["keypoints_per_step"] == d1["keypoints_per_step"]  # the gathered counts are the rank's own
+
+
+@pytest.mark.gpu
+def test_bench_measures_its_hbm_traffic_live():
+    # roofline.traffic was a committed constant.  The default run now measures it: two rocprofv3 --pmc child
+    # passes (FETCH_SIZE, WRITE_SIZE) of a small batch; the line says so, and the figure is at least the algorithmic bytes
+    import shutil
+
+    if not (shutil.which("rocprofv3") or os.path.exists("/opt/rocm/bin/rocprofv3")):
+        pytest.skip("no rocprofv3 on this box")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--frames", "16", "--rows", "540", "--cols", "960", "--steps", "2", "--warmup", "1",
+                        "--cpu-sample", "0", "--cxx-host", "0"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    roof = d["roofline"]
+    assert roof["traffic_profiled"]["live"] is True and "measured in this run" in roof["traffic_source"], roof
+    assert roof["traffic"] >= 0.95 * roof["algorithmic_bytes_per_launch"]
+    assert roof["traffic"] < 3 * roof["algorithmic_bytes_per_launch"]
