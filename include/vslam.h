@@ -393,6 +393,31 @@ int vslam_batch_out_required(const vslam_params* p, int n_frames, vslam_batch_ou
 int vslam_detect_batch_dev(vslam_ctx* ctx, const vslam_params* p, const uint8_t* d_frames, size_t frame_stride,
                            int n_frames, const vslam_batch_out* out);
 
+/* The same detection for callers with HOST memory and no device code of their own (plain C, ctypes + numpy, ...):
+ * n_frames dense frames in host memory in, the two keypoint lists out, packed frame after frame; synchronous.
+ * Harris list (when p->do_harris) and DoG list (when p->n_octaves > 0; p->localize chooses candidates with value >=
+ * min_contrast or FeaturePointLocalization's survivors, as in vslam_detect_batch_dev).  For each list: `x` receives
+ * the records of all frames back to back (x_bytes = capacity of the caller's buffer; records beyond it are not
+ * written), x_offsets[f] (n_frames + 1 entries) the record index where frame f starts, x_counts[f] the frame's true
+ * total (may exceed the per-frame capacity p->harris_cap / p->dog_cap, only that many are listed).  A list whose
+ * three pointers are all NULL is skipped.  The images (response, pyramid ...) stay on the device and are dropped:
+ * use the per-image entry points or vslam_detect_batch_dev for them.  This is a convenience path - it allocates its
+ * device buffers per call and copies over PCIe synchronously; the throughput path is vslam_detect_batch_dev
+ * (visualslam_amd/cxx/batch_detector.hpp pipelines it from host memory). */
+typedef struct {
+    size_t struct_size; /* = sizeof(vslam_host_lists) */
+    vslam_kp* harris;
+    size_t harris_bytes;
+    uint64_t* harris_offsets;
+    uint32_t* harris_counts;
+    vslam_point* dog;
+    size_t dog_bytes;
+    uint64_t* dog_offsets;
+    uint32_t* dog_counts;
+} vslam_host_lists;
+int vslam_detect_batch_host(vslam_ctx* ctx, const vslam_params* p, const uint8_t* frames, size_t frame_stride, int n_frames,
+                            const vslam_host_lists* out);
+
 /* Packs the first min(counts[f], cap) records of every frame's list ([n_frames][cap] records of
  * record_bytes each: harris_kps, dog_points or oriented_points of vslam_detect_batch_dev) back to back
  * into `packed`, frame after frame, and writes offsets[f] = sum over g < f of min(counts[g], cap) for

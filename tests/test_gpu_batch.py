@@ -434,6 +434,46 @@ def test_pack_lists(env, n, cap):
             assert int(offsets[-1]) == total
 
 
+@pytest.mark.parametrize("localize", [0, 1])
+def test_detect_batch_host_lists(env, localize):
+    # vslam_detect_batch_host: numpy frames in, packed lists out (no torch in the call), against the oracle frame by
+    # frame; then a Harris-only and a DoG-only call, a destination that is too small, and the argument errors
+    ctx, torch = env
+    n, rows, cols, n_oct = 5, 150, 217, 3
+    frames = synth.frames_np(n, rows, cols, stream_id=4)
+    frames[2] = 90  # a frame with nothing in it: empty lists in the middle of the batch
+    p = capi.default_params(rows, cols, n_octaves=n_oct, localize=localize)
+    res = ctx.detect_batch_host(p, frames)
+    hk, hoff, hcnt = res["harris"]
+    dp, doff, dcnt = res["dog"]
+    assert hcnt[2] == 0 and dcnt[2] == 0 and hoff[0] == 0 and doff[0] == 0
+    for f in range(n):
+        n2, _ = oracle.nms2(oracle.harris_response(frames[f]), 5)
+        kps = oracle.harris_keypoints(n2)
+        assert hcnt[f] == len(kps) and hoff[f + 1] - hoff[f] == min(len(kps), p.harris_cap)
+        assert hk[int(hoff[f]): int(hoff[f + 1])].tobytes() == kps[: p.harris_cap].tobytes()
+        want = oracle.Pyramid(frames[f], n_oct, p.sigma0)
+        pts = np.concatenate([want.keypoints(o, p.extrema_window) if localize else want.extrema(o, p.extrema_window, p.min_contrast)[1] for o in range(n_oct)])
+        want.close()
+        assert dcnt[f] == len(pts) and doff[f + 1] - doff[f] == min(len(pts), p.dog_cap)
+        assert dp[int(doff[f]): int(doff[f + 1])].tobytes() == pts[: p.dog_cap].tobytes()
+    assert len(hk) == hoff[n] and len(dp) == doff[n] and hoff[n] > 0 and doff[n] > 0
+    only_h = ctx.detect_batch_host(p, frames, dog_budget=0)
+    assert set(only_h) == {"harris"} and only_h["harris"][0].tobytes() == hk.tobytes()
+    only_d = ctx.detect_batch_host(p, frames, harris_budget=0)
+    assert set(only_d) == {"dog"} and only_d["dog"][0].tobytes() == dp.tobytes() and (only_d["dog"][1] == doff).all()
+    # too small a destination: filled to its end with the first records, offsets and counts still the whole truth
+    small = ctx.detect_batch_host(p, frames, harris_budget=int(hoff[n]) - 3, dog_budget=7)
+    assert small["harris"][0].tobytes() == hk[:-3].tobytes() and (small["harris"][1] == hoff).all() and (small["harris"][2] == hcnt).all()
+    assert small["dog"][0].tobytes() == dp[:7].tobytes() and (small["dog"][1] == doff).all()
+    with pytest.raises(capi.VslamError):
+        ctx.detect_batch_host(capi.default_params(rows, cols, n_octaves=n_oct, orient=1), frames)
+    with pytest.raises(capi.VslamError):
+        ctx.detect_batch_host(p, frames, harris_budget=0, dog_budget=0)
+    with pytest.raises(ValueError):
+        ctx.detect_batch_host(p, frames[:, :-1])
+
+
 def test_fast_paths_are_the_ones_that_run(env):
     # the specialised kernels must actually be dispatched for the reference configuration
     # (a silent fall-back to the generic kernels would still pass parity)

@@ -63,6 +63,13 @@ class BatchOut(C.Structure):
     _fields_ = [("struct_size", C.c_size_t)] + [f for n in BATCH_OUT_FIELDS for f in ((n, C.c_void_p), (n + "_bytes", C.c_size_t))]
 
 
+class HostLists(C.Structure):
+    """vslam_host_lists: the packed host-side lists of vslam_detect_batch_host."""
+    _fields_ = [("struct_size", C.c_size_t),
+                ("harris", C.c_void_p), ("harris_bytes", C.c_size_t), ("harris_offsets", C.c_void_p), ("harris_counts", C.c_void_p),
+                ("dog", C.c_void_p), ("dog_bytes", C.c_size_t), ("dog_offsets", C.c_void_p), ("dog_counts", C.c_void_p)]
+
+
 class PyramidInfo(C.Structure):
     _fields_ = [
         ("n_octaves", C.c_int), ("n_levels", C.c_int), ("n_dogs", C.c_int), ("sigma0", C.c_double),
@@ -119,6 +126,7 @@ SIGNATURES = {
     "vslam_batch_layout_query": (_I, [C.POINTER(Params), C.POINTER(BatchLayout)]),
     "vslam_batch_out_required": (_I, [C.POINTER(Params), _I, C.POINTER(BatchOut)]),
     "vslam_detect_batch_dev": (_I, [_P, C.POINTER(Params), _P, _Z, _I, C.POINTER(BatchOut)]),
+    "vslam_detect_batch_host": (_I, [_P, C.POINTER(Params), _P, _Z, _I, C.POINTER(HostLists)]),
     "vslam_pack_lists_dev": (_I, [_P, _P, _Z, C.c_uint32, _P, _I, _P, _Z, _P]),
     "vslam_count_totals_dev": (_I, [_P, _P, _P, _I, _P]),
     "vslam_kernel_timing_enable": (_I, [_P, C.c_char_p]),
@@ -464,6 +472,34 @@ class Context:
                 setattr(bo, k, t.data_ptr())
                 setattr(bo, k + "_bytes", t.numel() * t.element_size())
         return n, bo, (frames.stride(0) if n > 1 else N)  # a size-1 dimension may carry any stride
+
+    def detect_batch_host(self, params: Params, frames, harris_budget: int | None = None, dog_budget: int | None = None):
+        """vslam_detect_batch_host: numpy uint8 frames [n, rows, cols] in, the packed lists out - no torch involved.
+        Returns {"harris": (records, offsets, counts), "dog": (records, offsets, counts)}; a budget of 0 skips the list,
+        None = room for every frame's full capacity."""
+        fr = np.ascontiguousarray(frames, dtype=np.uint8)
+        if fr.ndim != 3 or fr.shape[1:] != (params.rows, params.cols):
+            raise ValueError("detect_batch_host: frames must be [n, rows, cols] uint8")
+        n = fr.shape[0]
+        hl = HostLists()
+        hl.struct_size = C.sizeof(HostLists)
+        res = {}
+        keep = []
+        for name, dtype, cap, budget in (("harris", KP_DTYPE, params.harris_cap, harris_budget), ("dog", POINT_DTYPE, params.dog_cap, dog_budget)):
+            if budget == 0 or (name == "dog" and params.n_octaves == 0) or (name == "harris" and not params.do_harris):
+                continue
+            rec = np.zeros(n * cap if budget is None else budget, dtype)
+            off = np.zeros(n + 1, np.uint64)
+            cnt = np.zeros(n, np.uint32)
+            setattr(hl, name, rec.ctypes.data)
+            setattr(hl, name + "_bytes", rec.nbytes)
+            setattr(hl, name + "_offsets", off.ctypes.data)
+            setattr(hl, name + "_counts", cnt.ctypes.data)
+            keep.append((name, rec, off, cnt))
+        self._chk(lib().vslam_detect_batch_host(self._h, C.byref(params), fr.ctypes.data, params.rows * params.cols, n, C.byref(hl)), "vslam_detect_batch_host")
+        for name, rec, off, cnt in keep:
+            res[name] = (rec[: min(int(off[n]), len(rec))], off, cnt)
+        return res
 
     def pack_lists(self, lists, counts, packed, offsets):
         """vslam_pack_lists_dev: lists [n, cap, k] (int32 / float32 records), counts [n] int32 -> packed (flat,

@@ -1851,6 +1851,88 @@ int vslam_detect_batch_dev(vslam_ctx* c, const vslam_params* pp, const uint8_t* 
     return VSLAM_OK;
 }
 
+int vslam_detect_batch_host(vslam_ctx* c, const vslam_params* pp, const uint8_t* frames, size_t frame_stride, int n_frames,
+                            const vslam_host_lists* out) {
+    TRY(bind_device(c));
+    ARGCHK(c, pp && frames && out && n_frames > 0 && n_frames <= 65535, "detect_batch_host: bad arguments");
+    ARGCHK(c, out->struct_size == sizeof(vslam_host_lists), "detect_batch_host: out->struct_size is not sizeof(vslam_host_lists)");
+    vslam_params p = *pp;
+    ARGCHK(c, p.rows > 0 && p.cols > 0 && frame_stride >= (size_t)p.rows * p.cols, "detect_batch_host: bad frame geometry");
+    ARGCHK(c, !p.orient && !p.extrema_dense, "detect_batch_host: the Harris and DoG lists only (orient / extrema_dense: vslam_detect_batch_dev)");
+    const bool want_h = out->harris || out->harris_offsets || out->harris_counts, want_d = out->dog || out->dog_offsets || out->dog_counts;
+    ARGCHK(c, !want_h || (out->harris_offsets && out->harris_counts && (out->harris || out->harris_bytes == 0)), "detect_batch_host: incomplete Harris list");
+    ARGCHK(c, !want_d || (out->dog_offsets && out->dog_counts && (out->dog || out->dog_bytes == 0)), "detect_batch_host: incomplete DoG list");
+    ARGCHK(c, want_h || want_d, "detect_batch_host: no list requested");
+    p.do_harris = want_h ? 1 : 0;
+    if (!want_d) p.n_octaves = 0;
+    ARGCHK(c, !want_d || p.n_octaves > 0, "detect_batch_host: the DoG list needs n_octaves > 0");
+    vslam_batch_out need{};
+    if (vslam_batch_out_required(&p, n_frames, &need) != VSLAM_OK) return fail(c, VSLAM_ERR_INVALID, "detect_batch_host: bad parameters");
+    const size_t n = (size_t)n_frames, N = (size_t)p.rows * p.cols;
+    // one device block for everything this call needs (recycled through the context's block cache when small)
+    const size_t hpk = want_h ? out->harris_bytes / sizeof(vslam_kp) * sizeof(vslam_kp) : 0, dpk = want_d ? out->dog_bytes / sizeof(vslam_point) * sizeof(vslam_point) : 0;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) {
+        const size_t o = off;
+        off += align_up(bytes ? bytes : 1, 256);
+        return o;
+    };
+    const size_t o_frames = carve(n * N), o_pyr = carve(want_d ? need.pyramid_bytes : 0), o_hk = carve(want_h ? need.harris_kps_bytes : 0),
+                 o_hc = carve(n * 4), o_dp = carve(want_d ? need.dog_points_bytes : 0), o_dc = carve(n * 4), o_hp = carve(hpk), o_dpk = carve(dpk),
+                 o_off = carve(2 * (n + 1) * 8);
+    size_t cap = 0;
+    char* blk = (char*)block_alloc(c, off, &cap);
+    if (!blk) return fail(c, VSLAM_ERR_NOMEM, "detect_batch_host: device allocation failed");
+    struct Release {
+        vslam_ctx* c;
+        void* p;
+        size_t cap;
+        ~Release() {
+            (void)hipStreamSynchronize(c->stream);
+            block_release(c, p, cap);
+        }
+    } rel{c, blk, cap};
+    uint8_t* d_frames = (uint8_t*)(blk + o_frames);
+    HIPCHK(c, hipMemsetAsync(blk + o_hc, 0, n * 4, c->stream));
+    HIPCHK(c, hipMemsetAsync(blk + o_dc, 0, n * 4, c->stream));
+    HIPCHK(c, hipMemsetAsync(blk + o_off, 0, 2 * (n + 1) * 8, c->stream));
+    TRY(h2d(c, d_frames, N, frames, frame_stride, N, n));
+    vslam_batch_out bo{};
+    bo.struct_size = sizeof(bo);
+    if (want_h) {
+        bo.harris_kps = (vslam_kp*)(blk + o_hk), bo.harris_kps_bytes = need.harris_kps_bytes;
+        bo.harris_counts = (uint32_t*)(blk + o_hc), bo.harris_counts_bytes = need.harris_counts_bytes;
+    }
+    if (want_d) {
+        bo.pyramid = (uint8_t*)(blk + o_pyr), bo.pyramid_bytes = need.pyramid_bytes;
+        bo.dog_points = (vslam_point*)(blk + o_dp), bo.dog_points_bytes = need.dog_points_bytes;
+        bo.dog_counts = (uint32_t*)(blk + o_dc), bo.dog_counts_bytes = need.dog_counts_bytes;
+    }
+    TRY(vslam_detect_batch_dev(c, &p, d_frames, N, n_frames, &bo));
+    uint64_t* d_off = (uint64_t*)(blk + o_off);
+    if (want_h) TRY(vslam_pack_lists_dev(c, bo.harris_kps, sizeof(vslam_kp), p.harris_cap, bo.harris_counts, n_frames, blk + o_hp, hpk, d_off));
+    if (want_d) TRY(vslam_pack_lists_dev(c, bo.dog_points, sizeof(vslam_point), p.dog_cap, bo.dog_counts, n_frames, blk + o_dpk, dpk, d_off + (n + 1)));
+    if (want_h) {
+        HIPCHK(c, hipMemcpyAsync(out->harris_offsets, d_off, (n + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(out->harris_counts, bo.harris_counts, n * 4, hipMemcpyDeviceToHost, c->stream));
+    }
+    if (want_d) {
+        HIPCHK(c, hipMemcpyAsync(out->dog_offsets, d_off + (n + 1), (n + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(out->dog_counts, bo.dog_counts, n * 4, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // the offsets say how many records exist
+    if (want_h) {
+        const size_t bytes = std::min<size_t>(out->harris_offsets[n] * sizeof(vslam_kp), hpk);
+        if (bytes) HIPCHK(c, hipMemcpyAsync(out->harris, blk + o_hp, bytes, hipMemcpyDeviceToHost, c->stream));
+    }
+    if (want_d) {
+        const size_t bytes = std::min<size_t>(out->dog_offsets[n] * sizeof(vslam_point), dpk);
+        if (bytes) HIPCHK(c, hipMemcpyAsync(out->dog, blk + o_dpk, bytes, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VSLAM_OK;
+}
+
 int vslam_pack_lists_dev(vslam_ctx* c, const void* lists, size_t record_bytes, uint32_t cap, const uint32_t* counts, int n_frames,
                          void* packed, size_t packed_bytes, uint64_t* offsets) {
     TRY(bind_device(c));
