@@ -81,6 +81,14 @@ const char* vslam_status_string(int status);
 int vslam_ctx_create(int device, void* stream, vslam_ctx** out);
 int vslam_ctx_destroy(vslam_ctx* ctx);
 int vslam_ctx_sync(vslam_ctx* ctx);
+/* Two batches in flight: a second context (own stream, own output buffers) whose batch starts when `leader`'s most
+ * recent vslam_detect_batch_dev call is past its octave-0 kernels - the long, issue-bound part - instead of beside
+ * them.  The coarse octaves, scans and list kernels that follow are short and leave issue slots idle; the follower's
+ * octave 0 can fill them (+3..5 % frames/s measured for two contexts taking alternate batches, each following the
+ * other, when their streams get hardware queues of their own; see DESIGN section 5.4 for when they do not).
+ * Enqueues one event wait on ctx's stream; a no-op if the leader has not run a batch yet.
+ * visualslam_amd/cxx/batch_detector.hpp (Options::pipelines) uses it. */
+int vslam_ctx_follow(vslam_ctx* ctx, const vslam_ctx* leader);
 const char* vslam_last_error(const vslam_ctx* ctx);
 
 /* ------------------------------------------ host-side parameter helpers (no GPU) */

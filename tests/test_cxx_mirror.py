@@ -216,8 +216,9 @@ def _read_dump(path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["device", "hostfed"])
-def test_stream_one_rank_over_rccl_matches_the_oracle(built, tmp_path, mode):
+@pytest.mark.parametrize("mode,pipelines", [("device", 1), ("hostfed", 1), ("device", 2), ("hostfed", 2)])
+def test_stream_one_rank_over_rccl_matches_the_oracle(built, tmp_path, mode, pipelines):
+    # (pipelines = 2: consecutive batches alternate between two contexts / streams, the collectives on a stream of their own)
     # the C++ host end to end: one process = one rank, RCCL communicator of one rank (ncclCommInitRank +
     # ncclAllGather from librccl, no torch), BatchDetector driving vslam_detect_batch_dev; the per-frame lists
     # of the last batch against the oracle on four frames of the camera stream (stream id = rank = 0)
@@ -229,10 +230,11 @@ def test_stream_one_rank_over_rccl_matches_the_oracle(built, tmp_path, mode):
     rows, cols, n = 270, 480, 6
     dump = tmp_path / "lists.bin"
     r = subprocess.run([os.path.join(built, "Stream"), "--mode", mode, "--frames", str(n), "--batches", "4", "--warmup", "1", "--rows", str(rows),
-                        "--cols", str(cols), "--dump", str(dump)], capture_output=True, text=True, timeout=600, env=_rank_env(0, 1, 29890))
+                        "--cols", str(cols), "--dump", str(dump), "--pipelines", str(pipelines)], capture_output=True, text=True, timeout=600,
+                       env=_rank_env(0, 1, 29890))
     assert r.returncode == 0, r.stdout + r.stderr
     line = json.loads(r.stdout.strip().splitlines()[-1])
-    assert line["exe"] == "Stream" and line["mode"] == mode and line["n_gpus"] == 1 and line["frames_per_sec"] > 0
+    assert line["exe"] == "Stream" and line["mode"] == mode and line["n_gpus"] == 1 and line["frames_per_sec"] > 0 and line["pipelines"] == pipelines
     gr, gc, frames = _read_dump(dump)
     assert (gr, gc, len(frames)) == (rows, cols, n)
     tot_h = tot_d = 0

@@ -126,6 +126,7 @@ SIGNATURES = {
     "vslam_batch_layout_query": (_I, [C.POINTER(Params), C.POINTER(BatchLayout)]),
     "vslam_batch_out_required": (_I, [C.POINTER(Params), _I, C.POINTER(BatchOut)]),
     "vslam_detect_batch_dev": (_I, [_P, C.POINTER(Params), _P, _Z, _I, C.POINTER(BatchOut)]),
+    "vslam_ctx_follow": (_I, [_P, _P]),
     "vslam_detect_batch_host": (_I, [_P, C.POINTER(Params), _P, _Z, _I, C.POINTER(HostLists)]),
     "vslam_pack_lists_dev": (_I, [_P, _P, _Z, C.c_uint32, _P, _I, _P, _Z, _P]),
     "vslam_count_totals_dev": (_I, [_P, _P, _P, _I, _P]),
@@ -472,6 +473,10 @@ class Context:
                 setattr(bo, k, t.data_ptr())
                 setattr(bo, k + "_bytes", t.numel() * t.element_size())
         return n, bo, (frames.stride(0) if n > 1 else N)  # a size-1 dimension may carry any stride
+
+    def follow(self, leader: "Context"):
+        """vslam_ctx_follow: this context's next work starts once `leader`'s latest batch is past its octave-0 kernels."""
+        self._chk(lib().vslam_ctx_follow(self._h, leader._h), "vslam_ctx_follow")
 
     def detect_batch_host(self, params: Params, frames, harris_budget: int | None = None, dog_budget: int | None = None):
         """vslam_detect_batch_host: numpy uint8 frames [n, rows, cols] in, the packed lists out - no torch involved.

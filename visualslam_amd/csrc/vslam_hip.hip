@@ -48,6 +48,8 @@ struct vslam_ctx {
     static constexpr int kAux = 3;
     hipStream_t aux[kAux] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[kAux] = {nullptr, nullptr, nullptr}, ev_oct[VSLAM_MAX_OCTAVES] = {};
+    hipEvent_t ev_phase = nullptr;  // recorded by every vslam_detect_batch_dev call once its octave-0 kernels are enqueued (vslam_ctx_follow)
+    bool phase_marked = false;
     hipEvent_t ev_up2 = nullptr;  // the second half of a batch has been upsampled (enqueue_dog)
     hipEvent_t ev_chunk = nullptr;  // the main-stream kernels of a chunk (the readers of the octave bases) are enqueued up to here
     hipEvent_t ev_list0 = nullptr, ev_edge = nullptr;  // octave 0's part of the DoG list is written / its edge test is done
@@ -155,7 +157,8 @@ static int ensure_aux(vslam_ctx* c) {
         // aux[0], aux[1] (Harris chain, scans and lists) yield to the octave kernels; aux[2] carries only the
         // second-half upsample, which the main stream WAITS for: at low priority it was starved for the whole
         // first-half octave kernel whenever its start slipped behind that kernel's (C++ host, 0.35 ms per step)
-        if (hipStreamCreateWithPriority(&c->aux[i], hipStreamNonBlocking, i == 2 ? 0 : prio_lo) != hipSuccess) {
+        static const bool flat = getenv("VSLAM_FLAT_PRIORITY") != nullptr;
+        if (hipStreamCreateWithPriority(&c->aux[i], hipStreamNonBlocking, (i == 2 || flat) ? 0 : prio_lo) != hipSuccess) {
             (void)hipGetLastError();  // priorities are a speed matter only
             HIPCHK(c, hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking));
         }
@@ -588,6 +591,22 @@ static int enqueue_pyr_octave(vslam_ctx* c, double sigma0, int o, const OctPlan&
 
 // The octave whose kernels the held-back side work of a batch waits for (enqueue_dog): the last
 // LDS-tiled one for batches of 32 frames or more, -1 (no gate) otherwise.
+// vslam_ctx_follow: the point of a batch call behind which a second context's batch may start (its heavy octave-0
+// kernels then run beside this call's remaining, shorter kernels instead of beside its own octave 0).
+static int follow_octave() {
+    static const int o = [] {
+        const char* e = getenv("VSLAM_FOLLOW_OCTAVE");
+        return e ? atoi(e) : 0;
+    }();
+    return o;
+}
+static int mark_phase(vslam_ctx* c) {
+    if (!c->ev_phase) HIPCHK(c, hipEventCreateWithFlags(&c->ev_phase, hipEventDisableTiming));
+    HIPCHK(c, hipEventRecord(c->ev_phase, c->stream));
+    c->phase_marked = true;
+    return VSLAM_OK;
+}
+
 static int dog_side_gate(const vslam_params& p, const vslam_batch_layout& L, int nf) {
     int gate = -1;
     if (nf >= 32)
@@ -709,6 +728,7 @@ static int enqueue_dog(vslam_ctx* c, const vslam_params& p, const vslam_batch_la
                    dim3(256), oct + (size_t)3 * P, pframe, pitch, s.bases + s.base_off[o + 1], s.bases_frame, L.pitch[o + 1], rows,
                    L.rows[o + 1], L.cols[o + 1]);
         if (side) HIPCHK(c, hipEventRecord(c->ev_oct[o], c->stream));
+        if (o == follow_octave() || (o == L.n_octaves - 1 && o < follow_octave())) TRY(mark_phase(c));
         if (after_octave) TRY(after_octave(o));  // octave o's kernels are enqueued and ev_oct[o] marks their end
         if (o < gate) continue;  // scan + compaction of this octave are enqueued behind octave `gate`
         const int o_done = o;    // the octave whose kernels were enqueued last
@@ -878,7 +898,7 @@ int vslam_ctx_destroy(vslam_ctx* c) {
         if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
     }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    for (hipEvent_t e : {c->ev_up2, c->ev_chunk, c->ev_list0, c->ev_edge})
+    for (hipEvent_t e : {c->ev_phase, c->ev_up2, c->ev_chunk, c->ev_list0, c->ev_edge})
         if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ev_oct)
         if (e) (void)hipEventDestroy(e);
@@ -1745,6 +1765,7 @@ int vslam_detect_batch_dev(vslam_ctx* c, const vslam_params* pp, const uint8_t* 
         need += (out->response ? 0 : ws_need((size_t)chunk * N * 4)) + ws_need((size_t)chunk * harris_flag_words(p.rows, p.cols) * 8) +
                 ws_need(4 * compaction_ws_elems(harris_flag_words(p.rows, p.cols), chunk));
     if (orient) need += orient_scratch_bytes(p, chunk);
+    c->phase_marked = false;
     TRY(ws_reserve(c, need));
     DogScratch s;
     if (dog) TRY(dog_scratch_take(c, L, p.sigma0, chunk, s));
@@ -1847,7 +1868,15 @@ int vslam_detect_batch_dev(vslam_ctx* c, const vslam_params* pp, const uint8_t* 
             HIPCHK(c, hipEventRecord(c->ev_join[i], c->aux[i]));
             HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[i], 0));
         }
+    if (!c->phase_marked) TRY(mark_phase(c));  // no DoG path in this call: its end is the mark
     guard.armed = false;
+    return VSLAM_OK;
+}
+
+int vslam_ctx_follow(vslam_ctx* c, const vslam_ctx* leader) {
+    TRY(bind_device(c));
+    ARGCHK(c, leader && leader != c && leader->device == c->device, "ctx_follow: the leader must be another context on the same device");
+    if (leader->ev_phase) HIPCHK(c, hipStreamWaitEvent(c->stream, leader->ev_phase, 0));  // no batch call yet: nothing to wait for
     return VSLAM_OK;
 }
 

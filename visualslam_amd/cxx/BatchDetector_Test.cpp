@@ -42,7 +42,7 @@ int main(int argc, char** argv) {
             std::memcpy(h_frames + (size_t)f * N, imgs.back().data, N);
         }
         vslam::BatchDetector::Options opt;
-        opt.rows = rows, opt.cols = cols, opt.batch = n, opt.slots = 3;
+        opt.rows = rows, opt.cols = cols, opt.batch = n, opt.slots = 3, opt.pipelines = 2;
         vslam::BatchDetector det(opt);
         const vslam_params& p = det.params();
 
@@ -103,6 +103,68 @@ int main(int argc, char** argv) {
             EXPECT(std::memcmp(q.data(), pt0.data() + doff[f], q.size() * sizeof(vslam_point)) == 0);
         }
         EXPECT(tot[0] == sum[0] && tot[1] == sum[1] && sum[0] > 0 && sum[1] > 0);
+
+        // ---- 1b. two pipelines: the kernels of consecutive batches overlap (own context, stream and image buffers each).
+        //          Two different batches A, B alternate through three slots; every result equals what a one-pipeline
+        //          detector gives for the same batch, host-fed and device-resident
+        {
+            EXPECT(det.pipelines() == 2);
+            uint8_t* hB = (uint8_t*)vslam::BatchDetector::alloc_pinned((size_t)n * N);
+            for (int f = 0; f < n; ++f) {
+                cv::Mat b = imgio::synthetic(rows, cols, f, 11);
+                std::memcpy(hB + (size_t)f * N, b.data, N);
+            }
+            vslam::BatchDetector::Options o1 = opt;
+            o1.pipelines = 1;
+            vslam::BatchDetector one(o1);
+            EXPECT(one.pipelines() == 1);
+            one.submit(hB, n);
+            const vslam::BatchResult& rb = one.collect();
+            const std::vector<vslam_kp> kpB(rb.harris, rb.harris + rb.harris_records);
+            const std::vector<vslam_point> ptB(rb.dog, rb.dog + rb.dog_records);
+            EXPECT(kpB.size() != kp0.size() || std::memcmp(kpB.data(), kp0.data(), kpB.size() * sizeof(vslam_kp)) != 0);  // B is another batch
+            const uint8_t* src[2] = {h_frames, hB};
+            int sub = 0, col = 0;
+            const int tot2 = 7;
+            for (; sub < 3; ++sub) det.submit(src[sub & 1], n);
+            while (col < tot2) {
+                const vslam::BatchResult& r = det.collect();
+                const std::vector<vslam_kp>& wk = (col & 1) ? kpB : kp0;
+                const std::vector<vslam_point>& wp = (col & 1) ? ptB : pt0;
+                EXPECT(r.harris_records == wk.size() && r.dog_records == wp.size());
+                EXPECT(r.harris_records == wk.size() && std::memcmp(r.harris, wk.data(), wk.size() * sizeof(vslam_kp)) == 0);
+                EXPECT(r.dog_records == wp.size() && std::memcmp(r.dog, wp.data(), wp.size() * sizeof(vslam_point)) == 0);
+                ++col;
+                if (sub < tot2) det.submit(src[sub & 1], n), ++sub;
+            }
+            // device-resident: A and B back to back without a sync in between, each on its own pipeline
+            uint8_t* dAB = nullptr;
+            EXPECT(hipMalloc((void**)&dAB, 2 * (size_t)n * N) == hipSuccess);
+            EXPECT(hipMemcpy(dAB, h_frames, (size_t)n * N, hipMemcpyHostToDevice) == hipSuccess);
+            EXPECT(hipMemcpy(dAB + (size_t)n * N, hB, (size_t)n * N, hipMemcpyHostToDevice) == hipSuccess);
+            const uint64_t* tp[4];
+            const void* st[4];
+            const vslam_point* lists[4];
+            for (int k = 0; k < 4; ++k) {
+                EXPECT(det.next_stream() != det.stream() || k == 0);
+                det.detect_device(dAB + (size_t)(k & 1) * n * N, N, n);
+                tp[k] = det.device_totals(), st[k] = det.stream(), lists[k] = det.device_outputs().dog_points;
+            }
+            det.sync();
+            EXPECT(st[0] != st[1] && st[0] == st[2] && st[1] == st[3] && tp[0] != tp[1] && lists[0] != lists[1] && lists[0] == lists[2]);
+            uint64_t ta[2], tb[2];
+            EXPECT(hipMemcpy(ta, tp[2], 16, hipMemcpyDeviceToHost) == hipSuccess && hipMemcpy(tb, tp[3], 16, hipMemcpyDeviceToHost) == hipSuccess);
+            uint64_t wa[2] = {0, 0}, wb[2] = {0, 0};
+            for (int f = 0; f < n; ++f) wa[0] += hoff[f + 1] - hoff[f], wa[1] += doff[f + 1] - doff[f], wb[0] += rb.harris_counts[f], wb[1] += rb.dog_counts[f];
+            EXPECT(ta[0] == wa[0] && ta[1] == wa[1] && tb[0] == wb[0] && tb[1] == wb[1]);
+            std::vector<vslam_point> q(rb.dog_counts[n - 1]);  // the last frame's list of batch B in HBM
+            if (!q.empty()) {
+                EXPECT(hipMemcpy(q.data(), lists[3] + (size_t)(n - 1) * p.dog_cap, q.size() * sizeof(vslam_point), hipMemcpyDeviceToHost) == hipSuccess);
+                EXPECT(std::memcmp(q.data(), rb.dog + rb.dog_offsets[n - 1], q.size() * sizeof(vslam_point)) == 0);
+            }
+            (void)hipFree(dAB);
+            vslam::BatchDetector::free_pinned(hB);
+        }
 
         // ---- 2. the per-image drop-in functions give the same lists (frames 0 and n-1)
         for (int f : {0, n - 1}) {

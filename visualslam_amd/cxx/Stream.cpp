@@ -4,12 +4,13 @@
 // with batches of frames instead of one imread(), with the display replaced by one JSON line.
 //
 //   Stream [--mode device|hostfed] [--frames 256] [--batches 8] [--warmup 2] [--rows 1080 --cols 1920]
-//          [--octaves 4] [--source synth|<file of raw 8-bit frames>] [--dump <file>] [--rdv-selftest]
+//          [--octaves 4] [--source synth|<file of raw 8-bit frames>] [--dump <file>] [--rdv-selftest] [--pipelines 1]
 //          [--lists candidates|localize|orient|describe]   (how much of the DoG executable runs per frame:
 //           the contrast-8 candidate list, + FeaturePointLocalization, + filterKeypoints, + SIFT descriptors)
 //
 //   device   frames are uploaded once and stay in HBM; every step = BatchDetector::detect_device +
-//            the RCCL all-gather of the {harris, dog} counts on the same stream (what bench.py times);
+//            the RCCL all-gather of the {harris, dog} counts behind it (bench.py's step; --pipelines 2 lets the
+//            kernels of two consecutive batches overlap - see BatchDetector::Options::pipelines for when that pays);
 //   hostfed  every batch starts in pinned host memory and its keypoint lists end there, uploads /
 //            kernels / downloads of consecutive batches overlapped (BatchDetector::submit / collect);
 //            the all-gather of a batch's counts follows its kernels on the same stream.
@@ -42,7 +43,7 @@ namespace {
 
 struct Args {
     std::string mode = "device", source = "synth", dump, lists = "candidates";
-    int frames = 256, batches = 8, warmup = 2, rows = 1080, cols = 1920, octaves = 4;
+    int frames = 256, batches = 8, warmup = 2, rows = 1080, cols = 1920, octaves = 4, pipelines = 1;
     bool rdv_selftest = false, no_allgather = false, no_rccl = false;
 };
 
@@ -57,6 +58,7 @@ Args parse(int argc, char** argv) {
         if (k == "--mode") a.mode = val();
         else if (k == "--frames") a.frames = std::stoi(val());
         else if (k == "--batches") a.batches = std::stoi(val());
+        else if (k == "--pipelines") a.pipelines = std::stoi(val());  // batches whose kernels may overlap (BatchDetector::Options::pipelines)
         else if (k == "--warmup") a.warmup = std::stoi(val());
         else if (k == "--rows") a.rows = std::stoi(val());
         else if (k == "--cols") a.cols = std::stoi(val());
@@ -157,6 +159,7 @@ int main(int argc, char** argv) {
         opt.device = device;
         opt.rows = a.rows, opt.cols = a.cols, opt.batch = a.frames;
         opt.host_fed = hostfed;
+        opt.pipelines = a.pipelines;
         opt.localize = a.lists != "candidates", opt.orient = a.lists == "orient" || a.lists == "describe", opt.describe = a.lists == "describe";
         if (a.octaves != 4) {
             opt.custom_params = true;
@@ -193,7 +196,27 @@ int main(int argc, char** argv) {
         } else {
             ex.cx = std::make_unique<vslam::CountExchange>(env, device, vslam::CountExchange::backend_from_environment());
         }
-        const hipStream_t cs = (hipStream_t)det.stream();
+        // Consecutive batches run on alternating streams (pipelines), but every collective of the communicator goes to ONE
+        // stream, in batch order: the exchange stream waits for a batch's totals, and the batch that reuses the pair of
+        // totals waits for the collective that read it (hold_totals_until).
+        hipStream_t cs = (hipStream_t)det.stream();
+        if (det.pipelines() > 1 && hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) throw std::runtime_error("hipStreamCreate");
+        struct Ev {
+            hipEvent_t totals = nullptr, sent = nullptr;
+        };
+        std::vector<Ev> ring(16);
+        for (Ev& e : ring)
+            if (hipEventCreateWithFlags(&e.totals, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&e.sent, hipEventDisableTiming) != hipSuccess)
+                throw std::runtime_error("hipEventCreate");
+        size_t gathers = 0;
+        auto gather_counts = [&] {
+            Ev& e = ring[gathers++ % ring.size()];
+            (void)hipEventRecord(e.totals, (hipStream_t)det.stream());
+            (void)hipStreamWaitEvent(cs, e.totals, 0);
+            ex.all_gather_async(det.device_totals(), cs);  // 16 bytes per rank behind the kernels: no host round trip
+            (void)hipEventRecord(e.sent, cs);
+            det.hold_totals_until(e.sent);
+        };
 
         // the camera stream: stream_id = rank.  One batch of frames in pinned host memory.
         uint8_t* h_frames = (uint8_t*)vslam::BatchDetector::alloc_pinned((size_t)a.frames * N);
@@ -213,9 +236,10 @@ int main(int argc, char** argv) {
             if (hipMemcpy(d_frames, h_frames, (size_t)a.frames * N, hipMemcpyHostToDevice) != hipSuccess) throw std::runtime_error("upload");
             auto step = [&] {
                 det.detect_device(d_frames, N, a.frames);
-                if (!a.no_allgather) ex.all_gather_async(det.device_totals(), cs);  // 16 bytes per rank, same stream: no host round trip
+                if (!a.no_allgather) gather_counts();
             };
             for (int i = 0; i < a.warmup; ++i) step();
+            det.sync();
             ex.barrier(cs);
             const double t0 = now_s();
             for (int i = 0; i < a.batches; ++i) step();
@@ -256,7 +280,7 @@ int main(int argc, char** argv) {
             bool truncated = false;
             auto submit = [&] {
                 det.submit(h_frames, a.frames);
-                ex.all_gather_async(det.device_totals(), cs);
+                gather_counts();
             };
             std::vector<double> t_collect;
             auto run = [&](int nb) {
@@ -272,6 +296,7 @@ int main(int argc, char** argv) {
                 }
             };
             if (a.warmup) run(a.warmup);
+            det.sync();
             ex.barrier(cs);
             const double t0 = now_s();
             run(a.batches);
@@ -280,13 +305,13 @@ int main(int argc, char** argv) {
             dt = now_s() - t0;
             all = ex.fetch(cs);
             if (truncated) std::fprintf(stderr, "Stream: rank %d: lists truncated (raise the caps or the host budget)\n", env.rank);
-            // steady state of the pipeline: the median interval between consecutive collect() returns (the whole-run
-            // figure also carries the first upload and the last download, which nothing overlaps)
-            if (t_collect.size() >= 4) {
-                std::vector<double> d;
-                for (size_t i = 1; i < t_collect.size(); ++i) d.push_back(t_collect[i] - t_collect[i - 1]);
-                std::sort(d.begin(), d.end());
-                steady_ms = d[d.size() / 2] * 1e3;
+            // steady state of the pipeline: the mean interval between collect() returns over the middle of the run (the
+            // whole-run figure also carries the first upload and the last download, which nothing overlaps; with two
+            // pipelines the intervals alternate, so a median would pick one of the two)
+            const size_t skip = (size_t)depth + 1;
+            if (t_collect.size() >= 2 * skip + 4) {
+                const size_t i0 = skip, i1 = t_collect.size() - 1 - skip;
+                steady_ms = (t_collect[i1] - t_collect[i0]) / (double)(i1 - i0) * 1e3;
             }
         }
         unsigned long long oriented_rank = 0;  // this rank's oriented points of the last batch (reported, not all-gathered)
@@ -313,11 +338,11 @@ int main(int argc, char** argv) {
             std::printf("{\"exe\": \"Stream\", \"host\": \"C++ (BatchDetector) + %s\", \"mode\": \"%s\", \"n_gpus\": %d, \"frames_per_batch\": %d, "
                         "\"batches\": %d, \"warmup\": %d, \"rows\": %d, \"cols\": %d, \"octaves\": %d, \"frames_per_sec\": %.2f, \"ms_per_batch\": %.4f, "
                         "\"keypoints_per_batch\": {\"harris\": %llu, \"dog\": %llu}, \"keypoints_per_sec\": %.1f, \"rank0_counts\": [%llu, %llu], "
-                        "\"steady_ms_per_batch\": %.4f, \"steady_frames_per_sec\": %.2f, \"counts_by_rank\": %s, \"lists\": \"%s\", \"oriented_points_rank0_last_batch\": %llu}\n",
+                        "\"steady_ms_per_batch\": %.4f, \"steady_frames_per_sec\": %.2f, \"counts_by_rank\": %s, \"lists\": \"%s\", \"oriented_points_rank0_last_batch\": %llu, \"pipelines\": %d}\n",
                         a.no_rccl ? "no communicator (--no-rccl)" : tcp ? "TCP rehearsal exchange (VSLAM_COUNT_BACKEND=tcp)" : "RCCL ncclAllGather", a.mode.c_str(),
                         env.world, a.frames, a.batches, a.warmup, a.rows, a.cols, det.params().n_octaves, fps, dt_max / a.batches * 1e3,
                         (unsigned long long)gh, (unsigned long long)gd, (double)(gh + gd) * a.batches / dt_max, (unsigned long long)all[0],
-                        (unsigned long long)all[1], steady_ms, steady_ms > 0 ? a.frames * 1e3 / steady_ms * env.world : 0.0, by_rank.c_str(), a.lists.c_str(), oriented_rank);
+                        (unsigned long long)all[1], steady_ms, steady_ms > 0 ? a.frames * 1e3 / steady_ms * env.world : 0.0, by_rank.c_str(), a.lists.c_str(), oriented_rank, det.pipelines());
         }
         vslam::BatchDetector::free_pinned(h_frames);
         return 0;

@@ -61,7 +61,8 @@ BatchDetector::BatchDetector(const Options& opt) : opt_(opt) {
 }
 
 void BatchDetector::init(const Options& opt) {
-    if (opt.batch <= 0 || opt.rows <= 0 || opt.cols <= 0 || opt.slots < 1) throw Error(VSLAM_ERR_INVALID, "BatchDetector: bad options");
+    if (opt.batch <= 0 || opt.rows <= 0 || opt.cols <= 0 || opt.slots < 1 || opt.pipelines < 1 || opt.pipelines > 4)
+        throw Error(VSLAM_ERR_INVALID, "BatchDetector: bad options");
     if (opt.custom_params)
         p_ = opt.params;
     else
@@ -78,23 +79,28 @@ void BatchDetector::init(const Options& opt) {
     // Streams map onto a small number of hardware queues (4 by default): every extra stream can end up
     // sharing a queue - and therefore serialising - with the library's side streams, so the copy streams
     // exist only in host-fed use (device-resident Stream runs lost 4 % to two idle streams).
-    hipStream_t cs, us = nullptr, ds = nullptr, ps = nullptr;
-    HIPX(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+    hipStream_t us = nullptr, ds = nullptr, ps = nullptr;
+    pipes_.resize((size_t)opt.pipelines);
+    for (Pipe& pp : pipes_) {
+        hipStream_t cs;
+        HIPX(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+        pp.stream = cs;
+        rc = vslam_ctx_create(opt.device, cs, &pp.ctx);
+        if (rc != VSLAM_OK) throw Error(rc, std::string("vslam_ctx_create: ") + vslam_status_string(rc) + " (no usable HIP device: there is no CPU fallback)");
+    }
     if (opt.host_fed) {
         HIPX(hipStreamCreateWithFlags(&us, hipStreamNonBlocking));
         HIPX(hipStreamCreateWithFlags(&ds, hipStreamNonBlocking));
         HIPX(hipStreamCreateWithFlags(&ps, hipStreamNonBlocking));
     }
-    compute_ = cs, up_ = us, down_ = ds, pack_ = ps;
-    rc = vslam_ctx_create(opt.device, compute_, &ctx_);
-    if (rc != VSLAM_OK) throw Error(rc, std::string("vslam_ctx_create: ") + vslam_status_string(rc) + " (no usable HIP device: there is no CPU fallback)");
+    up_ = us, down_ = ds, pack_ = ps;
     if (opt.host_fed) {
         rc = vslam_ctx_create(opt.device, pack_, &ctx_pack_);
         if (rc != VSLAM_OK) throw Error(rc, "vslam_ctx_create (pack stream)");
     }
 
     vslam_batch_out need{};
-    check(vslam_batch_out_required(&p_, opt.batch, &need), ctx_, "vslam_batch_out_required");
+    check(vslam_batch_out_required(&p_, opt.batch, &need), pipes_[0].ctx, "vslam_batch_out_required");
     auto dmalloc = [&](size_t bytes) {
         void* p = nullptr;
         HIPX(hipMalloc(&p, bytes ? bytes : 256));
@@ -106,22 +112,25 @@ void BatchDetector::init(const Options& opt) {
         pinned_allocs_.push_back(p);
         return p;
     };
-    // image outputs: one set, shared by all slots (the kernels of consecutive batches are ordered on one stream)
-    vslam_batch_out img{};
-    img.struct_size = sizeof(vslam_batch_out);
+    // image outputs: one set per pipeline (the kernels of the batches of one pipeline are ordered on its stream)
     const bool dog = p_.n_octaves > 0;
-    if (p_.do_harris) {
-        img.response = (float*)dmalloc(need.response_bytes), img.response_bytes = need.response_bytes;
-        img.nms_mask = (uint8_t*)dmalloc(need.nms_mask_bytes), img.nms_mask_bytes = need.nms_mask_bytes;
+    for (Pipe& pp : pipes_) {
+        vslam_batch_out& img = pp.img;
+        img.struct_size = sizeof(vslam_batch_out);
+        if (p_.do_harris) {
+            img.response = (float*)dmalloc(need.response_bytes), img.response_bytes = need.response_bytes;
+            img.nms_mask = (uint8_t*)dmalloc(need.nms_mask_bytes), img.nms_mask_bytes = need.nms_mask_bytes;
+        }
+        if (dog) {
+            img.pyramid = (uint8_t*)dmalloc(need.pyramid_bytes), img.pyramid_bytes = need.pyramid_bytes;
+            img.extrema_bits = (uint64_t*)dmalloc(need.extrema_bits_bytes), img.extrema_bits_bytes = need.extrema_bits_bytes;
+        }
     }
-    if (dog) {
-        img.pyramid = (uint8_t*)dmalloc(need.pyramid_bytes), img.pyramid_bytes = need.pyramid_bytes;
-        img.extrema_bits = (uint64_t*)dmalloc(need.extrema_bits_bytes), img.extrema_bits_bytes = need.extrema_bits_bytes;
-    }
-    d_totals_all_ = (uint64_t*)dmalloc(2 * sizeof(uint64_t) * (size_t)std::max(1, opt.slots));
-    HIPX(hipMemset(d_totals_all_, 0, 2 * sizeof(uint64_t) * (size_t)std::max(1, opt.slots)));
+    // host-fed: `slots` batches between submit() and collect(); device-resident: one set of lists per pipeline
+    const int nslots = opt.host_fed ? std::max(opt.slots, opt.pipelines) : opt.pipelines;
+    d_totals_all_ = (uint64_t*)dmalloc(2 * sizeof(uint64_t) * (size_t)nslots);
+    HIPX(hipMemset(d_totals_all_, 0, 2 * sizeof(uint64_t) * (size_t)nslots));
     d_totals_ = d_totals_all_;
-    const int nslots = opt.host_fed ? opt.slots : 1;
     const size_t n = (size_t)opt.batch;
     packed_cap_h_ = std::min<size_t>(n * p_.harris_cap, n * opt.host_records_per_frame);
     packed_cap_p_ = std::min<size_t>(n * p_.dog_cap, n * opt.host_records_per_frame);
@@ -130,7 +139,7 @@ void BatchDetector::init(const Options& opt) {
     const bool orient = dog && opt_.orient, describe = orient && opt_.describe;
     slots_.resize(nslots);
     for (Slot& s : slots_) {
-        s.out = img;
+        s.out = pipes_[0].img;
         if (p_.do_harris) {
             s.out.harris_kps = (vslam_kp*)dmalloc(need.harris_kps_bytes), s.out.harris_kps_bytes = need.harris_kps_bytes;
             s.out.harris_counts = (uint32_t*)dmalloc(need.harris_counts_bytes), s.out.harris_counts_bytes = need.harris_counts_bytes;
@@ -188,8 +197,9 @@ void BatchDetector::release() {
     (void)hipSetDevice(opt_.device);
     (void)hipDeviceSynchronize();
     if (ctx_pack_) (void)vslam_ctx_destroy(ctx_pack_);
-    if (ctx_) (void)vslam_ctx_destroy(ctx_);
-    ctx_pack_ = ctx_ = nullptr;
+    ctx_pack_ = nullptr;
+    for (Pipe& pp : pipes_)
+        if (pp.ctx) (void)vslam_ctx_destroy(pp.ctx), pp.ctx = nullptr;
     for (Slot& s : slots_)
         for (void* e : {s.up_done, s.comp_done, s.down_done, s.det_done})
             if (e) (void)hipEventDestroy((hipEvent_t)e);
@@ -198,29 +208,48 @@ void BatchDetector::release() {
     for (void* p : pinned_allocs_) (void)hipHostFree(p);
     dev_allocs_.clear();
     pinned_allocs_.clear();
-    for (void** s : {&up_, &down_, &pack_, &compute_}) {
+    for (void** s : {&up_, &down_, &pack_}) {
         if (*s) (void)hipStreamDestroy((hipStream_t)*s);
         *s = nullptr;
     }
+    for (Pipe& pp : pipes_)
+        if (pp.stream) (void)hipStreamDestroy((hipStream_t)pp.stream), pp.stream = nullptr;
+    pipes_.clear();
 }
 
 void BatchDetector::sync() {
     HIPX(hipSetDevice(opt_.device));
-    HIPX(hipStreamSynchronize((hipStream_t)compute_));
+    for (Pipe& pp : pipes_) HIPX(hipStreamSynchronize((hipStream_t)pp.stream));
 }
 
-void BatchDetector::run_on_slot(Slot& s, const uint8_t* d_frames, size_t stride, int n) {
-    check(vslam_detect_batch_dev(ctx_, &p_, d_frames, stride, n, &s.out), ctx_, "vslam_detect_batch_dev");
+// The slot's lists + the image buffers of the pipeline whose turn it is.  The pair of totals of the slot may still be
+// read by the caller's collective (hold_totals_until): the pipeline's stream waits for that first.
+BatchDetector::Slot& BatchDetector::begin_batch(int slot, int n) {
+    Slot& s = slots_[(size_t)slot];
+    const int prev = last_pipe_;
+    const bool first = batches_ == 0;
+    last_pipe_ = next_pipe();
+    last_slot_ = slot;
+    ++batches_;
+    const Pipe& pp = pipes_[(size_t)last_pipe_];
+    s.out.response = pp.img.response, s.out.nms_mask = pp.img.nms_mask, s.out.pyramid = pp.img.pyramid, s.out.extrema_bits = pp.img.extrema_bits;
+    // two batches in flight run staggered: this one starts when the previous one (other pipeline) is past its octave 0
+    if (!first && prev != last_pipe_) check(vslam_ctx_follow(pp.ctx, pipes_[(size_t)prev].ctx), pp.ctx, "vslam_ctx_follow");
+    if (s.totals_read) HIPX(hipStreamWaitEvent((hipStream_t)pp.stream, (hipEvent_t)s.totals_read, 0));
+    s.totals_read = nullptr;
     s.n = n;
+    d_totals_ = d_totals_all_ + 2 * (size_t)slot;
+    return s;
 }
 
 void BatchDetector::detect_device(const uint8_t* d_frames, size_t frame_stride, int n) {
     if (n <= 0 || n > opt_.batch) throw Error(VSLAM_ERR_INVALID, "BatchDetector::detect_device: n outside 1..batch");
     HIPX(hipSetDevice(opt_.device));
-    Slot& s = slots_[0];
-    run_on_slot(s, d_frames, frame_stride, n);
-    d_totals_ = d_totals_all_;
-    check(vslam_count_totals_dev(ctx_, s.out.harris_counts, s.out.dog_counts, n, d_totals_), ctx_, "vslam_count_totals_dev");
+    // device-resident batches use the lists of slot = pipeline: a batch's outputs stay valid until `pipelines` calls later
+    Slot& s = begin_batch(next_pipe(), n);
+    vslam_ctx* ctx = pipes_[(size_t)last_pipe_].ctx;
+    check(vslam_detect_batch_dev(ctx, &p_, d_frames, frame_stride, n, &s.out), ctx, "vslam_detect_batch_dev");
+    check(vslam_count_totals_dev(ctx, s.out.harris_counts, s.out.dog_counts, n, d_totals_), ctx, "vslam_count_totals_dev");
 }
 
 void BatchDetector::submit(const uint8_t* host_frames, int n) {
@@ -228,8 +257,9 @@ void BatchDetector::submit(const uint8_t* host_frames, int n) {
     if (!host_frames || n <= 0 || n > opt_.batch) throw Error(VSLAM_ERR_INVALID, "BatchDetector::submit: bad arguments");
     if (in_flight() >= (int)slots_.size()) throw Error(VSLAM_ERR_INVALID, "BatchDetector::submit: every slot is in flight - collect() first");
     HIPX(hipSetDevice(opt_.device));
-    Slot& s = slots_[submitted_ % slots_.size()];
-    const hipStream_t up = (hipStream_t)up_, cs = (hipStream_t)compute_;
+    Slot& s = begin_batch((int)(submitted_ % slots_.size()), n);
+    vslam_ctx* ctx = pipes_[(size_t)last_pipe_].ctx;
+    const hipStream_t up = (hipStream_t)up_, cs = (hipStream_t)pipes_[(size_t)last_pipe_].stream;
     const size_t N = (size_t)p_.rows * p_.cols;
     // the slot's frame buffer is free once the kernels of its previous batch have run (comp_done), its list
     // buffers once that batch's lists have been downloaded (down_done; collect() has waited for it already)
@@ -238,11 +268,10 @@ void BatchDetector::submit(const uint8_t* host_frames, int n) {
     HIPX(hipEventRecord((hipEvent_t)s.up_done, up));
     HIPX(hipStreamWaitEvent(cs, (hipEvent_t)s.up_done, 0));
     HIPX(hipStreamWaitEvent(cs, (hipEvent_t)s.down_done, 0));
-    run_on_slot(s, s.d_frames, N, n);
+    check(vslam_detect_batch_dev(ctx, &p_, s.d_frames, N, n, &s.out), ctx, "vslam_detect_batch_dev");
     // this batch's {harris, dog} totals stay on the device (one pair per slot): the count all-gather can be
     // enqueued right behind submit() without the host seeing them
-    d_totals_ = d_totals_all_ + 2 * (submitted_ % slots_.size());
-    check(vslam_count_totals_dev(ctx_, s.out.harris_counts, s.out.dog_counts, n, d_totals_), ctx_, "vslam_count_totals_dev");
+    check(vslam_count_totals_dev(ctx, s.out.harris_counts, s.out.dog_counts, n, d_totals_), ctx, "vslam_count_totals_dev");
     const size_t nb = (size_t)opt_.batch;
     // The packing (bandwidth-bound, 0.45 ms for a 256-frame 1080p batch) and the small downloads go to the pack stream:
     // they read only this slot's lists, so they run beside the first kernels of the NEXT batch instead of in front of them.

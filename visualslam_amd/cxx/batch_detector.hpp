@@ -6,7 +6,8 @@
 // and this class is that loop for batches of frames on one GPU:
 //
 //   device-resident   detect_device(d_frames, stride, n): frames already in HBM, outputs stay in HBM
-//                     (device_outputs()), asynchronous on stream() - what bench.py times;
+//                     (device_outputs()), asynchronous on stream() - what bench.py times.  Consecutive
+//                     batches alternate between `pipelines` streams, so two batches' kernels overlap;
 //   host-fed          submit(host_frames, n) / collect(): frames start in (pinned) host memory and the two
 //                     keypoint lists end there.  Up to `slots` batches are in flight: the upload of batch
 //                     k+1 / k+2 (own stream) and the download of batch k-1's lists (own stream) overlap the
@@ -73,6 +74,14 @@ public:
         bool custom_params = false;      // false: vslam_params_default(rows, cols)
         vslam_params params{};
         int slots = 3;                   // host-fed batches in flight (>= 1); device buffers of frames + lists per slot
+        // Batches whose KERNELS may run at the same time (1..4).  Each pipeline is a context + compute stream + set of
+        // image buffers (response, mask, pyramid, bitmask: 33 GB for 256 x 1080p) of its own; consecutive batches
+        // alternate between them, each starting once its predecessor is past octave 0 (vslam_ctx_follow), so that the
+        // tail of batch k (coarse octaves, scans, lists: short kernels that leave issue slots idle) runs under the
+        // octave-0 kernels of batch k + 1.  Worth +3..5 % frames/s when the streams land on hardware queues of their
+        // own, and -20 % when they do not: the outcome follows GPU_MAX_HW_QUEUES and the order in which streams are first
+        // used (DESIGN section 5.4 has the table), so the default stays at one pipeline.
+        int pipelines = 1;
         size_t host_records_per_frame = (size_t)1 << 17;  // pinned host budget per list, averaged over the batch
         bool host_fed = true;            // false: no frame / list staging buffers at all (device-resident use only)
         // The rest of the reference's DoG executable for every frame of the batch (Diff_of_Gauss.cpp:785-791):
@@ -89,19 +98,25 @@ public:
 
     const vslam_params& params() const { return p_; }
     const vslam_batch_layout& layout() const { return L_; }
-    vslam_ctx* context() const { return ctx_; }
-    void* stream() const { return compute_; }  // hipStream_t of the kernels
+    vslam_ctx* context() const { return pipes_[last_pipe_].ctx; }
+    // hipStream_t of the kernels of the most recent batch (detect_device / submit), and of the batch that comes next
+    void* stream() const { return pipes_[last_pipe_].stream; }
+    void* next_stream() const { return pipes_[next_pipe()].stream; }
+    int pipelines() const { return (int)pipes_.size(); }
 
     // ---- device-resident
     // Harris + DoG over n frames in HBM (frame f at d_frames + f * frame_stride).  Asynchronous on stream().
     void detect_device(const uint8_t* d_frames, size_t frame_stride, int n);
-    // The device buffers detect_device (and the most recent submit) wrote: response, nms_mask, pyramid,
-    // extrema_bits shared by all batches; lists of slot 0 for detect_device.
-    const vslam_batch_out& device_outputs() const { return slots_[0].out; }
+    // The device buffers the most recent detect_device / submit wrote (valid on stream()): the image buffers of its
+    // pipeline - overwritten by the batch `pipelines` calls later - and the lists of its slot.
+    const vslam_batch_out& device_outputs() const { return slots_[last_slot_].out; }
     // {harris, dog} totals of the last detect_device() / submit() as two uint64 in device memory
-    // (vslam_count_totals_dev; one pair per slot): the send buffer of the count all-gather, valid on stream()
+    // (vslam_count_totals_dev; one pair per slot): the send buffer of the count all-gather, valid on stream().
+    // A reader on another stream (the collective's) names the event that marks its read with hold_totals_until():
+    // the batch that overwrites the pair waits for it.
     const uint64_t* device_totals() const { return d_totals_; }
-    void sync();
+    void hold_totals_until(void* hip_event) { slots_[last_slot_].totals_read = hip_event; }
+    void sync();  // every pipeline's stream
 
     // ---- host-fed pipeline
     // Enqueues upload + detection + list packing of one batch.  host_frames: n dense frames; pinned memory
@@ -132,18 +147,27 @@ private:
         vslam_kp* h_hpacked = nullptr;  // pinned
         vslam_point* h_ppacked = nullptr;
         void *up_done = nullptr, *comp_done = nullptr, *down_done = nullptr, *det_done = nullptr;  // hipEvent_t
+        void* totals_read = nullptr;    // caller's event (hold_totals_until), not owned
         int n = 0;
         BatchResult res;
     };
+    struct Pipe {
+        vslam_ctx* ctx = nullptr;
+        void* stream = nullptr;         // hipStream_t
+        vslam_batch_out img{};          // image buffers only
+    };
+    int next_pipe() const { return (int)(batches_ % pipes_.size()); }
+    Slot& begin_batch(int slot, int n);  // binds the slot to the next pipeline
     void init(const Options& opt);
     void release();
-    void run_on_slot(Slot& s, const uint8_t* d_frames, size_t stride, int n);
     vslam_params p_{};
     vslam_batch_layout L_{};
     Options opt_;
-    vslam_ctx* ctx_ = nullptr;
-    vslam_ctx* ctx_pack_ = nullptr;  // a second context on the pack stream: the list packing of batch k runs beside the kernels of batch k+1
-    void *compute_ = nullptr, *up_ = nullptr, *down_ = nullptr, *pack_ = nullptr;  // hipStream_t
+    std::vector<Pipe> pipes_;
+    int last_pipe_ = 0, last_slot_ = 0;
+    uint64_t batches_ = 0;           // detect_device + submit calls so far
+    vslam_ctx* ctx_pack_ = nullptr;  // a context on the pack stream: the list packing of batch k runs beside the kernels of batch k+1
+    void *up_ = nullptr, *down_ = nullptr, *pack_ = nullptr;  // hipStream_t
     std::vector<Slot> slots_;
     std::vector<void*> dev_allocs_, pinned_allocs_;
     uint64_t *d_totals_ = nullptr, *d_totals_all_ = nullptr;
