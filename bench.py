@@ -452,6 +452,7 @@ def main():
             },
             "distributed": {"initialized": bool(use_dist), "world_size": dist.get_world_size() if use_dist else 1,
                             "backend": dist.get_backend() if use_dist else None, "ranks_gathered": int(world)},
+            "side_streams": dict(zip(("replaced_by_placement_probe", "at_main_priority"), ctx.side_stream_report())),
             "keypoints_per_sec": kp_per_step * args.steps / dt,
             "keypoints_per_step": {"harris": main["harris"], "dog": main["dog"], "list_overflow": main["list_overflow"],
                                    **({"oriented": main["oriented"], "oriented_truncated": main["oriented_truncated"]} if args.orient else {})},

@@ -127,6 +127,7 @@ SIGNATURES = {
     "vslam_batch_out_required": (_I, [C.POINTER(Params), _I, C.POINTER(BatchOut)]),
     "vslam_detect_batch_dev": (_I, [_P, C.POINTER(Params), _P, _Z, _I, C.POINTER(BatchOut)]),
     "vslam_ctx_follow": (_I, [_P, _P]),
+    "vslam_ctx_side_stream_report": (_I, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "vslam_detect_batch_host": (_I, [_P, C.POINTER(Params), _P, _Z, _I, C.POINTER(HostLists)]),
     "vslam_pack_lists_dev": (_I, [_P, _P, _Z, C.c_uint32, _P, _I, _P, _Z, _P]),
     "vslam_count_totals_dev": (_I, [_P, _P, _P, _I, _P]),
@@ -473,6 +474,12 @@ class Context:
                 setattr(bo, k, t.data_ptr())
                 setattr(bo, k + "_bytes", t.numel() * t.element_size())
         return n, bo, (frames.stride(0) if n > 1 else N)  # a size-1 dimension may carry any stride
+
+    def side_stream_report(self):
+        """vslam_ctx_side_stream_report: (candidate side streams replaced by the placement probe, side streams left at the main priority)."""
+        a, b = C.c_int(0), C.c_int(0)
+        self._chk(lib().vslam_ctx_side_stream_report(self._h, C.byref(a), C.byref(b)), "vslam_ctx_side_stream_report")
+        return a.value, b.value
 
     def follow(self, leader: "Context"):
         """vslam_ctx_follow: this context's next work starts once `leader`'s latest batch is past its octave-0 kernels."""

@@ -11,6 +11,7 @@
 #include <map>
 #include <string>
 #include <set>
+#include <memory>
 #include <vector>
 
 #include "../../include/vslam.h"
@@ -48,6 +49,7 @@ struct vslam_ctx {
     static constexpr int kAux = 3;
     hipStream_t aux[kAux] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[kAux] = {nullptr, nullptr, nullptr}, ev_oct[VSLAM_MAX_OCTAVES] = {};
+    int side_streams_replaced = 0, side_streams_flat = 0;  // placement probe of the low-priority side streams (ensure_aux)
     hipEvent_t ev_phase = nullptr;  // recorded by every vslam_detect_batch_dev call once its octave-0 kernels are enqueued (vslam_ctx_follow)
     bool phase_marked = false;
     hipEvent_t ev_up2 = nullptr;  // the second half of a batch has been upsampled (enqueue_dog)
@@ -146,6 +148,93 @@ static std::pair<hipEvent_t, hipEvent_t>* timing_slot(vslam_ctx* c) {
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// ---- side-stream placement probe -------------------------------------------------------------------------------
+// HIP binds every stream to one of GPU_MAX_HW_QUEUES hardware queues per priority level, and the placement is not ours to
+// choose.  Measured: a LOW-priority queue that shares a command-processor pipe with the main
+// stream's queue is starved whenever that queue is parked on a barrier waiting for it - which is what the join at the
+// end of every batch call is: its kernels then run 1.6-5x slower even with the chip otherwise idle (11.3 k instead of
+// 14.1 k frames/s).  So a new low-priority side stream is tried out once: a many-workgroup kernel timed with the main
+// stream idle and with the main stream parked on its end event.  A starved stream is replaced by a fresh one (which
+// binds to the next queue of the pool), a few times; if none passes, the side stream runs at the main stream's priority,
+// where the effect does not exist.  VSLAM_QUEUE_PROBE=0 skips the probe.
+namespace vslam {
+__global__ void __launch_bounds__(256) k_queue_probe(uint4* p, unsigned n) {
+    const unsigned i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    uint4 v = p[i];
+    v.x = v.x * 1664525u + v.y;
+    p[i] = v;
+}
+}  // namespace vslam
+
+struct QueueProbe {
+    uint4* buf = nullptr;
+    unsigned n = 16u << 20;  // 256 MB: 65536 workgroups, ~0.1 ms
+    hipEvent_t a = nullptr, b = nullptr, fork = nullptr;
+    bool ok = false;
+    QueueProbe() {
+        ok = hipMalloc((void**)&buf, (size_t)n * sizeof(uint4)) == hipSuccess && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess &&
+             hipEventCreateWithFlags(&fork, hipEventDisableTiming) == hipSuccess;
+        if (!ok) (void)hipGetLastError();
+    }
+    ~QueueProbe() {
+        if (buf) (void)hipFree(buf);
+        for (hipEvent_t e : {a, b, fork})
+            if (e) (void)hipEventDestroy(e);
+    }
+    // best of three; < 0 on any HIP error (the probe then decides nothing)
+    float run(hipStream_t main_s, hipStream_t s, bool park_main) {
+        float best = -1.f;
+        for (int rep = 0; rep < 3; ++rep) {
+            bool good = hipEventRecord(fork, main_s) == hipSuccess && hipStreamWaitEvent(s, fork, 0) == hipSuccess && hipEventRecord(a, s) == hipSuccess;
+            hipLaunchKernelGGL(vslam::k_queue_probe, dim3(n / 256), dim3(256), 0, s, buf, n);
+            good = good && hipGetLastError() == hipSuccess && hipEventRecord(b, s) == hipSuccess;
+            if (good && park_main) {  // what the join of a batch call looks like: main waits for the side stream, more work behind
+                good = hipStreamWaitEvent(main_s, b, 0) == hipSuccess;
+                hipLaunchKernelGGL(vslam::k_queue_probe, dim3(64), dim3(256), 0, main_s, buf, 64u * 256u);
+                good = good && hipGetLastError() == hipSuccess;
+            }
+            good = (hipStreamSynchronize(s) == hipSuccess) && good;
+            good = (hipStreamSynchronize(main_s) == hipSuccess) && good;
+            float ms = 0.f;
+            if (!good || hipEventElapsedTime(&ms, a, b) != hipSuccess) {
+                (void)hipGetLastError();
+                return -1.f;
+            }
+            best = (best < 0.f || ms < best) ? ms : best;
+        }
+        return best;
+    }
+    bool starved(hipStream_t main_s, hipStream_t s) {
+        const float free_ms = run(main_s, s, false), parked_ms = run(main_s, s, true);
+        return free_ms > 0.f && parked_ms > 1.3f * free_ms;
+    }
+};
+
+// A low-priority side stream that the main stream's queue does not starve, or a normal-priority one.
+static int create_side_stream(vslam_ctx* c, int prio_lo, QueueProbe* probe, hipStream_t* out) {
+    std::vector<hipStream_t> rejected;
+    hipStream_t s = nullptr;
+    for (int attempt = 0; attempt < 4 && prio_lo != 0; ++attempt) {
+        if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio_lo) != hipSuccess) {
+            (void)hipGetLastError();  // priorities are a speed matter only
+            s = nullptr;
+            break;
+        }
+        if (!probe || !probe->ok || !probe->starved(c->stream, s)) break;
+        rejected.push_back(s);  // kept alive until the end, so that the next one binds to another queue
+        s = nullptr;
+    }
+    for (hipStream_t r : rejected) (void)hipStreamDestroy(r);
+    c->side_streams_replaced += (int)rejected.size();
+    if (!s) {
+        HIPCHK(c, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        if (!rejected.empty()) c->side_streams_flat += 1;
+    }
+    *out = s;
+    return VSLAM_OK;
+}
+
 static int ensure_aux(vslam_ctx* c) {
     if (c->ev_fork) return VSLAM_OK;
     int prio_lo = 0, prio_hi = 0;
@@ -153,16 +242,27 @@ static int ensure_aux(vslam_ctx* c) {
         (void)hipGetLastError();  // priorities are a speed matter only: do not leave the error for the next launch check
         prio_lo = 0;
     }
-    for (int i = 0; i < vslam_ctx::kAux; ++i) {
-        // aux[0], aux[1] (Harris chain, scans and lists) yield to the octave kernels; aux[2] carries only the
-        // second-half upsample, which the main stream WAITS for: at low priority it was starved for the whole
-        // first-half octave kernel whenever its start slipped behind that kernel's (C++ host, 0.35 ms per step)
-        static const bool flat = getenv("VSLAM_FLAT_PRIORITY") != nullptr;
-        if (hipStreamCreateWithPriority(&c->aux[i], hipStreamNonBlocking, (i == 2 || flat) ? 0 : prio_lo) != hipSuccess) {
-            (void)hipGetLastError();  // priorities are a speed matter only
-            HIPCHK(c, hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking));
+    static const bool flat = getenv("VSLAM_FLAT_PRIORITY") != nullptr;
+    static const bool probe_on = [] {
+        const char* e = getenv("VSLAM_QUEUE_PROBE");
+        return !(e && e[0] == '0');
+    }();
+    {
+        std::unique_ptr<QueueProbe> probe;
+        if (!flat && prio_lo != 0 && probe_on) {
+            (void)hipStreamSynchronize(c->stream);  // first batch call of the context only
+            probe.reset(new QueueProbe());
         }
-        HIPCHK(c, hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
+        for (int i = 0; i < vslam_ctx::kAux; ++i) {
+            // aux[0], aux[1] (Harris chain, scans and lists) yield to the octave kernels; aux[2] carries only the
+            // second-half upsample, which the main stream WAITS for: at low priority it was starved for the whole
+            // first-half octave kernel whenever its start slipped behind that kernel's (C++ host, 0.35 ms per step)
+            if (i == 2 || flat)
+                HIPCHK(c, hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking));
+            else
+                TRY(create_side_stream(c, prio_lo, probe.get(), &c->aux[i]));
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
+        }
     }
     for (auto& e : c->ev_oct) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_up2, hipEventDisableTiming));
@@ -1870,6 +1970,13 @@ int vslam_detect_batch_dev(vslam_ctx* c, const vslam_params* pp, const uint8_t* 
         }
     if (!c->phase_marked) TRY(mark_phase(c));  // no DoG path in this call: its end is the mark
     guard.armed = false;
+    return VSLAM_OK;
+}
+
+int vslam_ctx_side_stream_report(const vslam_ctx* c, int* replaced, int* at_main_priority) {
+    if (!c) return VSLAM_ERR_INVALID;
+    if (replaced) *replaced = c->side_streams_replaced;
+    if (at_main_priority) *at_main_priority = c->side_streams_flat;
     return VSLAM_OK;
 }
 

@@ -324,6 +324,8 @@ int main(int argc, char** argv) {
                 for (uint32_t v : oc) oriented_rank += v;
             }
         }
+        int probe_replaced = 0, probe_flat = 0;
+        (void)vslam_ctx_side_stream_report(det.context(), &probe_replaced, &probe_flat);
         const double dt_max = ex.max_over_ranks(dt, cs);
         if (!a.dump.empty() && last) dump_lists(a.dump, a.rows, a.cols, *last);
         uint64_t gh = 0, gd = 0;
@@ -338,11 +340,11 @@ int main(int argc, char** argv) {
             std::printf("{\"exe\": \"Stream\", \"host\": \"C++ (BatchDetector) + %s\", \"mode\": \"%s\", \"n_gpus\": %d, \"frames_per_batch\": %d, "
                         "\"batches\": %d, \"warmup\": %d, \"rows\": %d, \"cols\": %d, \"octaves\": %d, \"frames_per_sec\": %.2f, \"ms_per_batch\": %.4f, "
                         "\"keypoints_per_batch\": {\"harris\": %llu, \"dog\": %llu}, \"keypoints_per_sec\": %.1f, \"rank0_counts\": [%llu, %llu], "
-                        "\"steady_ms_per_batch\": %.4f, \"steady_frames_per_sec\": %.2f, \"counts_by_rank\": %s, \"lists\": \"%s\", \"oriented_points_rank0_last_batch\": %llu, \"pipelines\": %d}\n",
+                        "\"steady_ms_per_batch\": %.4f, \"steady_frames_per_sec\": %.2f, \"counts_by_rank\": %s, \"lists\": \"%s\", \"oriented_points_rank0_last_batch\": %llu, \"pipelines\": %d, \"side_streams_replaced\": %d, \"side_streams_at_main_priority\": %d}\n",
                         a.no_rccl ? "no communicator (--no-rccl)" : tcp ? "TCP rehearsal exchange (VSLAM_COUNT_BACKEND=tcp)" : "RCCL ncclAllGather", a.mode.c_str(),
                         env.world, a.frames, a.batches, a.warmup, a.rows, a.cols, det.params().n_octaves, fps, dt_max / a.batches * 1e3,
                         (unsigned long long)gh, (unsigned long long)gd, (double)(gh + gd) * a.batches / dt_max, (unsigned long long)all[0],
-                        (unsigned long long)all[1], steady_ms, steady_ms > 0 ? a.frames * 1e3 / steady_ms * env.world : 0.0, by_rank.c_str(), a.lists.c_str(), oriented_rank, det.pipelines());
+                        (unsigned long long)all[1], steady_ms, steady_ms > 0 ? a.frames * 1e3 / steady_ms * env.world : 0.0, by_rank.c_str(), a.lists.c_str(), oriented_rank, det.pipelines(), probe_replaced, probe_flat);
         }
         vslam::BatchDetector::free_pinned(h_frames);
         return 0;
