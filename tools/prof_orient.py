@@ -17,3 +17,10 @@ o=dict(response=torch.empty((n,rows,cols),dtype=torch.float32,device=dev), nms_m
 for i in range(3): ctx.detect_batch(p,frames,**o)
 torch.cuda.synchronize()
 print("survivors", int(o["oriented_survivors"].sum()), "oriented", int(o["oriented_counts"].sum()), "dog", int(o["dog_counts"].sum()))
+for name in ("k_orient_survivors",):
+    ctx.kernel_timing_enable(name)
+    for i in range(3): ctx.detect_batch(p,frames,**o)
+    torch.cuda.synchronize()
+    la, ms = ctx.kernel_timing_read()
+    ctx.kernel_timing_enable(None)
+    print(f"{name}: {la} launches, {ms / 3:.3f} ms per step", flush=True)

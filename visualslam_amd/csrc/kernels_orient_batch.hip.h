@@ -161,12 +161,20 @@ __global__ __launch_bounds__(256) void k_orient_survivors(const vslam_point* __r
             __syncthreads();
             const uint8_t* Pb = reinterpret_cast<const uint8_t*>(Pw) + sh;
             const int pb = 4 * pdw;
+            // element it = rr * span + cc; it += 256 moves (rr, cc) by (256 / span, 256 % span) with at most one wrap:
+            // one division per survivor instead of one per element
+            const int dq = 256 / span, dr = 256 - dq * span;
+            int rr = (int)threadIdx.x / span, cc = (int)threadIdx.x - rr * span;
+            int off = (rr + 1) * pb + (cc + 1);  // the region pixel inside the patch
             for (int it = threadIdx.x; it < span * span; it += 256) {
-                const int rr = it / span, cc = it - rr * span;
-                const uint8_t* c0 = Pb + (rr + 1) * pb + (cc + 1);  // the region pixel inside the patch
+                const uint8_t* c0 = Pb + off;
                 const float gx = (float)((int)c0[1] - (int)c0[-1]), gy = (float)((int)c0[pb] - (int)c0[-pb]);
                 const float xx = gx * gx, yy = gy * gy;
                 M[it] = sqrt_rn_small(xx + yy);
+                cc += dr;
+                const bool wrap = cc >= span;
+                cc -= wrap ? span : 0;
+                off += dq * pb + dr + (wrap ? pb - span : 0);
             }
             __syncthreads();
         } else if (region) {
@@ -202,7 +210,12 @@ __global__ __launch_bounds__(256) void k_orient_survivors(const vslam_point* __r
             for (int t = 1; t <= R; ++t) s0 += kl[R + t] * (rb[(i + R + t) * OR_WIN + j] + rb[(i + R - t) * OR_WIN + j]);
             mw[threadIdx.x] = s0;
             float gx, gy;
-            gradient_at(G, gpitch, rows, cols, clampi(y + i - OR_PAD, 0, rows - 1), clampi(x + j - OR_PAD, 0, cols - 1), gx, gy);
+            if (patch) {  // interior survivor: the window's pixels and their Sobel neighbours are in the staged patch
+                const uint8_t* c0 = reinterpret_cast<const uint8_t*>(Pw) + (px0 & 3) + (i + R + 1) * (4 * pdw) + (j + R + 1);
+                gx = (float)((int)c0[1] - (int)c0[-1]), gy = (float)((int)c0[4 * pdw] - (int)c0[-4 * pdw]);
+            } else {
+                gradient_at(G, gpitch, rows, cols, clampi(y + i - OR_PAD, 0, rows - 1), clampi(x + j - OR_PAD, 0, cols - 1), gx, gy);
+            }
             const float reductionCoeff = (float)OR_BINS / 360.0f;            // :114
             const int index = (int)(fast_atan2_deg(gy, gx) * reductionCoeff);  // :126
             bin_of = min(max(index, 0), OR_BINS - 1);
