@@ -46,5 +46,13 @@ while time.time() - t0 < (float(sys.argv[2]) if len(sys.argv) > 2 else 120):
             assert int(o["dog_counts"][f]) == len(allp)
             k = min(len(allp), pd.dog_cap)
             assert o["dog_points"][f][:k].cpu().numpy().view(capi.POINT_DTYPE).reshape(-1).tobytes() == allp[:k].tobytes()
+    if it % 7 == 0 and mode <= 1:  # the host-memory entry point (vslam_detect_batch_host): the same lists, packed
+        res = ctx.detect_batch_host(capi.default_params(rows, cols, n_octaves=n_oct, harris_cap=4096, dog_cap=16384, localize=int(mode >= 1)), frames)
+        for name, key, cnt, cap in (("harris", "harris_kps", "harris_counts", p.harris_cap), ("dog", "dog_points", "dog_counts", p.dog_cap)):
+            rec, off, c = res[name]
+            m = np.minimum(out[cnt], cap).astype(np.int64)
+            assert (c == out[cnt].astype(np.uint32)).all() and (off == np.concatenate([[0], np.cumsum(m)]).astype(np.uint64)).all()
+            want = np.concatenate([out[key][f][: m[f]] for f in range(n)]).reshape(-1)
+            assert rec.view(np.int32).reshape(-1).tobytes() == want.astype(np.int32).tobytes()
     it += 1
 print("soak ok", it, "cases")
