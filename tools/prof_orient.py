@@ -14,10 +14,12 @@ o=dict(response=torch.empty((n,rows,cols),dtype=torch.float32,device=dev), nms_m
  dog_points=torch.empty((n,p.dog_cap,6),dtype=torch.int32,device=dev), dog_counts=torch.zeros(n,dtype=torch.int32,device=dev),
  oriented_points=torch.empty((n,p.oriented_cap,6),dtype=torch.int32,device=dev), oriented_counts=torch.zeros(n,dtype=torch.int32,device=dev),
  oriented_survivors=torch.zeros(n,dtype=torch.int32,device=dev))
+if os.environ.get("DESCRIBE"):
+    o["descriptors"]=torch.empty((n,p.oriented_cap,128),dtype=torch.float32,device=dev); o["descriptor_defined"]=torch.zeros((n,p.oriented_cap),dtype=torch.uint8,device=dev)
 for i in range(3): ctx.detect_batch(p,frames,**o)
 torch.cuda.synchronize()
 print("survivors", int(o["oriented_survivors"].sum()), "oriented", int(o["oriented_counts"].sum()), "dog", int(o["dog_counts"].sum()))
-for name in ("k_orient_survivors",):
+for name in (("k_orient_survivors", "k_sift_descriptors") if os.environ.get("DESCRIBE") else ("k_orient_survivors",)):
     ctx.kernel_timing_enable(name)
     for i in range(3): ctx.detect_batch(p,frames,**o)
     torch.cuda.synchronize()

@@ -41,7 +41,11 @@ struct SiftLevels {  // per Gaussian level of the octave (null / 0 when no keypo
 // a = (cos, sin) of its angle.  Writes the 128 floats and the defined flag (0: the rotated window
 // leaves the padded level, descriptor zeroed).  Ends with the workgroup's shared arrays free again.
 constexpr int SIFT_KMAX = 640;  // blur taps staged in LDS (309 for octave 3 of the reference pyramid); longer kernels read them from memory
+constexpr int SIFT_EXT_R = 47;  // kernels up to 95 taps (octaves 0 and 1 of the reference pyramid: 25 ... 77) filter explicitly extended rows
+constexpr int SIFT_EXT_SPAN = SIFT_WIN + 2 * SIFT_EXT_R;
 struct SiftShared {
+    float ext[SIFT_WIN * SIFT_EXT_SPAN];   // rows of magROI extended by the repeated reflect-101, [row][R + 16 + R]
+    float extc[SIFT_EXT_SPAN * SIFT_WIN];  // the row-filtered ROI extended likewise along the rows, [R + 16 + R][col]
     float kt[SIFT_KMAX];
     float mag[SIFT_WIN * SIFT_WIN];   // magROI
     float rowf[SIFT_WIN * SIFT_WIN];  // row-filtered ROI
@@ -95,7 +99,43 @@ __device__ __forceinline__ void sift_one_keypoint(SiftShared& sh, const vslam_po
         sh.bin[t] = (uint8_t)min(max(index, 0), 7);
     }
     const int R = kn >> 1;
-    if (kn <= SIFT_KMAX) {
+    if (R <= SIFT_EXT_R) {
+        // The ROI is 16 wide and the kernels 25 ... 77 taps: the reflect-101 extension of a row is the triangle wave of
+        // period 30.  Written out once per row (and once per column of the row-filtered ROI), the two filter loops are a
+        // tap, a value at a fixed stride and the multiply-add - no index arithmetic per tap (it was two thirds of the
+        // loops' instructions).  Same products, same order.
+        constexpr int PER = 2 * (SIFT_WIN - 1);
+        const int span = SIFT_WIN + 2 * R;
+        for (int m = t; m < kn; m += 256) sh.kt[m] = k[m];
+        for (int e = t; e < SIFT_WIN * span; e += 256) {
+            const int r = e / span, p = e - r * span;
+            int q = (p - R) % PER;
+            q = q < 0 ? q + PER : q;
+            sh.ext[e] = sh.mag[r * SIFT_WIN + (q < SIFT_WIN ? q : PER - q)];
+        }
+        __syncthreads();
+        {   // row filter of ROI row i: s = k[0]*S[0]; s += k[m]*S[m]
+            const float* S = sh.ext + i * span + j;
+            float s0 = sh.kt[0] * S[0];
+#pragma unroll 4
+            for (int m = 1; m < kn; ++m) s0 += sh.kt[m] * S[m];
+            // its value stands at every extended row position that reflects onto row i: R + i + 30 z and R - i + 30 z
+            for (int p = (R + i) % PER; p < span; p += PER) sh.extc[p * SIFT_WIN + j] = s0;
+            if (i != 0 && i != SIFT_WIN - 1) {
+                int p0 = (R - i) % PER;
+                p0 = p0 < 0 ? p0 + PER : p0;
+                for (int p = p0; p < span; p += PER) sh.extc[p * SIFT_WIN + j] = s0;
+            }
+        }
+        __syncthreads();
+        {   // symmetric column filter: s = k[R]*S(0); s += k[R+m]*(S(+m) + S(-m))
+            const float* C = sh.extc + (R + i) * SIFT_WIN + j;
+            float s0 = sh.kt[R] * C[0];
+#pragma unroll 4
+            for (int m = 1; m <= R; ++m) s0 += sh.kt[R + m] * (C[m * SIFT_WIN] + C[-m * SIFT_WIN]);
+            sh.mw[t] = s0;
+        }
+    } else if (kn <= SIFT_KMAX) {
         // Taps from LDS (read from memory inside the loops, every multiply waited for a load round trip), and the
         // repeated reflect-101 of the 16-wide ROI as the triangle wave of period 30 it is, advanced by one per tap
         // instead of a reflection loop per tap: position p -> q = p mod 30, index = q < 16 ? q : 30 - q.
