@@ -52,6 +52,21 @@ __device__ __forceinline__ float edge_response_u8(const uint8_t* __restrict__ G,
     return (tr * tr) / det;                                                               // :107
 }
 
+// Lane B of the wave receives the 64-bit mask of the lanes whose bin is B, for B = 0 .. OR_BINS - 1: one compare into VCC
+// and two v_writelane with an immediate lane select per bin (this compiler has no builtin for v_writelane; the wait
+// states between the compare and the reads of VCC are written out because the hazard recogniser does not look inside
+// inline asm).
+template <int B>
+__device__ __forceinline__ void bin_masks_to_lanes(int mybin, unsigned int& lo, unsigned int& hi) {
+    if constexpr (B < OR_BINS) {
+        asm volatile("v_cmp_eq_u32_e32 vcc, %2, %3\n\ts_nop 3\n\tv_writelane_b32 %0, vcc_lo, %2\n\tv_writelane_b32 %1, vcc_hi, %2"
+                     : "+v"(lo), "+v"(hi)
+                     : "n"(B), "v"(mybin)
+                     : "vcc");
+        bin_masks_to_lanes<B + 1>(mybin, lo, hi);
+    }
+}
+
 // grid = (keypoints), 256 threads, dynamic LDS = orient_lds_bytes(max R).
 __global__ __launch_bounds__(256) void k_orient_keypoints(const vslam_point* __restrict__ kps, int n, OrientLevels lv, int gpitch, int rows, int cols,
                                                            unsigned long long* __restrict__ masks) {
@@ -109,10 +124,10 @@ __global__ __launch_bounds__(256) void k_orient_keypoints(const vslam_point* __r
     }
     // histogram (:112-133): a bin's magnitudes in pixel order.  Every wave ballots its 64 pixels bin by bin, the bin's
     // lane then adds only its own pixels (ascending bit = ascending pixel index) - as in k_orient_survivors
-#pragma unroll 4
-    for (int b = 0; b < OR_BINS; ++b) {
-        const unsigned long long m = __ballot(bin_of == b);
-        if ((threadIdx.x & 63) == 0) binmask[b][threadIdx.x >> 6] = m;
+    {
+        unsigned int mlo = 0, mhi = 0;
+        bin_masks_to_lanes<0>(bin_of, mlo, mhi);
+        if ((threadIdx.x & 63) < OR_BINS) binmask[threadIdx.x & 63][threadIdx.x >> 6] = ((unsigned long long)mhi << 32) | mlo;
     }
     __syncthreads();
     if (threadIdx.x < 64) {

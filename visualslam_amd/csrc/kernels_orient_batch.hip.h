@@ -225,12 +225,9 @@ __global__ __launch_bounds__(256) void k_orient_survivors(const vslam_point* __r
         // its 64 pixels bin by bin (ascending pixel index inside a mask = the reference's order), and the bin's
         // lane adds only its own pixels: a handful instead of 256.
         {
-            const int mybin = bin_of;
-#pragma unroll 4
-            for (int b = 0; b < OR_BINS; ++b) {
-                const unsigned long long m = __ballot(mybin == b);
-                if ((threadIdx.x & 63) == 0) binmask[b][threadIdx.x >> 6] = m;
-            }
+            unsigned int mlo = 0, mhi = 0;
+            bin_masks_to_lanes<0>(bin_of, mlo, mhi);
+            if ((threadIdx.x & 63) < OR_BINS) binmask[threadIdx.x & 63][threadIdx.x >> 6] = ((unsigned long long)mhi << 32) | mlo;
         }
         __syncthreads();
         if (threadIdx.x < 64) {
