@@ -55,4 +55,6 @@ while time.time() - t0 < (float(sys.argv[2]) if len(sys.argv) > 2 else 120):
             want = np.concatenate([out[key][f][: m[f]] for f in range(n)]).reshape(-1)
             assert rec.view(np.int32).reshape(-1).tobytes() == want.astype(np.int32).tobytes()
     it += 1
+    if it % 500 == 0:
+        print(f"... {it} cases, {time.time() - t0:.0f} s", flush=True)  # gpurun takes a silent run for a hung one
 print("soak ok", it, "cases")
