@@ -142,3 +142,43 @@ def test_dense_mode_layout(lib):
     for bad in (dict(localize=1), dict(extrema_window=5), dict(localize=1, orient=1)):
         with pytest.raises(capi.VslamError):
             capi.batch_layout(capi.default_params(64, 64, extrema_dense=1, **bad))
+
+
+def test_header_is_plain_c_and_ctypes_mirrors_its_struct_layouts(lib, tmp_path):
+    # The boundary is a C ABI: include/vslam.h must compile as C99 (no C++ leaking in), a C program must link against the
+    # library and get the same answers from its host-side helpers as the Python binding, and every struct the binding
+    # mirrors with ctypes must have the C compiler's size and field offsets (a mismatch would corrupt arguments silently).
+    import shutil
+    import subprocess
+
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    structs = {"vslam_params": capi.Params, "vslam_batch_layout": capi.BatchLayout, "vslam_batch_out": capi.BatchOut,
+               "vslam_host_lists": capi.HostLists, "vslam_pyramid_info": capi.PyramidInfo}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "vslam.h"', "int main(void) {"]
+    for cname, ct in structs.items():
+        lines.append(f'  printf("{cname} %zu", sizeof({cname}));')
+        for fname, *_ in ct._fields_:
+            lines.append(f'  printf(" %zu", offsetof({cname}, {fname}));')
+        lines.append('  printf("\\n");')
+    lines += ["  vslam_params p; vslam_batch_layout L; vslam_batch_out need;",
+              "  vslam_params_default(&p, 1080, 1920);",
+              "  if (vslam_batch_layout_query(&p, &L) != VSLAM_OK || vslam_batch_out_required(&p, 256, &need) != VSLAM_OK) return 2;",
+              '  printf("helpers %d %d %u %u %zu %zu %d\\n", vslam_version(), vslam_gauss_ksize_u8(1.6), p.harris_cap, p.dog_cap, (size_t)L.pyramid_frame_bytes, need.pyramid_bytes, (int)sizeof(vslam_point));',
+              "  return 0;", "}"]
+    src = tmp_path / "abi.c"
+    src.write_text("\n".join(lines) + "\n")
+    exe = tmp_path / "abi"
+    libdir = os.path.join(ROOT, "visualslam_amd", "lib")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                        "-L", libdir, "-lvslam", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    rows = {l.split()[0]: l.split()[1:] for l in out.stdout.strip().splitlines()}
+    for cname, ct in structs.items():
+        want = [C.sizeof(ct)] + [getattr(ct, f[0]).offset for f in ct._fields_]
+        assert [int(v) for v in rows[cname]] == want, (cname, rows[cname], want)
+    p = capi.default_params(1080, 1920)
+    Lp, need = capi.batch_layout(p), capi.batch_out_required(p, 256)
+    assert [int(v) for v in rows["helpers"]] == [200, oracle.gauss_ksize_u8(1.6), p.harris_cap, p.dog_cap, Lp.pyramid_frame_bytes, need.pyramid_bytes, 24]
