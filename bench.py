@@ -373,6 +373,42 @@ def main():
                            **({"what": "extension: dense 3x3x3 scale-space test on every pixel of levels 1..3 (params.extrema_dense) instead of the reference's lattice test"} if dn else {})}
         del mixed
 
+    # Two batches in flight: a second context on a second stream with output buffers of its own, the
+    # K steps alternating between the two.  Reported beside `value`, never as it: the pair's kernels run side by side, so a
+    # per-launch roofline of such a run says little, and how much the pair gains depends on the hardware-queue layout.
+    two = None
+    if args.modes and args.octaves > 0 and not (args.localize or args.orient) and n * rows * cols <= 256 * 1080 * 1920:
+        try:
+            s2 = torch.cuda.Stream()
+            ctx2 = capi.Context(local_rank_dev, s2.cuda_stream)
+            out1 = {k: v for k, v in shared.items() if k != "dense_bits"}
+            out2 = {k: torch.empty_like(v) for k, v in out1.items()}
+            cur = torch.cuda.current_stream()
+            pair = ((ctx, cur, out1), (ctx2, s2, out2))
+
+            def step2(k):
+                c, st, o = pair[k & 1]
+                with torch.cuda.stream(st):
+                    c.detect_batch(p, frames, **o)
+
+            s2.wait_stream(cur)
+            for k in range(4):
+                step2(k)
+            fence()
+            t0 = time.perf_counter()
+            for k in range(args.steps):
+                step2(k)
+            fence()
+            dt2 = time.perf_counter() - t0
+            same = bool((out2["dog_counts"] == out1["dog_counts"]).all() and (out2["harris_counts"] == out1["harris_counts"]).all())
+            two = {"frames_per_sec": n * world * args.steps / dt2, "ms_per_step": dt2 / args.steps * 1e3, "steps": args.steps,
+                   "same_counts_on_both_contexts": same,
+                   "what": "K steps alternating between two contexts / streams / output sets (per rank); not `value`: see DESIGN section 5.4"}
+            ctx2.close()
+            del out2
+        except Exception as e:  # a secondary figure must never take the headline down
+            two = {"error": str(e)[:200]}
+
     if rank == 0:
         algo = kernel_algorithmic_bytes(L, rows, cols)
         total_frames = n * world * args.steps
@@ -457,6 +493,7 @@ def main():
             "keypoints_per_step": {"harris": main["harris"], "dog": main["dog"], "list_overflow": main["list_overflow"],
                                    **({"oriented": main["oriented"], "oriented_truncated": main["oriented_truncated"]} if args.orient else {})},
             "modes": modes,
+            "two_in_flight": two,
             "pipeline_hbm": {
                 "algorithmic_bytes_per_frame": bytes_frame,
                 "achieved_GBps": bytes_frame * fps / world / 1e9,

@@ -64,6 +64,7 @@ def test_bench_one_rank_goes_through_rccl():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["value"] > 0
     assert d["distributed"] == {"initialized": True, "world_size": 1, "backend": "nccl", "ranks_gathered": 1}
+    assert d["two_in_flight"]["frames_per_sec"] > 0 and d["two_in_flight"]["same_counts_on_both_contexts"] is True  # secondary figure, DESIGN 5.4
     assert d["cxx_host"]["device"]["frames_per_sec"] > 0 and "RCCL" in d["cxx_host"]["device"]["host"]
     assert d["cxx_host"]["device"]["keypoints_per_batch"] == {"harris": d["keypoints_per_step"]["harris"], "dog": d["keypoints_per_step"]["dog"]}
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--frames", "8", "--rows", "240", "--cols", "320", "--steps", "2",
