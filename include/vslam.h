@@ -81,11 +81,13 @@ const char* vslam_status_string(int status);
 int vslam_ctx_create(int device, void* stream, vslam_ctx** out);
 int vslam_ctx_destroy(vslam_ctx* ctx);
 int vslam_ctx_sync(vslam_ctx* ctx);
-/* The batched path's two low-priority side streams are tried out when they are created (first batch call): HIP binds a
- * stream to a hardware queue of its choosing, and a low-priority queue on the main stream's command-processor pipe is
- * starved while that stream waits for it.  Reports how many candidate streams were replaced and
- * how many side streams ended up at the main stream's priority because no candidate passed.  Diagnostic only. */
-int vslam_ctx_side_stream_report(const vslam_ctx* ctx, int* replaced, int* at_main_priority);
+/* The batched path runs its Harris chain and its scans / lists on two low-priority side streams.  HIP binds a stream to a
+ * hardware queue of its choosing, and on an unlucky queue those kernels crawl (up to -20 %), so a
+ * context times its 2nd to 5th full-size batch call on three candidate pairs of side streams and keeps the fastest from the
+ * 6th call on (one host-side wait for the 5th call's end happens there; results never depend on the pair).
+ * Reports the index of the pair in use (0 = the first created) and the state of the comparison (0 not started,
+ * 1 measuring, 2 decided).  VSLAM_STREAM_TUNER=0 switches the comparison off.  Diagnostic only. */
+int vslam_ctx_side_stream_report(const vslam_ctx* ctx, int* pair, int* state);
 /* Two batches in flight: a second context (own stream, own output buffers) whose batch starts when `leader`'s most
  * recent vslam_detect_batch_dev call is past its octave-0 kernels - the long, issue-bound part - instead of beside
  * them.  The coarse octaves, scans and list kernels that follow are short and leave issue slots idle; the follower's

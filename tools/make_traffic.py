@@ -16,7 +16,7 @@ out = {"_how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) 
        "_round": sys.argv[4] if len(sys.argv) > 4 else ""}
 tot = 0.0
 for k, v in sorted(d.items()):
-    if k == "k_queue_probe":  # the side streams' placement probe: once per context, not per frame
+    if k == "k_queue_probe":  # a one-off probe kernel an earlier build of the library ran once per context (not per frame)
         continue
     if "hbm_bytes_total" in v:
         per = v["hbm_bytes_total"] / (frames * steps)

@@ -476,7 +476,8 @@ class Context:
         return n, bo, (frames.stride(0) if n > 1 else N)  # a size-1 dimension may carry any stride
 
     def side_stream_report(self):
-        """vslam_ctx_side_stream_report: (candidate side streams replaced by the placement probe, side streams left at the main priority)."""
+        """vslam_ctx_side_stream_report: (index of the side-stream pair the batched path runs on: 0 = the first created,
+        state of the comparison: 0 not started, 1 measuring, 2 decided)."""
         a, b = C.c_int(0), C.c_int(0)
         self._chk(lib().vslam_ctx_side_stream_report(self._h, C.byref(a), C.byref(b)), "vslam_ctx_side_stream_report")
         return a.value, b.value

@@ -31,6 +31,20 @@ using namespace vslam;
 
 // ------------------------------------------------------------------------- context
 
+// Which pair of low-priority side streams the batched path runs on: see "side-stream placement" below.
+struct StreamTuner {
+    static constexpr int K = 3;                      // candidate pairs
+    static constexpr int M = K + 1;                  // measured calls: pair 0, 1, 2, 0
+    hipStream_t cand[K][2] = {};                     // cand[0] = the pair ensure_aux created
+    hipEvent_t t0[M] = {}, t1[M] = {};
+    int measured = 0;                                // calls measured so far
+    int measuring = -1;                              // slot being measured by the current call
+    bool done = false;
+    int chosen = 0;
+    unsigned long long key = 0;                      // shape of the calls being compared
+    int calls = 0;
+};
+
 struct vslam_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -49,7 +63,8 @@ struct vslam_ctx {
     static constexpr int kAux = 3;
     hipStream_t aux[kAux] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[kAux] = {nullptr, nullptr, nullptr}, ev_oct[VSLAM_MAX_OCTAVES] = {};
-    int side_streams_replaced = 0, side_streams_flat = 0;  // placement probe of the low-priority side streams (ensure_aux)
+    int prio_lo = 0;      // priority of the two yielding side streams (0: the main stream's)
+    StreamTuner tuner;    // which pair of side streams the batched path runs on (see StreamTuner)
     hipEvent_t ev_phase = nullptr;  // recorded by every vslam_detect_batch_dev call once its octave-0 kernels are enqueued (vslam_ctx_follow)
     bool phase_marked = false;
     hipEvent_t ev_up2 = nullptr;  // the second half of a batch has been upsampled (enqueue_dog)
@@ -148,90 +163,101 @@ static std::pair<hipEvent_t, hipEvent_t>* timing_slot(vslam_ctx* c) {
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-// ---- side-stream placement probe -------------------------------------------------------------------------------
+// ---- side-stream placement ---------------------------------------------------------------------------------------
 // HIP binds every stream to one of GPU_MAX_HW_QUEUES hardware queues per priority level, and the placement is not ours to
-// choose.  Measured: a LOW-priority queue that shares a command-processor pipe with the main
-// stream's queue is starved whenever that queue is parked on a barrier waiting for it - which is what the join at the
-// end of every batch call is: its kernels then run 1.6-5x slower even with the chip otherwise idle (11.3 k instead of
-// 14.1 k frames/s).  So a new low-priority side stream is tried out once: a many-workgroup kernel timed with the main
-// stream idle and with the main stream parked on its end event.  A starved stream is replaced by a fresh one (which
-// binds to the next queue of the pool), a few times; if none passes, the side stream runs at the main stream's priority,
-// where the effect does not exist.  VSLAM_QUEUE_PROBE=0 skips the probe.
-namespace vslam {
-__global__ void __launch_bounds__(256) k_queue_probe(uint4* p, unsigned n) {
-    const unsigned i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    uint4 v = p[i];
-    v.x = v.x * 1664525u + v.y;
-    p[i] = v;
+// choose.  Measured: depending on the queue a LOW-priority side stream lands on, the batch runs up
+// to 20 % slower (the same binary: 11.4 k frames/s with 3 queues per level, 14.2 k with 12) - on one bad queue the side
+// kernels crawl while the main stream's queue sits on the barrier that waits for them.  A synthetic probe of that
+// effect (tools/queue_probe.hip) finds the bad queue in some layouts and condemns a good one in others, so the library
+// measures the real thing instead: the 2nd to 5th batch call of a context run on three candidate pairs of side streams
+// (the first pair twice), each call timed with events on the main stream, and the 6th call adopts the fastest pair -
+// the first one unless another is at least 3 % faster.  The calls must have the same shape; the results of a call do not
+// depend on the streams it runs on.  One host-side wait (for the 5th call's end) happens at the 6th call.
+// VSLAM_STREAM_TUNER=0 keeps the first pair.
+static int tuner_pair_of(int slot) { return slot == StreamTuner::K ? 0 : slot; }
+
+static int create_side_stream(vslam_ctx* c, int prio_lo, hipStream_t* out) {
+    if (prio_lo == 0 || hipStreamCreateWithPriority(out, hipStreamNonBlocking, prio_lo) != hipSuccess) {
+        (void)hipGetLastError();  // priorities are a speed matter only
+        HIPCHK(c, hipStreamCreateWithFlags(out, hipStreamNonBlocking));
+    }
+    return VSLAM_OK;
 }
-}  // namespace vslam
 
-struct QueueProbe {
-    uint4* buf = nullptr;
-    unsigned n = 16u << 20;  // 256 MB: 65536 workgroups, ~0.1 ms
-    hipEvent_t a = nullptr, b = nullptr, fork = nullptr;
-    bool ok = false;
-    QueueProbe() {
-        ok = hipMalloc((void**)&buf, (size_t)n * sizeof(uint4)) == hipSuccess && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess &&
-             hipEventCreateWithFlags(&fork, hipEventDisableTiming) == hipSuccess;
-        if (!ok) (void)hipGetLastError();
+static void tuner_finish(vslam_ctx* c, int chosen) {
+    StreamTuner& t = c->tuner;
+    t.chosen = chosen;
+    t.done = true;
+    t.measuring = -1;
+    c->aux[0] = t.cand[chosen][0], c->aux[1] = t.cand[chosen][1];
+    for (int k = 0; k < StreamTuner::K; ++k) {
+        if (k == chosen) continue;
+        for (hipStream_t& st : t.cand[k])
+            if (st) (void)hipStreamSynchronize(st), (void)hipStreamDestroy(st), st = nullptr;
     }
-    ~QueueProbe() {
-        if (buf) (void)hipFree(buf);
-        for (hipEvent_t e : {a, b, fork})
-            if (e) (void)hipEventDestroy(e);
+    for (int m = 0; m < StreamTuner::M; ++m) {
+        if (t.t0[m]) (void)hipEventDestroy(t.t0[m]), t.t0[m] = nullptr;
+        if (t.t1[m]) (void)hipEventDestroy(t.t1[m]), t.t1[m] = nullptr;
     }
-    // best of three; < 0 on any HIP error (the probe then decides nothing)
-    float run(hipStream_t main_s, hipStream_t s, bool park_main) {
-        float best = -1.f;
-        for (int rep = 0; rep < 3; ++rep) {
-            bool good = hipEventRecord(fork, main_s) == hipSuccess && hipStreamWaitEvent(s, fork, 0) == hipSuccess && hipEventRecord(a, s) == hipSuccess;
-            hipLaunchKernelGGL(vslam::k_queue_probe, dim3(n / 256), dim3(256), 0, s, buf, n);
-            good = good && hipGetLastError() == hipSuccess && hipEventRecord(b, s) == hipSuccess;
-            if (good && park_main) {  // what the join of a batch call looks like: main waits for the side stream, more work behind
-                good = hipStreamWaitEvent(main_s, b, 0) == hipSuccess;
-                hipLaunchKernelGGL(vslam::k_queue_probe, dim3(64), dim3(256), 0, main_s, buf, 64u * 256u);
-                good = good && hipGetLastError() == hipSuccess;
-            }
-            good = (hipStreamSynchronize(s) == hipSuccess) && good;
-            good = (hipStreamSynchronize(main_s) == hipSuccess) && good;
-            float ms = 0.f;
-            if (!good || hipEventElapsedTime(&ms, a, b) != hipSuccess) {
-                (void)hipGetLastError();
-                return -1.f;
-            }
-            best = (best < 0.f || ms < best) ? ms : best;
-        }
-        return best;
-    }
-    bool starved(hipStream_t main_s, hipStream_t s) {
-        const float free_ms = run(main_s, s, false), parked_ms = run(main_s, s, true);
-        return free_ms > 0.f && parked_ms > 1.3f * free_ms;
-    }
-};
+}
 
-// A low-priority side stream that the main stream's queue does not starve, or a normal-priority one.
-static int create_side_stream(vslam_ctx* c, int prio_lo, QueueProbe* probe, hipStream_t* out) {
-    std::vector<hipStream_t> rejected;
-    hipStream_t s = nullptr;
-    for (int attempt = 0; attempt < 4 && prio_lo != 0; ++attempt) {
-        if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio_lo) != hipSuccess) {
-            (void)hipGetLastError();  // priorities are a speed matter only
-            s = nullptr;
-            break;
-        }
-        if (!probe || !probe->ok || !probe->starved(c->stream, s)) break;
-        rejected.push_back(s);  // kept alive until the end, so that the next one binds to another queue
-        s = nullptr;
+// Before the fork of a batch call (ensure_aux has run): picks the pair of side streams this call uses.
+static int tuner_before_call(vslam_ctx* c, unsigned long long key, bool eligible) {
+    StreamTuner& t = c->tuner;
+    static const bool enabled = [] {
+        const char* e = getenv("VSLAM_STREAM_TUNER");
+        return !(e && e[0] == '0');
+    }();
+    if (t.done) return VSLAM_OK;
+    ++t.calls;
+    if (!enabled || c->prio_lo == 0) {
+        t.done = true;
+        return VSLAM_OK;
     }
-    for (hipStream_t r : rejected) (void)hipStreamDestroy(r);
-    c->side_streams_replaced += (int)rejected.size();
-    if (!s) {
-        HIPCHK(c, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-        if (!rejected.empty()) c->side_streams_flat += 1;
+    if (t.calls == 1 || !eligible) {  // the first call pays one-time costs; small / odd calls are not what is being tuned
+        t.key = key;
+        return VSLAM_OK;
     }
-    *out = s;
+    if (key != t.key) {  // the shape changed in the middle: start over with the new one (the pairs created so far stay)
+        t.key = key;
+        t.measured = 0;
+        c->aux[0] = t.cand[0][0], c->aux[1] = t.cand[0][1];
+        return VSLAM_OK;
+    }
+    if (t.measured < StreamTuner::M) {
+        const int m = t.measured, k = tuner_pair_of(m);
+        for (hipStream_t& st : t.cand[k])
+            if (!st) TRY(create_side_stream(c, c->prio_lo, &st));  // created while the other pairs exist: binds to another queue
+        if (!t.t0[m]) HIPCHK(c, hipEventCreate(&t.t0[m]));
+        if (!t.t1[m]) HIPCHK(c, hipEventCreate(&t.t1[m]));
+        c->aux[0] = t.cand[k][0], c->aux[1] = t.cand[k][1];
+        HIPCHK(c, hipEventRecord(t.t0[m], c->stream));
+        t.measuring = m;
+        return VSLAM_OK;
+    }
+    // every candidate has been timed: wait (once) for the last measured call and keep the fastest pair
+    float ms[StreamTuner::M] = {};
+    bool ok = hipEventSynchronize(t.t1[StreamTuner::M - 1]) == hipSuccess;
+    for (int m = 0; m < StreamTuner::M && ok; ++m) ok = hipEventElapsedTime(&ms[m], t.t0[m], t.t1[m]) == hipSuccess;
+    int best = 0;
+    if (ok) {
+        const float first = std::min(ms[0], ms[StreamTuner::K]);  // pair 0 was timed twice (the early calls run on cold clocks)
+        float best_ms = first;
+        for (int k = 1; k < StreamTuner::K; ++k)
+            if (ms[k] < 0.97f * first && ms[k] < best_ms) best = k, best_ms = ms[k];
+    } else {
+        (void)hipGetLastError();
+    }
+    tuner_finish(c, best);
+    return VSLAM_OK;
+}
+
+static int tuner_after_call(vslam_ctx* c) {
+    StreamTuner& t = c->tuner;
+    if (t.measuring < 0) return VSLAM_OK;
+    HIPCHK(c, hipEventRecord(t.t1[t.measuring], c->stream));
+    t.measuring = -1;
+    ++t.measured;
     return VSLAM_OK;
 }
 
@@ -243,27 +269,18 @@ static int ensure_aux(vslam_ctx* c) {
         prio_lo = 0;
     }
     static const bool flat = getenv("VSLAM_FLAT_PRIORITY") != nullptr;
-    static const bool probe_on = [] {
-        const char* e = getenv("VSLAM_QUEUE_PROBE");
-        return !(e && e[0] == '0');
-    }();
-    {
-        std::unique_ptr<QueueProbe> probe;
-        if (!flat && prio_lo != 0 && probe_on) {
-            (void)hipStreamSynchronize(c->stream);  // first batch call of the context only
-            probe.reset(new QueueProbe());
-        }
-        for (int i = 0; i < vslam_ctx::kAux; ++i) {
-            // aux[0], aux[1] (Harris chain, scans and lists) yield to the octave kernels; aux[2] carries only the
-            // second-half upsample, which the main stream WAITS for: at low priority it was starved for the whole
-            // first-half octave kernel whenever its start slipped behind that kernel's (C++ host, 0.35 ms per step)
-            if (i == 2 || flat)
-                HIPCHK(c, hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking));
-            else
-                TRY(create_side_stream(c, prio_lo, probe.get(), &c->aux[i]));
-            HIPCHK(c, hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
-        }
+    c->prio_lo = flat ? 0 : prio_lo;
+    for (int i = 0; i < vslam_ctx::kAux; ++i) {
+        // aux[0], aux[1] (Harris chain, scans and lists) yield to the octave kernels; aux[2] carries only the
+        // second-half upsample, which the main stream WAITS for: at low priority it was starved for the whole
+        // first-half octave kernel whenever its start slipped behind that kernel's (C++ host, 0.35 ms per step)
+        if (i == 2)
+            HIPCHK(c, hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking));
+        else
+            TRY(create_side_stream(c, c->prio_lo, &c->aux[i]));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
     }
+    c->tuner.cand[0][0] = c->aux[0], c->tuner.cand[0][1] = c->aux[1];
     for (auto& e : c->ev_oct) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_up2, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_chunk, hipEventDisableTiming));
@@ -993,6 +1010,7 @@ int vslam_ctx_destroy(vslam_ctx* c) {
     for (auto& b : c->block_cache) (void)hipFree(b.second);
     if (c->loc_lut) (void)hipFree(c->loc_lut);
     for (auto& kv : c->orient_taps) (void)hipFree(kv.second);
+    if (c->ev_fork && !c->tuner.done) tuner_finish(c, 0);  // candidate pairs of an unfinished comparison go first (aux = pair 0 again)
     for (int i = 0; i < vslam_ctx::kAux; ++i) {
         if (c->aux[i]) (void)hipStreamDestroy(c->aux[i]);
         if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
@@ -1899,6 +1917,11 @@ int vslam_detect_batch_dev(vslam_ctx* c, const vslam_params* pp, const uint8_t* 
     } guard{c};
     if (use_aux) {
         TRY(ensure_aux(c));
+        // the side-stream pair of this call (StreamTuner): only full-size batches with both paths are compared
+        const unsigned long long key = ((unsigned long long)(unsigned)n_frames << 40) ^ ((unsigned long long)(unsigned)p.rows << 20) ^ (unsigned)p.cols ^
+                                       ((unsigned long long)(p.localize + 2 * p.orient + 4 * p.extrema_dense + 8 * (out->descriptors != nullptr)) << 60) ^
+                                       ((unsigned long long)(unsigned)p.n_octaves << 56);
+        TRY(tuner_before_call(c, key, dog && harris && n_frames >= 32));
         HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
         for (int i = 0; i < vslam_ctx::kAux; ++i) HIPCHK(c, hipStreamWaitEvent(c->aux[i], c->ev_fork, 0));
         sh = c->aux[0];
@@ -1969,14 +1992,15 @@ int vslam_detect_batch_dev(vslam_ctx* c, const vslam_params* pp, const uint8_t* 
             HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[i], 0));
         }
     if (!c->phase_marked) TRY(mark_phase(c));  // no DoG path in this call: its end is the mark
+    if (use_aux) TRY(tuner_after_call(c));
     guard.armed = false;
     return VSLAM_OK;
 }
 
-int vslam_ctx_side_stream_report(const vslam_ctx* c, int* replaced, int* at_main_priority) {
+int vslam_ctx_side_stream_report(const vslam_ctx* c, int* replaced, int* at_main_priority) {  // = (chosen pair, tuner state)
     if (!c) return VSLAM_ERR_INVALID;
-    if (replaced) *replaced = c->side_streams_replaced;
-    if (at_main_priority) *at_main_priority = c->side_streams_flat;
+    if (replaced) *replaced = c->tuner.chosen;
+    if (at_main_priority) *at_main_priority = c->tuner.done ? 2 : (c->tuner.calls > 1 ? 1 : 0);
     return VSLAM_OK;
 }
 

@@ -43,7 +43,7 @@ namespace {
 
 struct Args {
     std::string mode = "device", source = "synth", dump, lists = "candidates";
-    int frames = 256, batches = 8, warmup = 2, rows = 1080, cols = 1920, octaves = 4, pipelines = 1;
+    int frames = 256, batches = 8, warmup = 6, rows = 1080, cols = 1920, octaves = 4, pipelines = 1;
     bool rdv_selftest = false, no_allgather = false, no_rccl = false;
 };
 
@@ -340,7 +340,7 @@ int main(int argc, char** argv) {
             std::printf("{\"exe\": \"Stream\", \"host\": \"C++ (BatchDetector) + %s\", \"mode\": \"%s\", \"n_gpus\": %d, \"frames_per_batch\": %d, "
                         "\"batches\": %d, \"warmup\": %d, \"rows\": %d, \"cols\": %d, \"octaves\": %d, \"frames_per_sec\": %.2f, \"ms_per_batch\": %.4f, "
                         "\"keypoints_per_batch\": {\"harris\": %llu, \"dog\": %llu}, \"keypoints_per_sec\": %.1f, \"rank0_counts\": [%llu, %llu], "
-                        "\"steady_ms_per_batch\": %.4f, \"steady_frames_per_sec\": %.2f, \"counts_by_rank\": %s, \"lists\": \"%s\", \"oriented_points_rank0_last_batch\": %llu, \"pipelines\": %d, \"side_streams_replaced\": %d, \"side_streams_at_main_priority\": %d}\n",
+                        "\"steady_ms_per_batch\": %.4f, \"steady_frames_per_sec\": %.2f, \"counts_by_rank\": %s, \"lists\": \"%s\", \"oriented_points_rank0_last_batch\": %llu, \"pipelines\": %d, \"side_stream_pair\": %d, \"side_stream_tuner\": %d}\n",
                         a.no_rccl ? "no communicator (--no-rccl)" : tcp ? "TCP rehearsal exchange (VSLAM_COUNT_BACKEND=tcp)" : "RCCL ncclAllGather", a.mode.c_str(),
                         env.world, a.frames, a.batches, a.warmup, a.rows, a.cols, det.params().n_octaves, fps, dt_max / a.batches * 1e3,
                         (unsigned long long)gh, (unsigned long long)gd, (double)(gh + gd) * a.batches / dt_max, (unsigned long long)all[0],
