@@ -96,6 +96,13 @@ int vslam_ctx_side_stream_report(const vslam_ctx* ctx, int* pair, int* state);
  * Enqueues one event wait on ctx's stream; a no-op if the leader has not run a batch yet.
  * visualslam_amd/cxx/batch_detector.hpp (Options::pipelines) uses it. */
 int vslam_ctx_follow(vslam_ctx* ctx, const vslam_ctx* leader);
+/* OPT-IN, off by default (environment: VSLAM_MX=1 switches it on for every context created afterwards): the
+ * Gaussian levels of the LDS-tiled octaves (GaussVector + Diff_of_Gauss, GaussPyramid.cpp:166-200) as banded
+ * matrix products on the matrix cores (v_mfma_i32_32x32x32_i8) instead of packed dot instructions.  Results are
+ * bit-identical (exact integer arithmetic either way); BASELINE.json's north star rules MFMA out for this path, so
+ * the default, and everything bench.py reports as `value` / `roofline`, stays on the dot kernels. */
+int vslam_ctx_set_matrix_path(vslam_ctx* ctx, int on);
+int vslam_ctx_get_matrix_path(const vslam_ctx* ctx);
 const char* vslam_last_error(const vslam_ctx* ctx);
 
 /* ------------------------------------------ host-side parameter helpers (no GPU) */

@@ -587,6 +587,65 @@ def test_band_kernel_is_dispatched_when_asked_for(env):
     assert launches >= 2 and ms > 0
 
 
+def test_matrix_core_octave_kernel_matches_oracle():
+    # OPT-IN path (VSLAM_MX=1 / vslam_ctx_set_matrix_path, never the default: the north star rules MFMA out): octaves 0
+    # and 1 of the reference's pyramid as banded matrix products (k_pyr_octave_mx).  One child process runs the shape
+    # sweep, the ragged / tiny / 1080p cases, the reference images and the dispatch check under the switch.
+    import os
+    import subprocess
+    import sys
+
+    if os.environ.get("VSLAM_MX") == "1":
+        pytest.skip("already inside the matrix-path run")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VSLAM_MX="1")
+    sel = ("random_shapes or ragged or tiny_frames or config2_and_3 or small_frames_all_outputs or matrix_kernel_is_dispatched "
+           "or two_full_chunks or batch_on_the_reference_images")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_batch.py"),
+                        os.path.join(root, "tests", "test_gpu_ref_images.py"), "-m", "gpu", "-q", "-x", "-k", sel],
+                       capture_output=True, text=True, timeout=1500, env=env, cwd=root)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_matrix_kernel_is_dispatched_when_asked_for(env):
+    import os
+
+    if os.environ.get("VSLAM_MX") != "1":
+        pytest.skip("runs inside test_matrix_core_octave_kernel_matches_oracle's child process")
+    ctx, torch = env
+    assert ctx.matrix_path()
+    ctx.kernel_timing_enable("k_pyr_octave_mx")
+    run_batch(ctx, torch, synth.frames_np(1, 480, 640, stream_id=1))
+    launches, ms = ctx.kernel_timing_read()
+    ctx.kernel_timing_enable(None)
+    assert launches >= 2 and ms > 0
+
+
+def test_matrix_path_switch_per_context(env):
+    # the same batch through the dot kernels and, switched on for this context only, through the matrix-core kernels:
+    # every byte of the pyramid and both lists equal
+    ctx, torch = env
+    frames = synth.frames_np(3, 200, 320, stream_id=5)  # every octave's width a multiple of 16: no row padding, whole blocks comparable
+    frames[1] = synth.frame_np(200, 320, kind="noise")
+    was = ctx.matrix_path()
+    try:
+        ctx.set_matrix_path(False)
+        p, L, a = run_batch(ctx, torch, frames)
+        ctx.set_matrix_path(True)
+        ctx.kernel_timing_enable("k_pyr_octave_mx")
+        p, L, b = run_batch(ctx, torch, frames)
+        launches, _ = ctx.kernel_timing_read()
+        ctx.kernel_timing_enable(None)
+    finally:
+        ctx.set_matrix_path(was)
+    assert launches == 2
+    for k in a:
+        if a[k] is not None:
+            assert np.array_equal(a[k], b[k]), k
+    for f in range(3):
+        check_frame(p, L, b, f, frames[f], 4)
+
+
 def test_batch_random_shapes(env):
     # seeded sweep over frame sizes (multiples of 4/8/16 and ragged ones) through every dispatch
     # path of the batch: specialised and generic kernels must agree with the oracle everywhere

@@ -127,6 +127,8 @@ SIGNATURES = {
     "vslam_batch_out_required": (_I, [C.POINTER(Params), _I, C.POINTER(BatchOut)]),
     "vslam_detect_batch_dev": (_I, [_P, C.POINTER(Params), _P, _Z, _I, C.POINTER(BatchOut)]),
     "vslam_ctx_follow": (_I, [_P, _P]),
+    "vslam_ctx_set_matrix_path": (_I, [_P, _I]),
+    "vslam_ctx_get_matrix_path": (_I, [_P]),
     "vslam_ctx_side_stream_report": (_I, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "vslam_detect_batch_host": (_I, [_P, C.POINTER(Params), _P, _Z, _I, C.POINTER(HostLists)]),
     "vslam_pack_lists_dev": (_I, [_P, _P, _Z, C.c_uint32, _P, _I, _P, _Z, _P]),
@@ -481,6 +483,13 @@ class Context:
         a, b = C.c_int(0), C.c_int(0)
         self._chk(lib().vslam_ctx_side_stream_report(self._h, C.byref(a), C.byref(b)), "vslam_ctx_side_stream_report")
         return a.value, b.value
+
+    def set_matrix_path(self, on: bool):
+        """vslam_ctx_set_matrix_path: OPT-IN matrix-core (MFMA) form of the LDS-tiled octave kernels; off by default."""
+        self._chk(lib().vslam_ctx_set_matrix_path(self._h, 1 if on else 0), "vslam_ctx_set_matrix_path")
+
+    def matrix_path(self) -> bool:
+        return bool(lib().vslam_ctx_get_matrix_path(self._h))
 
     def follow(self, leader: "Context"):
         """vslam_ctx_follow: this context's next work starts once `leader`'s latest batch is past its octave-0 kernels."""

@@ -1,0 +1,337 @@
+// K-D1, matrix-core form (OPT-IN: VSLAM_MX=1 / vslam_ctx_set_matrix_path; never the default path).
+//
+// The same contract as k_pyr_octave (kernels_pyramid.hip.h): one launch turns the octave base (u8) into the
+// octave's six Gaussian images and five DoG images -- GaussVector + Diff_of_Gauss of
+// GaussPyramid.cpp:166-200 -- and the next octave's base (GaussPyramid.cpp:123-126), bit for bit.
+//
+// BASELINE.json's north star says "no MFMA (no dense contraction here)".  A separable blur IS a pair of
+// banded-Toeplitz matrix products, and round 3's probe (tools/mfma_probe.hip) measured that form at 1.8-2.8x
+// the packed-dot floor per level; the default path, bench.py's `value` and `roofline` therefore stay on the
+// dot kernels and this kernel is reported beside them.
+//
+// Arithmetic: G = (sum_y sum_x ty*tx*p + 32768) >> 16, exact integers, any order.
+// Per level and per 32 x 32 output block, as v_mfma_i32_32x32x32_i8 (A: lane l holds row l&31, K bytes
+// 16*(l>>5)+j; B: column l&31, same K; C: column l&31, rows (v&3) + 8*(v>>2) + 4*(l>>5) in register v):
+//
+//   pass 1 (vertical)    C1[x, y'] = sum_y P'[x, y] * Tv[y, y']     A = pixels - 128 from the byte-transposed
+//                        LDS image (lane = column x, 16 consecutive rows), B = the taps as a band matrix.
+//                        C1 = H - 32768, H the 16-bit column sum; NS = 2 K steps for kernels up to 33 taps, 3 up to 65.
+//   hand-off             C1 has the output row y' on the lane and 16 columns x in its registers: the shape of
+//                        a B operand whose K index is x.  Operands are 8-bit, H has 16: split into a signed
+//                        high-byte plane and a low-byte plane (4 v_perm + 1 v_xor per 4 values).
+//   pass 2 (horizontal)  C2[x', y'] = sum_x Th[x', x] * H[x, y']    A = the band matrix with its K columns in
+//                        the register order of C1 and its ROWS permuted so that register v of lane half h is
+//                        output column 16 h + v: each lane ends up with 16 CONSECUTIVE bytes of its image
+//                        row, no lane exchange.  One product per byte plane;
+//                        G = ((C2hi << 8) + C2lo) >> 16, the biases and the rounding constant in C2lo's start value.
+//   epilogue             as k_pyr_octave: byte 2 of each sum into 16-bit lanes, v_pk_sub_u16 clamp against the
+//                        previous level (kept in registers), 16-byte stores of G and D.
+//
+// A wave owns a strip of 32 rows x SW columns of the tile and walks along it: input block ib goes through
+// pass 1 and the split into a ring of NS converted blocks, and as soon as the ring holds output block
+// ob = ib - (NS - 1)'s inputs its pass 2 runs.  After the tile is staged the waves never meet again (no barrier, no
+// LDS writes).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+
+#include "../../include/vslam.h"
+
+namespace vslam {
+
+// (self-contained: this header is compiled in its own translation unit, the kernels of the other headers are not)
+__device__ __forceinline__ int mx_reflect101(int p, int len) {  // cv::borderInterpolate(p, len, BORDER_REFLECT_101), repeated until inside
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) p = p < 0 ? -p : 2 * (len - 1) - p;
+    return p;
+}
+typedef unsigned short mx_us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t mx_pk_sub_sat_u16(uint32_t a, uint32_t b) {  // v_pk_sub_u16 clamp
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(mx_us2, a), __builtin_bit_cast(mx_us2, b)));
+}
+
+typedef int mx_v4i __attribute__((ext_vector_type(4)));
+typedef int mx_v16i __attribute__((ext_vector_type(16)));
+
+template <int TW_, int TH_, int NWX_, int N0, int N1, int N2, int N3, int N4, int N5>
+struct MxCfg {
+    static constexpr int TW = TW_, TH = TH_, NWX = NWX_;
+    static constexpr int SW = TW / NWX;   // columns of a wave's strip
+    static constexpr int NWY = TH / 32;
+    static constexpr int NW = NWX * NWY, NT = 64 * NW;
+    static constexpr int NOB = SW / 32;   // output blocks per strip
+    static constexpr int n(int l) { return l == 0 ? N0 : l == 1 ? N1 : l == 2 ? N2 : l == 3 ? N3 : l == 4 ? N4 : N5; }
+    static constexpr int r(int l) { return n(l) / 2; }
+    static constexpr int off(int l) { return (r(l) + 15) / 16 * 16; }   // the K window starts `off` before the output block
+    static constexpr int ns(int l) { return 1 + off(l) / 16; }          // K steps of 32: window [-off, -off + 32 ns) covers [-r, 32 + r)
+    static constexpr int cmax(int a, int b) { return a > b ? a : b; }
+    static constexpr int R = cmax(cmax(cmax(off(0), off(1)), cmax(off(2), off(3))), cmax(off(4), off(5)));  // staged halo
+    static constexpr int NSMAX = 1 + R / 16;
+    static constexpr int RQ = (TH + 2 * R) / 4;   // row quads of the staged tile
+    static constexpr int RW = TW + 2 * R;         // its width = dwords per row quad
+    static constexpr int RWP = RW + 4;
+    // per-wave output buffers: a level's G and D rows of the strip, SW bytes + 16 per row (row pitch = 4 mod 32 dwords:
+    // the 16-byte writes of 8 consecutive rows and the 16-byte reads along a row are conflict-free)
+    static constexpr int OBP = SW / 4 + 4;            // dwords per buffered row
+    static constexpr int OBUF = 32 * OBP;             // dwords per plane buffer
+    static constexpr int STAGE_DWORDS = RQ * RWP;
+    static constexpr int LDS_BYTES = (STAGE_DWORDS + NW * 2 * OBUF) * 4;
+    static_assert(TW % (32 * NWX) == 0 && TH % 32 == 0 && NT <= 1024 && NT % 256 == 0, "strips of 32-row x 32-column blocks, four waves per SIMD round");
+    static_assert(SW == 128, "the output flush maps a wave's 64 lanes to 8 rows x 128 bytes");
+    static_assert(r(0) >= 1 && (N0 & 1) && (N1 & 1) && (N2 & 1) && (N3 & 1) && (N4 & 1) && (N5 & 1), "odd kernels");
+    static_assert(((R / 4 + 16 + 3) * RWP + RW) * 4 < 65536, "LDS read offsets are 16-bit immediates");
+};
+
+// Operand fragments in lane order, one 16-byte fragment per K step: see mx_pack_taps.
+template <class CFG>
+struct MxTaps {
+    mx_v4i b1[6][CFG::NSMAX][64];
+    mx_v4i a2[6][CFG::NSMAX][64];
+};
+
+// Stages the TW x TH tile with halo R, byte-transposed (a dword = 4 vertically adjacent pixels of one column),
+// BORDER_REFLECT_101 resolved at fill time, every byte ^ bias (0x80: pixels - 128 as signed bytes).
+template <int TW, int TH, int R, int RWP, int NT>
+__device__ __forceinline__ void mx_stage_tile(const uint8_t* __restrict__ src, int rows, int cols, int pitch, int tile_x0, int tile_y0,
+                                              uint32_t* __restrict__ rp, uint32_t bias) {
+    constexpr int RW = TW + 2 * R, RQ = (TH + 2 * R) / 4;
+    const int tid = threadIdx.x;
+    const bool interior = tile_x0 - R >= 0 && tile_x0 + TW + R <= cols && tile_y0 - R >= 0 && tile_y0 + TH + R <= rows;
+    if (interior) {
+        for (int it = tid; it < RQ * (RW / 16); it += NT) {
+            const int yq = it / (RW / 16), xs = it - yq * (RW / 16);
+            const uint8_t* p = src + (size_t)(tile_y0 - R + 4 * yq) * pitch + (tile_x0 - R + 16 * xs);
+            uint4 a[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a[k] = *reinterpret_cast<const uint4*>(p + (size_t)k * pitch);
+            const uint32_t* aw[4] = {&a[0].x, &a[1].x, &a[2].x, &a[3].x};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t r0 = aw[0][q], r1 = aw[1][q], r2 = aw[2][q], r3 = aw[3][q];
+                const uint32_t p01l = __builtin_amdgcn_perm(r1, r0, 0x05010400), p01h = __builtin_amdgcn_perm(r1, r0, 0x07030602);
+                const uint32_t p23l = __builtin_amdgcn_perm(r3, r2, 0x05010400), p23h = __builtin_amdgcn_perm(r3, r2, 0x07030602);
+                uint4 t;
+                t.x = __builtin_amdgcn_perm(p23l, p01l, 0x05040100) ^ bias;
+                t.y = __builtin_amdgcn_perm(p23l, p01l, 0x07060302) ^ bias;
+                t.z = __builtin_amdgcn_perm(p23h, p01h, 0x05040100) ^ bias;
+                t.w = __builtin_amdgcn_perm(p23h, p01h, 0x07060302) ^ bias;
+                *reinterpret_cast<uint4*>(rp + yq * RWP + 16 * xs + 4 * q) = t;
+            }
+        }
+    } else {
+        for (int it = tid; it < RQ * (RW / 4); it += NT) {
+            const int yq = it / (RW / 4), xq = it - yq * (RW / 4);
+            const int gy = tile_y0 - R + 4 * yq, gx = tile_x0 - R + 4 * xq;
+            const int x0 = mx_reflect101(gx, cols), x1 = mx_reflect101(gx + 1, cols), x2 = mx_reflect101(gx + 2, cols), x3 = mx_reflect101(gx + 3, cols);
+            uint32_t a[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint8_t* row = src + (size_t)mx_reflect101(gy + k, rows) * pitch;
+                a[k] = (uint32_t)row[x0] | ((uint32_t)row[x1] << 8) | ((uint32_t)row[x2] << 16) | ((uint32_t)row[x3] << 24);
+            }
+            const uint32_t p01l = __builtin_amdgcn_perm(a[1], a[0], 0x05010400), p01h = __builtin_amdgcn_perm(a[1], a[0], 0x07030602);
+            const uint32_t p23l = __builtin_amdgcn_perm(a[3], a[2], 0x05010400), p23h = __builtin_amdgcn_perm(a[3], a[2], 0x07030602);
+            uint4 t;
+            t.x = __builtin_amdgcn_perm(p23l, p01l, 0x05040100) ^ bias;
+            t.y = __builtin_amdgcn_perm(p23l, p01l, 0x07060302) ^ bias;
+            t.z = __builtin_amdgcn_perm(p23h, p01h, 0x05040100) ^ bias;
+            t.w = __builtin_amdgcn_perm(p23h, p01h, 0x07060302) ^ bias;
+            *reinterpret_cast<uint4*>(rp + yq * RWP + 4 * xq) = t;
+        }
+    }
+}
+
+// What one lane carries through the six levels.
+template <class CFG>
+struct MxLane {
+    const uint32_t* lp;    // LDS: top-left of the staged halo as seen by this lane (its column, its K half)
+    uint8_t* out;          // the frame's octave block
+    size_t P;              // bytes per plane
+    int nob_live;          // output blocks of the strip that start inside the image (wave-uniform)
+    // output flush: results leave the MFMA with the image ROW on the lane (16 bytes of 32 different rows per store
+    // instruction: measured 2.2 TB/s of a kernel whose arithmetic takes a third of that time).  Each wave therefore
+    // passes a level's G and D strips through its own LDS buffer and stores them with the lanes ALONG the rows:
+    // 8 rows x 128 contiguous bytes per instruction.
+    uint32_t* wb;          // LDS: this lane's write position (its row, 16 h bytes in) of the G buffer; D is OBUF dwords on
+    const uint32_t* rb;    // LDS: this lane's read position: row lane >> 3, bytes 16 (lane & 7)
+    uint32_t off;          // byte offset inside a plane of (strip row lane >> 3, strip column 16 (lane & 7))
+    uint32_t pitch8;       // 8 * pitch
+    int rows_left;         // rows - that row: read i of this lane (strip row 8 i + (lane >> 3)) stores iff 8 i < rows_left
+    bool col_ok;           // that column is inside the image
+    uint8_t* nb;           // next octave's base row of this lane (nullptr: none, odd row, or outside)
+    int ncols_left;        // next base: ncols - (strip origin + 16 h) / 2
+    int dbg;               // EXPERIMENT (0 = product behaviour): 1 no G / D stores, 2 stores at lane-contiguous fake addresses
+};
+
+// One Gaussian level of a wave's strip.
+template <class CFG, int L>
+__device__ __forceinline__ void mx_level(const MxTaps<CFG>* __restrict__ taps, const MxLane<CFG>& ln, uint32_t (&pe)[CFG::NOB][4],
+                                         uint32_t (&po)[CFG::NOB][4]) {
+    constexpr int OFF = CFG::off(L), NS = CFG::ns(L), NOB = CFG::NOB, NIN = NOB + NS - 1, R = CFG::R, RWP = CFG::RWP;
+    // G = ((C2hi << 8) + C2lo) >> 16 with C2lo starting at 256 * (128 + 32768) + 32768: the biases of the two byte planes
+    // (taps sum to 256) + the one round-half-up of A2-iv
+    constexpr int kLoInit = 256 * (128 + 32768) + 32768;
+    const int lane = threadIdx.x & 63;
+    mx_v4i b1[NS], a2[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) b1[s] = taps->b1[L][s][lane], a2[s] = taps->a2[L][s][lane];
+    mx_v4i hi[NS], lo[NS];
+#pragma unroll
+    for (int ib = 0; ib < NIN; ++ib) {
+        // ---- pass 1 on input block ib: columns [-OFF + 32 ib, +32) of the strip, rows [-OFF, -OFF + 32 NS) ----
+        mx_v16i c1 = {};
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            mx_v4i a;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a[k] = (int)ln.lp[((R - OFF + 32 * s) / 4 + k) * RWP + (R - OFF + 32 * ib)];
+            c1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b1[s], c1, 0, 0, 0);
+        }
+        // C1 = H - 32768 in [-32768, 32512]: signed high byte as it is, low byte - 128 (x ^ 0x80)
+        const int slot = ib % NS;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const uint32_t t01 = __builtin_amdgcn_perm((uint32_t)c1[4 * d + 1], (uint32_t)c1[4 * d + 0], 0x05010400);  // (lo0, lo1, hi0, hi1)
+            const uint32_t t23 = __builtin_amdgcn_perm((uint32_t)c1[4 * d + 3], (uint32_t)c1[4 * d + 2], 0x05010400);
+            lo[slot][d] = (int)(__builtin_amdgcn_perm(t23, t01, 0x05040100) ^ 0x80808080u);
+            hi[slot][d] = (int)__builtin_amdgcn_perm(t23, t01, 0x07060302);
+        }
+        if (ib < NS - 1) continue;
+        const int ob = ib - (NS - 1);
+        if (ob >= ln.nob_live) continue;  // wave-uniform: the block lies right of the image
+        // ---- pass 2 on output block ob ------------------------------------------------------------------------
+        mx_v16i chi = {}, clo;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) clo[v] = kLoInit;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            chi = __builtin_amdgcn_mfma_i32_32x32x32_i8(a2[s], hi[(ob + s) % NS], chi, 0, 0, 0);
+            clo = __builtin_amdgcn_mfma_i32_32x32x32_i8(a2[s], lo[(ob + s) % NS], clo, 0, 0, 0);
+        }
+        // ---- epilogue: register v = column 16 h + v of this lane's row --------------------------------------------
+        uint32_t g[4], d[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            uint32_t w[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[j] = ((uint32_t)chi[4 * k + j] << 8) + (uint32_t)clo[4 * k + j];
+            const uint32_t e = __builtin_amdgcn_perm(w[2], w[0], 0x0c060c02);  // (G0, G2) in 16-bit lanes
+            const uint32_t o = __builtin_amdgcn_perm(w[3], w[1], 0x0c060c02);  // (G1, G3)
+            g[k] = __builtin_amdgcn_perm(o, e, 0x06020400);
+            if (L > 0)  // D_{L-1} = saturate_u8(G_L - G_{L-1}), GaussPyramid.cpp:197
+                d[k] = __builtin_amdgcn_perm(mx_pk_sub_sat_u16(o, po[ob][k]), mx_pk_sub_sat_u16(e, pe[ob][k]), 0x06020400);
+            pe[ob][k] = e;
+            po[ob][k] = o;
+        }
+        *reinterpret_cast<uint4*>(ln.wb + 8 * ob) = make_uint4(g[0], g[1], g[2], g[3]);
+        if (L > 0) *reinterpret_cast<uint4*>(ln.wb + CFG::OBUF + 8 * ob) = make_uint4(d[0], d[1], d[2], d[3]);
+        // next octave's base = Gaussian[3] decimated 2:1, INTER_NEAREST (GaussPyramid.cpp:123-126): the even
+        // columns of the even rows; 16 ob < ncols_left keeps the 8-byte store inside the row (pitch: multiple of 16)
+        if (L == 3 && ln.nb && 16 * ob < ln.ncols_left)
+            *reinterpret_cast<uint2*>(ln.nb + 16 * ob) =
+                make_uint2(__builtin_amdgcn_perm(pe[ob][1], pe[ob][0], 0x06040200), __builtin_amdgcn_perm(pe[ob][3], pe[ob][2], 0x06040200));
+    }
+    // ---- flush: the strip's G (and D) rows from the wave's own LDS buffer, lanes along the rows ------------------
+    // (one wave's LDS operations execute in order: no barrier between its writes above and these reads, nor before
+    // the next level's writes)
+    if (ln.dbg == 1) return;  // EXPERIMENT: no stores
+    uint8_t* gp = ln.out + (size_t)L * ln.P;
+    uint8_t* dp = ln.out + (size_t)(VSLAM_NUM_LEVELS + L - 1) * ln.P;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint4 gv = *reinterpret_cast<const uint4*>(ln.rb + 8 * i * CFG::OBP);
+        uint4 dv;
+        if (L > 0) dv = *reinterpret_cast<const uint4*>(ln.rb + CFG::OBUF + 8 * i * CFG::OBP);
+        if (ln.col_ok && 8 * i < ln.rows_left) {
+            *reinterpret_cast<uint4*>(gp + ln.off + i * ln.pitch8) = gv;
+            if (L > 0) *reinterpret_cast<uint4*>(dp + ln.off + i * ln.pitch8) = dv;
+        }
+    }
+}
+
+// grid = (ceil(cols/TW), ceil(rows/TH), frames); block = CFG::NT; dynamic LDS = CFG::LDS_BYTES.
+// rows / cols arbitrary; `pitch` and `npitch` multiples of 16 (16-byte row stores), planes 16-byte aligned.
+template <class CFG>
+__global__ __launch_bounds__(CFG::NT) void k_pyr_octave_mx(const uint8_t* __restrict__ base, size_t bframe, uint8_t* __restrict__ oct_out,
+                                                           size_t pframe, int rows, int cols, int pitch,
+                                                           const MxTaps<CFG>* __restrict__ taps, uint8_t* __restrict__ next_base,
+                                                           size_t nframe, int nrows, int ncols, int npitch, int dbg) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    // XCD-aware tile order, as k_pyr_octave: every XCD walks one contiguous run of tiles (neighbours share halo lines in its L2)
+    unsigned int bid = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const unsigned int per_xcd = (gridDim.x * gridDim.y * gridDim.z) >> 3;
+    if (bid < (per_xcd << 3)) bid = (bid & 7u) * per_xcd + (bid >> 3);
+    const unsigned int tiles_per_frame = gridDim.x * gridDim.y;
+    const unsigned int fz = bid / tiles_per_frame, rem = bid - fz * tiles_per_frame;
+    const unsigned int by = rem / gridDim.x, bx = rem - by * gridDim.x;
+    const int tile_x0 = bx * CFG::TW, tile_y0 = by * CFG::TH;
+
+    mx_stage_tile<CFG::TW, CFG::TH, CFG::R, CFG::RWP, CFG::NT>(base + fz * bframe, rows, cols, pitch, tile_x0, tile_y0, smem, 0x80808080u);
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = lane & 31, h = lane >> 5;
+    const int Yw = 32 * (wave / CFG::NWX), Xw = CFG::SW * (wave % CFG::NWX);
+    if (tile_y0 + Yw >= rows || tile_x0 + Xw >= cols) return;  // the whole strip is outside (no barrier follows)
+    MxLane<CFG> ln;
+    ln.lp = smem + (Yw / 4 + 4 * h) * CFG::RWP + Xw + m;
+    ln.out = oct_out + fz * pframe;
+    ln.P = (size_t)rows * pitch;
+    const int y = tile_y0 + Yw + m, x = tile_x0 + Xw + 16 * h;
+    uint32_t* obuf = smem + CFG::STAGE_DWORDS + wave * 2 * CFG::OBUF;
+    ln.wb = obuf + m * CFG::OBP + 4 * h;
+    ln.rb = obuf + (lane >> 3) * CFG::OBP + 4 * (lane & 7);
+    const int yr = tile_y0 + Yw + (lane >> 3), xr = tile_x0 + Xw + 16 * (lane & 7);
+    ln.off = (uint32_t)yr * (uint32_t)pitch + (uint32_t)xr;
+    ln.pitch8 = 8u * (uint32_t)pitch;
+    ln.rows_left = rows - yr;
+    ln.col_ok = xr < cols;
+    ln.nob_live = min(CFG::NOB, (cols - (tile_x0 + Xw) + 31) / 32);
+    ln.nb = (next_base && (m & 1) == 0 && (y >> 1) < nrows) ? next_base + fz * nframe + (size_t)(y >> 1) * npitch + (x >> 1) : nullptr;
+    ln.ncols_left = ncols - (x >> 1);
+    ln.dbg = dbg;
+    uint32_t pe[CFG::NOB][4], po[CFG::NOB][4];
+    mx_level<CFG, 0>(taps, ln, pe, po);
+    mx_level<CFG, 1>(taps, ln, pe, po);
+    mx_level<CFG, 2>(taps, ln, pe, po);
+    mx_level<CFG, 3>(taps, ln, pe, po);
+    mx_level<CFG, 4>(taps, ln, pe, po);
+    mx_level<CFG, 5>(taps, ln, pe, po);
+}
+
+// Host side: the quantised taps as MFMA operand fragments.
+//   b1[l][s][lane] byte j: pass-1 B[k][y'] with y' = lane & 31 the output row and k = 16 (lane >> 5) + j the input row
+//                          -off + 32 s + k relative to the output block: tap index (input - output + r).
+//   a2[l][s][lane] byte j: pass-2 A[m][k]: row m = lane & 31 is output column 16 ((m >> 2) & 1) + (m & 3) + 4 (m >> 3) (so that
+//                          C register v of lane half h is column 16 h + v), k = 16 (lane >> 5) + j is the input column
+//                          -off + 32 s + rho(lane >> 5, j), rho(h, j) = (j & 3) + 8 (j >> 2) + 4 h: the row of C1 register j.
+template <class CFG>
+static bool mx_pack_taps(const uint16_t* const t[6], MxTaps<CFG>& out) {
+    std::memset(&out, 0, sizeof(out));
+    for (int l = 0; l < 6; ++l) {
+        const int n = CFG::n(l), r = n / 2, off = CFG::off(l);
+        auto tap = [&](int idx) -> int { return idx >= 0 && idx < n ? (int)t[l][idx] : 0; };
+        for (int k = 0; k < n; ++k)
+            if (t[l][k] > 127) return false;  // signed 8-bit operands
+        for (int s = 0; s < CFG::ns(l); ++s)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int m = lane & 31, h = lane >> 5;
+                int8_t b[16], a[16];
+                const int xout = 16 * ((m >> 2) & 1) + (m & 3) + 4 * (m >> 3);
+                for (int j = 0; j < 16; ++j) {
+                    b[j] = (int8_t)tap((-off + 32 * s + 16 * h + j) - m + r);
+                    a[j] = (int8_t)tap((-off + 32 * s + (j & 3) + 8 * (j >> 2) + 4 * h) - xout + r);
+                }
+                std::memcpy(&out.b1[l][s][lane], b, 16);
+                std::memcpy(&out.a2[l][s][lane], a, 16);
+            }
+    }
+    return true;
+}
+
+// The reference's fixed pyramid (sigma0 = 1.6): zero-trimmed widths as PyrCfgOct0 / PyrCfgOct1.
+using MxCfgOct0 = MxCfg<128, 128, 1, 9, 13, 15, 19, 23, 29>;
+using MxCfgOct1 = MxCfg<128, 128, 1, 19, 23, 29, 37, 45, 57>;
+
+}  // namespace vslam

@@ -26,6 +26,7 @@
 #include "kernels_sift.hip.h"
 #include "kernels_extrema_dense.hip.h"
 #include "vslam_internal.h"
+#include "vslam_mx.h"
 
 using namespace vslam;
 
@@ -56,6 +57,9 @@ struct vslam_ctx {
     std::map<std::pair<int, uint64_t>, uint16_t*> taps;  // device copies of quantised taps
     std::map<std::pair<uint64_t, int>, StripTaps*> strip_taps;  // (sigma0 bits, octave) -> device tables
     std::map<std::pair<uint64_t, int>, void*> tile_taps;        // (sigma0 bits, octave) -> PyrTaps<CFG>
+    // OPT-IN matrix-core form of the LDS-tiled octave kernels (VSLAM_MX=1 / vslam_ctx_set_matrix_path): never the default
+    bool mx = false;
+    std::map<std::pair<uint64_t, int>, void*> mx_taps;          // (sigma0 bits, octave) -> MxTaps<CFG>
     // auxiliary streams of the batched path: the HBM-bound chains (Harris; extrema + compaction)
     // run beside the VALU-bound pyramid kernels; forked from / joined to `stream` by events
     // aux[2] carries only the second-half upsample of a large batch (enqueue_dog): it must not queue behind
@@ -117,7 +121,7 @@ static int fail(vslam_ctx* c, int code, const std::string& msg) {
 
 static const char* const kKernelNames =
     "k_resize_linear2x\nk_blur_h_generic\nk_blur_v_generic\n"
-    "k_dog5\nk_resize_nearest_half\nk_extrema\nk_pyr_octave\n"
+    "k_dog5\nk_resize_nearest_half\nk_extrema\nk_pyr_octave\nk_pyr_octave_mx\n"
     "k_gauss_v_strip\nk_gauss_h_strip\nk_gauss_band\nk_resize_linear2x_slide\nk_resize_nearest_half_v4\nk_extrema_w3\nk_extrema_dense\nk_localize_points\nk_orient_keypoints\nk_edge_response_windows\nk_level_gradients\nk_pack_rows\nk_edge_flags\nk_survivor_ranges\nk_orient_survivors\n"
     "k_harris_strip\nk_flag_count\nk_chunk_scan\nk_flag_scatter\nk_level_gradients\nk_sift_descriptors\nk_pack_offsets\nk_pack_copy\nk_count_totals";
 
@@ -706,6 +710,34 @@ static int enqueue_pyr_octave(vslam_ctx* c, double sigma0, int o, const OctPlan&
     return VSLAM_OK;
 }
 
+// The same octave through the matrix-core kernel (kernels_pyramid_mx.hip.h, vslam_mx.hip); `cfg` from mx_config_for.
+static int enqueue_pyr_octave_mx(vslam_ctx* c, int cfg, double sigma0, int o, const OctPlan& pl, const uint8_t* base, size_t bframe,
+                                 uint8_t* oct_out, size_t pframe, int rows, int cols, int pitch, int nf, uint8_t* next_base, size_t nframe,
+                                 int nrows, int ncols, int npitch) {
+    uint64_t sb;
+    std::memcpy(&sb, &sigma0, 8);
+    auto key = std::make_pair(sb, o);
+    auto it = c->mx_taps.find(key);
+    if (it == c->mx_taps.end()) {
+        const uint16_t* tp[6];
+        for (int l = 0; l < 6; ++l) tp[l] = pl.taps[l].data();
+        std::vector<char> host(mx_taps_bytes(cfg));
+        if (!mx_pack(cfg, tp, host.data())) return fail(c, VSLAM_ERR_UNSUPPORTED, "matrix-core octave kernel: a tap exceeds 127");
+        HIPCHK(c, mx_prepare(cfg));
+        void* d = nullptr;
+        HIPCHK(c, hipMalloc(&d, host.size()));
+        HIPCHK(c, hipMemcpy(d, host.data(), host.size(), hipMemcpyHostToDevice));
+        it = c->mx_taps.emplace(key, d).first;
+    }
+    hipError_t e;
+    {
+        TimedScope ts(c, "k_pyr_octave_mx");
+        e = mx_launch(cfg, c->stream, it->second, base, bframe, oct_out, pframe, rows, cols, pitch, nf, next_base, nframe, nrows, ncols, npitch);
+    }
+    HIPCHK(c, e);
+    return VSLAM_OK;
+}
+
 // The octave whose kernels the held-back side work of a batch waits for (enqueue_dog): the last
 // LDS-tiled one for batches of 32 frames or more, -1 (no gate) otherwise.
 // vslam_ctx_follow: the point of a batch call behind which a second context's batch may start (its heavy octave-0
@@ -816,6 +848,9 @@ static int enqueue_dog(vslam_ctx* c, const vslam_params& p, const vslam_batch_la
             const uint8_t* b = base + (size_t)f_lo * s.bases_frame;
             uint8_t* oc = oct + (size_t)f_lo * pframe;
             uint8_t* nbh = nb ? nb + (size_t)f_lo * s.bases_frame : nullptr;
+            if (c->mx)
+                if (const int cfg = mx_config_for(pl.ke))
+                    return enqueue_pyr_octave_mx(c, cfg, p.sigma0, o, pl, b, s.bases_frame, oc, pframe, rows, cols, pitch, n, nbh, s.bases_frame, nr, nc, np);
 #define VSLAM_TILED(CFG) enqueue_pyr_octave<CFG>(c, p.sigma0, o, pl, b, s.bases_frame, oc, pframe, rows, cols, pitch, n, nbh, s.bases_frame, nr, nc, np)
             if (pl.path == OctPath::Tile0) return shape == 1 ? VSLAM_TILED(PyrCfgOct0W) : VSLAM_TILED(PyrCfgOct0);
             return shape == 1 ? VSLAM_TILED(PyrCfgOct1W) : VSLAM_TILED(PyrCfgOct1);
@@ -989,9 +1024,21 @@ int vslam_ctx_create(int device, void* stream, vslam_ctx** out) {
         }
         c->own_stream = true;
     }
+    {
+        const char* e = std::getenv("VSLAM_MX");
+        c->mx = e && e[0] == '1';
+    }
     *out = c;
     return VSLAM_OK;
 }
+
+int vslam_ctx_set_matrix_path(vslam_ctx* c, int on) {
+    if (!c) return VSLAM_ERR_INVALID;
+    c->mx = on != 0;
+    return VSLAM_OK;
+}
+
+int vslam_ctx_get_matrix_path(const vslam_ctx* c) { return c && c->mx ? 1 : 0; }
 
 int vslam_ctx_destroy(vslam_ctx* c) {
     if (!c) return VSLAM_ERR_INVALID;
@@ -1002,6 +1049,7 @@ int vslam_ctx_destroy(vslam_ctx* c) {
     for (auto& kv : c->taps) (void)hipFree(kv.second);
     for (auto& kv : c->strip_taps) (void)hipFree(kv.second);
     for (auto& kv : c->tile_taps) (void)hipFree(kv.second);
+    for (auto& kv : c->mx_taps) (void)hipFree(kv.second);
     for (auto& ev : c->timing_ev) {
         (void)hipEventDestroy(ev.first);
         (void)hipEventDestroy(ev.second);
