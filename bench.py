@@ -34,6 +34,7 @@ def kernel_algorithmic_bytes(L, rows, cols):
         "k_harris_strip": 6 * N,                 # u8 frame in, f32 response + u8 NMS mask out (one pass)
         "k_resize_linear2x_slide": N,            # DoG path's read of the frame
         "k_pyr_octave": 11 * sum(P[:2]),         # 6 Gaussian + 5 DoG images of octaves 0-1 (LDS-tiled)
+        "k_pyr_octave_mx": 11 * sum(P[:4]),      # OPT-IN matrix path: the same images of octaves 0-3, one kernel family
         "k_gauss_band": 11 * sum(P[2:]),         # the same for the coarse octaves (fused band kernel)
         "k_gauss_h_strip": 11 * sum(P[2:]),      # ... or the two strip kernels, where a band does not fit the LDS
     }
@@ -98,7 +99,7 @@ def cpu_baseline(rows, cols, n_oct, sample_frames, gpu_keypoints=None):
     }
 
 
-def live_traffic(kname, rows, cols, octaves, frames=64):
+def live_traffic(kname, rows, cols, octaves, frames=64, matrix_path=0):
     """HBM bytes per frame of kernel `kname`, MEASURED for this run's build on this box: two child runs of this
     script under rocprofv3 (separate `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` passes, nothing else traced), a small
     batch of the same frames; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950 (it counts 64 B of every
@@ -118,8 +119,8 @@ def live_traffic(kname, rows, cols, octaves, frames=64):
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             with tempfile.TemporaryDirectory(dir="/tmp") as td:
                 cmd = [prof, "--pmc", counter, "--output-format", "csv", "-d", td, "-o", "r", "--", sys.executable, os.path.join(ROOT, "bench.py"),
-                       "--frames", str(frames), "--steps", "1", "--warmup", "1", "--cpu-sample", "0", "--modes", "0", "--cxx-host", "0", "--live-traffic", "0",
-                       "--rows", str(rows), "--cols", str(cols), "--octaves", str(octaves)]
+                       "--frames", str(frames), "--steps", "1", "--warmup", "1", "--cpu-sample", "0", "--modes", "0", "--cxx-host", "0", "--live-traffic", "0", "--mx", "0",
+                       "--matrix-path", str(int(matrix_path)), "--rows", str(rows), "--cols", str(cols), "--octaves", str(octaves)]
                 env = dict(os.environ, TMPDIR="/tmp")
                 for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
                     env.pop(k, None)
@@ -159,14 +160,16 @@ def cxx_host_runs(rows, cols, n, octaves, rank=0, world=1, local_rank=0):
             return {"error": "building the C++ host failed: " + (r.stdout + r.stderr)[-400:]}
     port = int(os.environ.get("MASTER_PORT", "29533")) + 7  # the rendezvous of the C++ ranks (MASTER_PORT itself is torch's store)
     env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(local_rank), MASTER_ADDR="127.0.0.1", VSLAM_RDV_PORT=str(port))
+    if world > 1:  # a scaling run must not hang on a secondary figure: 20 s to meet, 45 s per child, one mode
+        env.setdefault("VSLAM_RDV_TIMEOUT_MS", "20000")
     env.pop("VSLAM_COUNT_BACKEND", None)
     if os.environ.get("VSLAM_BENCH_SHARE_GPU") == "1":  # rehearsal on one GPU (tests/test_bench_ranks.py): RCCL refuses two ranks per device
         env["VSLAM_COUNT_BACKEND"] = "tcp"
     res = {}
     for mode in (("device", "hostfed") if world == 1 else ("device",)):
         try:
-            r = subprocess.run([exe, "--mode", mode, "--frames", str(n), "--batches", "30" if mode == "device" else "40", "--warmup", "6", "--rows", str(rows), "--cols", str(cols),
-                                "--octaves", str(octaves)], capture_output=True, text=True, timeout=600 if world == 1 else 180, env=env)
+            r = subprocess.run([exe, "--mode", mode, "--frames", str(n), "--batches", ("30" if mode == "device" else "40") if world == 1 else "12", "--warmup", "6", "--rows", str(rows), "--cols", str(cols),
+                                "--octaves", str(octaves)], capture_output=True, text=True, timeout=600 if world == 1 else 45, env=env)
             if r.returncode != 0:
                 res[mode] = {"error": (r.stdout + r.stderr)[-400:]}
             elif rank == 0:
@@ -197,6 +200,11 @@ def main():
     ap.add_argument("--live-traffic", type=int, default=1,
                     help="1: measure roofline.traffic in this run (two rocprofv3 --pmc child passes on a 64-frame batch, N = 1 only); 0: the committed profile's figure")
     ap.add_argument("--cxx-host", type=int, default=1, help="1: also run the C++ Stream executable on the same workload (one process per rank, after the measurement)")
+    ap.add_argument("--matrix-path", type=int, default=0,
+                    help="PROFILING ONLY: 1 runs the timed region itself on the opt-in matrix-core kernels (vslam_ctx_set_matrix_path); the line then says so "
+                         "in config.matrix_path and is not the headline.  The default run reports that path beside `value` as `mx_path`.")
+    ap.add_argument("--mx", type=int, default=1, help="1: also time the opt-in matrix-core path (the `mx_path` object; never `value`)")
+    ap.add_argument("--secondary-at-scale", type=int, default=0, help="1: run `modes` / `two_in_flight` / `mx_path` also at N > 1 (default: N = 1 only)")
     ap.add_argument("--stream", choices=["side", "null"], default="side",
                     help="stream of the whole job: a torch side stream (default) or torch's default (NULL) stream")
     args = ap.parse_args()
@@ -248,6 +256,16 @@ def main():
     job_stream = torch.cuda.Stream(device=dev) if args.stream == "side" else torch.cuda.default_stream(dev)
     torch.cuda.set_stream(job_stream)
     ctx = capi.Context(local_rank_dev, torch.cuda.current_stream().cuda_stream)
+    ctx.set_matrix_path(bool(args.matrix_path))  # the headline runs on the default (MFMA-free) kernels whatever VSLAM_MX says
+    wall = {}  # seconds per leg of this script (rank 0's clock)
+    t_leg = [time.perf_counter()]
+
+    def leg(name):
+        now = time.perf_counter()
+        wall[name] = wall.get(name, 0.0) + now - t_leg[0]
+        t_leg[0] = now
+
+    secondary = world == 1 or bool(args.secondary_at_scale)
     cdev = dev if backend == "nccl" else torch.device("cpu")  # where the collectives' tensors live
     # one camera stream per GPU: stream_id = rank
     frames = synth.frames_torch(n, rows, cols, stream_id=rank, device=dev)
@@ -341,20 +359,38 @@ def main():
         ctx.kernel_timing_enable(None)
         return launches, kms
 
-    kname = args.kernel or "k_pyr_octave"
+    kname = args.kernel or ("k_pyr_octave_mx" if args.matrix_path else "k_pyr_octave")
+    leg("setup")
     main = run_mode(args.localize, args.orient, args.steps, args.warmup, kname)
+    leg("value")
     p, L, dt, launches, kms = main["p"], main["L"], main["dt"], main["launches"], main["kms"]
     # keypoints of the first frames of this rank's batch, for the CPU baseline's count check
     cs = min(args.cpu_sample, n)
     gpu_kp_sample = None
     if cs > 0 and not (args.localize or args.orient) and args.octaves > 0:
         gpu_kp_sample = int(shared["harris_counts"][:cs].sum().item() + shared["dog_counts"][:cs].sum().item())
-    alone = kernel_alone(kname, 3) if (args.modes and kname == "k_pyr_octave" and args.octaves >= 2) else None
+    alone = kernel_alone(kname, 3) if (args.modes and kname in ("k_pyr_octave", "k_pyr_octave_mx") and args.octaves >= 2) else None
+    leg("alone")
+    # OPT-IN matrix-core path: the same steps with vslam_ctx_set_matrix_path(1) - octaves 0..3 as
+    # chained i8 MFMA band products instead of packed dots.  The north star rules MFMA out of this path, so this is
+    # reported BESIDE the headline, never as `value` / `roofline`.
+    mxp = None
+    if args.mx and secondary and not args.matrix_path and args.octaves >= 1 and not (args.localize or args.orient):
+        try:
+            ctx.set_matrix_path(True)
+            mm = run_mode(0, 0, args.steps, 2, "k_pyr_octave_mx")
+            ma = kernel_alone("k_pyr_octave_mx", 3) if args.octaves >= 2 else None
+            ctx.set_matrix_path(False)
+            mxp = {"dt": mm["dt"], "launches": mm["launches"], "kms": mm["kms"], "harris": mm["harris"], "dog": mm["dog"], "alone": ma}
+        except Exception as e:
+            ctx.set_matrix_path(False)
+            mxp = {"error": str(e)[:200]}
+    leg("mx_path")
     # the list modes the reference's own functions produce (initialKeypointDetection appends the
     # FeaturePointLocalization survivors, Diff_of_Gauss.cpp:290; filterKeypoints the oriented points,
     # :787), measured in the same process on the same frames with fewer steps
     modes = None
-    if args.modes and args.octaves > 0 and not (args.localize or args.orient):
+    if args.modes and secondary and args.octaves > 0 and not (args.localize or args.orient):
         # on the checkerboard batch the orientation stage sees ~36 points per frame, so the list
         # modes were timed on near-empty work.  They run on a batch whose every second frame is the uniform-
         # noise frame of SURVEY 8d (tens of thousands of oriented points each); `candidates` is the default
@@ -372,12 +408,13 @@ def main():
                            **({"what": "the whole DoG executable: pyramid, initialKeypointDetection, filterKeypoints, SIFT descriptors of every oriented point"} if de else {}),
                            **({"what": "extension: dense 3x3x3 scale-space test on every pixel of levels 1..3 (params.extrema_dense) instead of the reference's lattice test"} if dn else {})}
         del mixed
+    leg("modes")
 
     # Two batches in flight: a second context on a second stream with output buffers of its own, the
     # K steps alternating between the two.  Reported beside `value`, never as it: the pair's kernels run side by side, so a
     # per-launch roofline of such a run says little, and how much the pair gains depends on the hardware-queue layout.
     two = None
-    if args.modes and args.octaves > 0 and not (args.localize or args.orient) and n * rows * cols <= 256 * 1080 * 1920:
+    if args.modes and secondary and args.octaves > 0 and not (args.localize or args.orient) and n * rows * cols <= 256 * 1080 * 1920:
         try:
             s2 = torch.cuda.Stream()
             ctx2 = capi.Context(local_rank_dev, s2.cuda_stream)
@@ -408,6 +445,7 @@ def main():
             del out2
         except Exception as e:  # a secondary figure must never take the headline down
             two = {"error": str(e)[:200]}
+    leg("two_in_flight")
 
     if rank == 0:
         algo = kernel_algorithmic_bytes(L, rows, cols)
@@ -426,7 +464,8 @@ def main():
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             # (not inside a profiler run of this script itself: tools/refresh_profiles.sh wraps it in rocprofv3 with --modes 0)
             profiled = any("rocprof" in os.environ.get(k, "") for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD"))
-            lt = live_traffic(kname, rows, cols, args.octaves) if (args.live_traffic and args.modes and world == 1 and not profiled) else None
+            lt = live_traffic(kname, rows, cols, args.octaves, matrix_path=args.matrix_path) if (args.live_traffic and args.modes and world == 1 and not profiled) else None
+            leg("live_traffic")
             if lt:
                 traffic = lt["hbm_bytes_per_frame"] * n * args.steps / launches
                 tsrc = "measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child passes (separate), 2*FETCH_SIZE + WRITE_SIZE KiB"
@@ -443,7 +482,7 @@ def main():
             roof = {
                 "kernel": kname, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": tsrc, "traffic_profiled": tprof,
-                "limited_by": "valu-dot issue rate, see roofline_valu" if kname == "k_pyr_octave" else None,
+                "limited_by": "valu-dot issue rate, see roofline_valu" if kname == "k_pyr_octave" else ("hbm (write-dominated mix: DESIGN 5.6)" if kname == "k_pyr_octave_mx" else None),
                 "launches": launches, "avg_launch_ms": kms / launches,
                 "algorithmic_bytes_per_frame": algo.get(kname, 0),
                 "algorithmic_bytes_per_launch": algo.get(kname, 0) * n * args.steps / launches,
@@ -467,6 +506,31 @@ def main():
             ach = per_frame * n * args.steps / (kms * 1e-3)
             valu = {"bound": "valu-dot", "achieved": ach / 1e12, "peak": 32.8, "unit": "T lane-instr/s",
                     "frac": ach / 32.8e12, "algorithmic_dot_instr_per_frame": per_frame, "trimmed_widths": widths}
+        mx_obj = None
+        if mxp and "error" in mxp:
+            mx_obj = mxp
+        elif mxp:
+            a_bytes = algo["k_pyr_octave_mx"]
+            mx_obj = {
+                "what": "OPT-IN (VSLAM_MX=1 / vslam_ctx_set_matrix_path): octaves 0-3 as chained v_mfma_i32_32x32x32_i8 band products, bit-identical outputs; "
+                        "NOT `value`: BASELINE's north star rules MFMA out of this path (DESIGN section 5.5)",
+                "frames_per_sec": n * world * args.steps / mxp["dt"], "ms_per_step": mxp["dt"] / args.steps * 1e3, "steps": args.steps,
+                "speedup_vs_value": (n * world * args.steps / mxp["dt"]) / fps,
+                "same_keypoint_counts_as_value": bool(mxp["harris"] == main["harris"] and mxp["dog"] == main["dog"]),
+                "k_pyr_octave_mx": {
+                    "launches_per_step": mxp["launches"] / args.steps, "kernel_ms_per_step": mxp["kms"] / args.steps,
+                    "avg_launch_ms": mxp["kms"] / max(1, mxp["launches"]),
+                    "algorithmic_bytes_per_frame": a_bytes,
+                    "achieved": a_bytes * n * args.steps / (mxp["kms"] * 1e-3) / 1e9 if mxp["kms"] > 0 else None, "unit": "GB/s",
+                    "frac": a_bytes * n * args.steps / (mxp["kms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS if mxp["kms"] > 0 else None,
+                },
+                "pipeline_hbm_frac_of_peak": bytes_frame * (n * args.steps / mxp["dt"]) / 1e9 / HBM_PEAK_GBPS,
+            }
+            if mxp["alone"] and mxp["alone"][0] and mxp["alone"][1] > 0:
+                a_ms_step = mxp["alone"][1] / 3
+                mx_obj["k_pyr_octave_mx"]["alone"] = {"kernel_ms_per_step": a_ms_step, "achieved": a_bytes * n / (a_ms_step * 1e-3) / 1e9,
+                                                      "frac": a_bytes * n / (a_ms_step * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                                      "what": "pyramid-only batches, 3 steps"}
         line = {
             "metric": "frames/sec @1080p (Harris + DoG keypoint detection)",
             "value": fps,
@@ -484,6 +548,7 @@ def main():
                 "workload": f"batch of {n} synthetic {cols}x{rows} frames per GPU, Harris(k=0.04)+NMS and DoG pyramid "
                             f"{args.octaves} octaves x (6 Gaussian, 5 DoG) + extrema, fused (BASELINE config 4)",
                 "frames_per_gpu": n, "rows": rows, "cols": cols, "octaves": args.octaves, "localize": p.localize, "orient": args.orient,
+                "matrix_path": bool(args.matrix_path),
                 "parallelism": f"frames sharded 1 stream/GPU x{world}; RCCL all-gather of counts only",
             },
             "distributed": {"initialized": bool(use_dist), "world_size": dist.get_world_size() if use_dist else 1,
@@ -494,6 +559,7 @@ def main():
                                    **({"oriented": main["oriented"], "oriented_truncated": main["oriented_truncated"]} if args.orient else {})},
             "modes": modes,
             "two_in_flight": two,
+            "mx_path": mx_obj,
             "pipeline_hbm": {
                 "algorithmic_bytes_per_frame": bytes_frame,
                 "achieved_GBps": bytes_frame * fps / world / 1e9,
@@ -503,6 +569,7 @@ def main():
             "roofline_valu": valu,
             "cpu_baseline": cpu_baseline(rows, cols, args.octaves, cs, gpu_kp_sample) if (world == 1 and args.cpu_sample > 0) else None,
         }
+        leg("cpu_baseline")
     # The same workload driven by the C++ host (visualslam_amd/cxx: BatchDetector + Stream, RCCL from librccl,
     # no torch in that process): device-resident, and host-fed (pinned frames in, packed lists out).  Child
     # processes, after this process has released the GPU memory; N = 1 only; never part of `value`.
@@ -521,7 +588,9 @@ def main():
             dist.barrier()
         if rank == 0:
             line["cxx_host"] = cxx
+    leg("cxx_host")
     if rank == 0:
+        line["bench_wall_s"] = {k: round(v, 2) for k, v in wall.items()}
         print(json.dumps(line))
     if use_dist:
         dist.destroy_process_group()

@@ -54,9 +54,12 @@ __device__ __forceinline__ uint32_t mx_pk_sub_sat_u16(uint32_t a, uint32_t b) { 
 typedef int mx_v4i __attribute__((ext_vector_type(4)));
 typedef int mx_v16i __attribute__((ext_vector_type(16)));
 
-template <int TW_, int TH_, int NWX_, int N0, int N1, int N2, int N3, int N4, int N5>
+template <int TW_, int TH_, int NWX_, int DBUF_, int N0, int N1, int N2, int N3, int N4, int N5>
 struct MxCfg {
     static constexpr int TW = TW_, TH = TH_, NWX = NWX_;
+    // 1: separate LDS buffers for a level's G and D strips; 0: one buffer, D waits in registers and follows G through it
+    // (same box, octaves 0 + 1 of 256 x 1080p alone: 8.0 ms per step with two buffers, 9.35 ms with one - two where they fit)
+    static constexpr int DBUF = DBUF_;
     static constexpr int SW = TW / NWX;   // columns of a wave's strip
     static constexpr int NWY = TH / 32;
     static constexpr int NW = NWX * NWY, NT = 64 * NW;
@@ -71,16 +74,16 @@ struct MxCfg {
     static constexpr int RQ = (TH + 2 * R) / 4;   // row quads of the staged tile
     static constexpr int RW = TW + 2 * R;         // its width = dwords per row quad
     static constexpr int RWP = RW + 4;
-    // per-wave output buffers: a level's G and D rows of the strip, SW bytes + 16 per row (row pitch = 4 mod 32 dwords:
-    // the 16-byte writes of 8 consecutive rows and the 16-byte reads along a row are conflict-free)
+    // per-wave output buffer: a level's G rows of the strip, then its D rows; SW bytes + 16 per row (row pitch = 4 mod 32
+    // dwords: the 16-byte writes of 8 consecutive rows and the 16-byte reads along a row are conflict-free)
     static constexpr int OBP = SW / 4 + 4;            // dwords per buffered row
-    static constexpr int OBUF = 32 * OBP;             // dwords per plane buffer
+    static constexpr int OBUF = 32 * OBP;             // dwords per wave
     static constexpr int STAGE_DWORDS = RQ * RWP;
-    static constexpr int LDS_BYTES = (STAGE_DWORDS + NW * 2 * OBUF) * 4;
+    static constexpr int LDS_BYTES = (STAGE_DWORDS + NW * (1 + DBUF) * OBUF) * 4;
+    static_assert(LDS_BYTES <= 160 * 1024, "one workgroup's LDS");
     static_assert(TW % (32 * NWX) == 0 && TH % 32 == 0 && NT <= 1024 && NT % 256 == 0, "strips of 32-row x 32-column blocks, four waves per SIMD round");
     static_assert(SW == 128, "the output flush maps a wave's 64 lanes to 8 rows x 128 bytes");
     static_assert(r(0) >= 1 && (N0 & 1) && (N1 & 1) && (N2 & 1) && (N3 & 1) && (N4 & 1) && (N5 & 1), "odd kernels");
-    static_assert(((R / 4 + 16 + 3) * RWP + RW) * 4 < 65536, "LDS read offsets are 16-bit immediates");
 };
 
 // Operand fragments in lane order, one 16-byte fragment per K step: see mx_pack_taps.
@@ -120,15 +123,22 @@ __device__ __forceinline__ void mx_stage_tile(const uint8_t* __restrict__ src, i
             }
         }
     } else {
+        // border tiles: one dword column (4 pixels) x 4 rows per item; the rows are reflected per row, the columns per
+        // dword where the four pixels lie inside the image and per byte only where they straddle its edge
         for (int it = tid; it < RQ * (RW / 4); it += NT) {
             const int yq = it / (RW / 4), xq = it - yq * (RW / 4);
             const int gy = tile_y0 - R + 4 * yq, gx = tile_x0 - R + 4 * xq;
-            const int x0 = mx_reflect101(gx, cols), x1 = mx_reflect101(gx + 1, cols), x2 = mx_reflect101(gx + 2, cols), x3 = mx_reflect101(gx + 3, cols);
             uint32_t a[4];
+            if (gx >= 0 && gx + 3 < cols) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint8_t* row = src + (size_t)mx_reflect101(gy + k, rows) * pitch;
-                a[k] = (uint32_t)row[x0] | ((uint32_t)row[x1] << 8) | ((uint32_t)row[x2] << 16) | ((uint32_t)row[x3] << 24);
+                for (int k = 0; k < 4; ++k) a[k] = *reinterpret_cast<const uint32_t*>(src + (size_t)mx_reflect101(gy + k, rows) * pitch + gx);
+            } else {
+                const int x0 = mx_reflect101(gx, cols), x1 = mx_reflect101(gx + 1, cols), x2 = mx_reflect101(gx + 2, cols), x3 = mx_reflect101(gx + 3, cols);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint8_t* row = src + (size_t)mx_reflect101(gy + k, rows) * pitch;
+                    a[k] = (uint32_t)row[x0] | ((uint32_t)row[x1] << 8) | ((uint32_t)row[x2] << 16) | ((uint32_t)row[x3] << 24);
+                }
             }
             const uint32_t p01l = __builtin_amdgcn_perm(a[1], a[0], 0x05010400), p01h = __builtin_amdgcn_perm(a[1], a[0], 0x07030602);
             const uint32_t p23l = __builtin_amdgcn_perm(a[3], a[2], 0x05010400), p23h = __builtin_amdgcn_perm(a[3], a[2], 0x07030602);
@@ -153,7 +163,7 @@ struct MxLane {
     // instruction: measured 2.2 TB/s of a kernel whose arithmetic takes a third of that time).  Each wave therefore
     // passes a level's G and D strips through its own LDS buffer and stores them with the lanes ALONG the rows:
     // 8 rows x 128 contiguous bytes per instruction.
-    uint32_t* wb;          // LDS: this lane's write position (its row, 16 h bytes in) of the G buffer; D is OBUF dwords on
+    uint32_t* wb;          // LDS: this lane's write position (its row, 16 h bytes in) in the wave's output buffer
     const uint32_t* rb;    // LDS: this lane's read position: row lane >> 3, bytes 16 (lane & 7)
     uint32_t off;          // byte offset inside a plane of (strip row lane >> 3, strip column 16 (lane & 7))
     uint32_t pitch8;       // 8 * pitch
@@ -161,7 +171,6 @@ struct MxLane {
     bool col_ok;           // that column is inside the image
     uint8_t* nb;           // next octave's base row of this lane (nullptr: none, odd row, or outside)
     int ncols_left;        // next base: ncols - (strip origin + 16 h) / 2
-    int dbg;               // EXPERIMENT (0 = product behaviour): 1 no G / D stores, 2 stores at lane-contiguous fake addresses
 };
 
 // One Gaussian level of a wave's strip.
@@ -177,6 +186,7 @@ __device__ __forceinline__ void mx_level(const MxTaps<CFG>* __restrict__ taps, c
 #pragma unroll
     for (int s = 0; s < NS; ++s) b1[s] = taps->b1[L][s][lane], a2[s] = taps->a2[L][s][lane];
     mx_v4i hi[NS], lo[NS];
+    uint32_t dd[NOB][4] = {};  // the level's D values wait in registers while G passes through the wave's LDS buffer
 #pragma unroll
     for (int ib = 0; ib < NIN; ++ib) {
         // ---- pass 1 on input block ib: columns [-OFF + 32 ib, +32) of the strip, rows [-OFF, -OFF + 32 NS) ----
@@ -210,7 +220,7 @@ __device__ __forceinline__ void mx_level(const MxTaps<CFG>* __restrict__ taps, c
             clo = __builtin_amdgcn_mfma_i32_32x32x32_i8(a2[s], lo[(ob + s) % NS], clo, 0, 0, 0);
         }
         // ---- epilogue: register v = column 16 h + v of this lane's row --------------------------------------------
-        uint32_t g[4], d[4];
+        uint32_t g[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             uint32_t w[4];
@@ -220,32 +230,52 @@ __device__ __forceinline__ void mx_level(const MxTaps<CFG>* __restrict__ taps, c
             const uint32_t o = __builtin_amdgcn_perm(w[3], w[1], 0x0c060c02);  // (G1, G3)
             g[k] = __builtin_amdgcn_perm(o, e, 0x06020400);
             if (L > 0)  // D_{L-1} = saturate_u8(G_L - G_{L-1}), GaussPyramid.cpp:197
-                d[k] = __builtin_amdgcn_perm(mx_pk_sub_sat_u16(o, po[ob][k]), mx_pk_sub_sat_u16(e, pe[ob][k]), 0x06020400);
+                dd[ob][k] = __builtin_amdgcn_perm(mx_pk_sub_sat_u16(o, po[ob][k]), mx_pk_sub_sat_u16(e, pe[ob][k]), 0x06020400);
             pe[ob][k] = e;
             po[ob][k] = o;
         }
         *reinterpret_cast<uint4*>(ln.wb + 8 * ob) = make_uint4(g[0], g[1], g[2], g[3]);
-        if (L > 0) *reinterpret_cast<uint4*>(ln.wb + CFG::OBUF + 8 * ob) = make_uint4(d[0], d[1], d[2], d[3]);
+        if (CFG::DBUF && L > 0) *reinterpret_cast<uint4*>(ln.wb + CFG::OBUF + 8 * ob) = make_uint4(dd[ob][0], dd[ob][1], dd[ob][2], dd[ob][3]);
         // next octave's base = Gaussian[3] decimated 2:1, INTER_NEAREST (GaussPyramid.cpp:123-126): the even
         // columns of the even rows; 16 ob < ncols_left keeps the 8-byte store inside the row (pitch: multiple of 16)
         if (L == 3 && ln.nb && 16 * ob < ln.ncols_left)
             *reinterpret_cast<uint2*>(ln.nb + 16 * ob) =
                 make_uint2(__builtin_amdgcn_perm(pe[ob][1], pe[ob][0], 0x06040200), __builtin_amdgcn_perm(pe[ob][3], pe[ob][2], 0x06040200));
     }
-    // ---- flush: the strip's G (and D) rows from the wave's own LDS buffer, lanes along the rows ------------------
-    // (one wave's LDS operations execute in order: no barrier between its writes above and these reads, nor before
-    // the next level's writes)
-    if (ln.dbg == 1) return;  // EXPERIMENT: no stores
+    // ---- flush: the strip's G rows, then its D rows, from the wave's own LDS buffer with the lanes along the rows ---
+    // (one wave's LDS operations execute in order: no barrier between the writes above and these reads, nor between
+    // the G reads and the D writes that reuse the buffer, nor before the next level's writes)
     uint8_t* gp = ln.out + (size_t)L * ln.P;
-    uint8_t* dp = ln.out + (size_t)(VSLAM_NUM_LEVELS + L - 1) * ln.P;
+    if (CFG::DBUF) {
+        uint8_t* dp = ln.out + (size_t)(VSLAM_NUM_LEVELS + L - 1) * ln.P;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const uint4 gv = *reinterpret_cast<const uint4*>(ln.rb + 8 * i * CFG::OBP);
-        uint4 dv;
-        if (L > 0) dv = *reinterpret_cast<const uint4*>(ln.rb + CFG::OBUF + 8 * i * CFG::OBP);
-        if (ln.col_ok && 8 * i < ln.rows_left) {
-            *reinterpret_cast<uint4*>(gp + ln.off + i * ln.pitch8) = gv;
-            if (L > 0) *reinterpret_cast<uint4*>(dp + ln.off + i * ln.pitch8) = dv;
+        for (int i = 0; i < 4; ++i) {
+            const uint4 gv = *reinterpret_cast<const uint4*>(ln.rb + 8 * i * CFG::OBP);
+            uint4 dv;
+            if (L > 0) dv = *reinterpret_cast<const uint4*>(ln.rb + CFG::OBUF + 8 * i * CFG::OBP);
+            if (ln.col_ok && 8 * i < ln.rows_left) {
+                *reinterpret_cast<uint4*>(gp + ln.off + i * ln.pitch8) = gv;
+                if (L > 0) *reinterpret_cast<uint4*>(dp + ln.off + i * ln.pitch8) = dv;
+            }
+        }
+        return;
+    }
+    uint4 gv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gv[i] = *reinterpret_cast<const uint4*>(ln.rb + 8 * i * CFG::OBP);
+    if (L > 0) {
+#pragma unroll
+        for (int ob = 0; ob < NOB; ++ob) *reinterpret_cast<uint4*>(ln.wb + 8 * ob) = make_uint4(dd[ob][0], dd[ob][1], dd[ob][2], dd[ob][3]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (ln.col_ok && 8 * i < ln.rows_left) *reinterpret_cast<uint4*>(gp + ln.off + i * ln.pitch8) = gv[i];
+    if (L > 0) {
+        uint8_t* dp = ln.out + (size_t)(VSLAM_NUM_LEVELS + L - 1) * ln.P;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint4 dv = *reinterpret_cast<const uint4*>(ln.rb + 8 * i * CFG::OBP);
+            if (ln.col_ok && 8 * i < ln.rows_left) *reinterpret_cast<uint4*>(dp + ln.off + i * ln.pitch8) = dv;
         }
     }
 }
@@ -256,7 +286,7 @@ template <class CFG>
 __global__ __launch_bounds__(CFG::NT) void k_pyr_octave_mx(const uint8_t* __restrict__ base, size_t bframe, uint8_t* __restrict__ oct_out,
                                                            size_t pframe, int rows, int cols, int pitch,
                                                            const MxTaps<CFG>* __restrict__ taps, uint8_t* __restrict__ next_base,
-                                                           size_t nframe, int nrows, int ncols, int npitch, int dbg) {
+                                                           size_t nframe, int nrows, int ncols, int npitch) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     // XCD-aware tile order, as k_pyr_octave: every XCD walks one contiguous run of tiles (neighbours share halo lines in its L2)
     unsigned int bid = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
@@ -279,7 +309,7 @@ __global__ __launch_bounds__(CFG::NT) void k_pyr_octave_mx(const uint8_t* __rest
     ln.out = oct_out + fz * pframe;
     ln.P = (size_t)rows * pitch;
     const int y = tile_y0 + Yw + m, x = tile_x0 + Xw + 16 * h;
-    uint32_t* obuf = smem + CFG::STAGE_DWORDS + wave * 2 * CFG::OBUF;
+    uint32_t* obuf = smem + CFG::STAGE_DWORDS + wave * (1 + CFG::DBUF) * CFG::OBUF;
     ln.wb = obuf + m * CFG::OBP + 4 * h;
     ln.rb = obuf + (lane >> 3) * CFG::OBP + 4 * (lane & 7);
     const int yr = tile_y0 + Yw + (lane >> 3), xr = tile_x0 + Xw + 16 * (lane & 7);
@@ -290,7 +320,6 @@ __global__ __launch_bounds__(CFG::NT) void k_pyr_octave_mx(const uint8_t* __rest
     ln.nob_live = min(CFG::NOB, (cols - (tile_x0 + Xw) + 31) / 32);
     ln.nb = (next_base && (m & 1) == 0 && (y >> 1) < nrows) ? next_base + fz * nframe + (size_t)(y >> 1) * npitch + (x >> 1) : nullptr;
     ln.ncols_left = ncols - (x >> 1);
-    ln.dbg = dbg;
     uint32_t pe[CFG::NOB][4], po[CFG::NOB][4];
     mx_level<CFG, 0>(taps, ln, pe, po);
     mx_level<CFG, 1>(taps, ln, pe, po);
@@ -331,7 +360,11 @@ static bool mx_pack_taps(const uint16_t* const t[6], MxTaps<CFG>& out) {
 }
 
 // The reference's fixed pyramid (sigma0 = 1.6): zero-trimmed widths as PyrCfgOct0 / PyrCfgOct1.
-using MxCfgOct0 = MxCfg<128, 128, 1, 9, 13, 15, 19, 23, 29>;
-using MxCfgOct1 = MxCfg<128, 128, 1, 19, 23, 29, 37, 45, 57>;
+using MxCfgOct0 = MxCfg<128, 128, 1, 1, 9, 13, 15, 19, 23, 29>;
+using MxCfgOct1 = MxCfg<128, 128, 1, 1, 19, 23, 29, 37, 45, 57>;
+// octaves 2 and 3 (the default path runs them through the strip kernels and a u16 scratch in HBM): K windows of 3 - 5
+// resp. 4 - 8 steps per level; octave 3's staged tile (halo 112) fills most of a CU's LDS
+using MxCfgOct2 = MxCfg<128, 128, 1, 0, 37, 45, 57, 71, 89, 111>;
+using MxCfgOct3 = MxCfg<128, 128, 1, 0, 71, 89, 111, 141, 177, 223>;
 
 }  // namespace vslam

@@ -856,7 +856,8 @@ static int enqueue_dog(vslam_ctx* c, const vslam_params& p, const vslam_batch_la
             return shape == 1 ? VSLAM_TILED(PyrCfgOct1W) : VSLAM_TILED(PyrCfgOct1);
 #undef VSLAM_TILED
         };
-        const bool is_tiled = pl.path == OctPath::Tile0 || pl.path == OctPath::Tile1;
+        // opt-in matrix path: also the octaves the default path runs through the strip kernels (no u16 scratch round trip)
+        const bool is_tiled = pl.path == OctPath::Tile0 || pl.path == OctPath::Tile1 || (c->mx && pl.path != OctPath::Generic && mx_config_for(pl.ke) != 0);
         if (o == 0 && nf_a < nf && !is_tiled) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_up2, 0));  // octave 0 needs every base
         if (is_tiled && o == 0 && nf_a < nf) {
             TRY(tiled(0, nf_a));

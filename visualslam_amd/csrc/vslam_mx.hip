@@ -2,6 +2,7 @@
 // (kernels_pyramid_mx.hip.h says why).  Its own translation unit because of its compiler flag (Makefile).
 #include "vslam_mx.h"
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 
@@ -19,14 +20,20 @@ static bool widths_match(const int ke[6]) {
 int mx_config_for(const int ke[6]) {
     if (widths_match<MxCfgOct0>(ke)) return 1;
     if (widths_match<MxCfgOct1>(ke)) return 2;
+    if (widths_match<MxCfgOct2>(ke)) return 3;
+    if (widths_match<MxCfgOct3>(ke)) return 4;
     return 0;
 }
 
-size_t mx_taps_bytes(int cfg) { return cfg == 1 ? sizeof(MxTaps<MxCfgOct0>) : cfg == 2 ? sizeof(MxTaps<MxCfgOct1>) : 0; }
+size_t mx_taps_bytes(int cfg) {
+    return cfg == 1 ? sizeof(MxTaps<MxCfgOct0>) : cfg == 2 ? sizeof(MxTaps<MxCfgOct1>) : cfg == 3 ? sizeof(MxTaps<MxCfgOct2>) : cfg == 4 ? sizeof(MxTaps<MxCfgOct3>) : 0;
+}
 
 bool mx_pack(int cfg, const uint16_t* const taps[6], void* host_table) {
     if (cfg == 1) return mx_pack_taps<MxCfgOct0>(taps, *static_cast<MxTaps<MxCfgOct0>*>(host_table));
     if (cfg == 2) return mx_pack_taps<MxCfgOct1>(taps, *static_cast<MxTaps<MxCfgOct1>*>(host_table));
+    if (cfg == 3) return mx_pack_taps<MxCfgOct2>(taps, *static_cast<MxTaps<MxCfgOct2>*>(host_table));
+    if (cfg == 4) return mx_pack_taps<MxCfgOct3>(taps, *static_cast<MxTaps<MxCfgOct3>*>(host_table));
     return false;
 }
 
@@ -35,18 +42,17 @@ static hipError_t prepare() {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pyr_octave_mx<CFG>), hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES);
 }
 
-hipError_t mx_prepare(int cfg) { return cfg == 1 ? prepare<MxCfgOct0>() : cfg == 2 ? prepare<MxCfgOct1>() : hipErrorInvalidValue; }
+hipError_t mx_prepare(int cfg) {
+
+    return cfg == 1 ? prepare<MxCfgOct0>() : cfg == 2 ? prepare<MxCfgOct1>() : cfg == 3 ? prepare<MxCfgOct2>() : cfg == 4 ? prepare<MxCfgOct3>() : hipErrorInvalidValue;
+}
 
 template <class CFG>
 static hipError_t launch(hipStream_t stream, const void* d_table, const uint8_t* base, size_t bframe, uint8_t* oct_out, size_t pframe, int rows,
                          int cols, int pitch, int nf, uint8_t* next_base, size_t nframe, int nrows, int ncols, int npitch) {
     const dim3 grid((cols + CFG::TW - 1) / CFG::TW, (rows + CFG::TH - 1) / CFG::TH, nf);
-    static const int dbg = [] {
-        const char* e = std::getenv("VSLAM_MX_DBG");
-        return e ? std::atoi(e) : 0;
-    }();
     hipLaunchKernelGGL(k_pyr_octave_mx<CFG>, grid, dim3(CFG::NT), CFG::LDS_BYTES, stream, base, bframe, oct_out, pframe, rows, cols, pitch,
-                       static_cast<const MxTaps<CFG>*>(d_table), next_base, nframe, nrows, ncols, npitch, dbg);
+                       static_cast<const MxTaps<CFG>*>(d_table), next_base, nframe, nrows, ncols, npitch);
     return hipGetLastError();
 }
 
@@ -54,6 +60,8 @@ hipError_t mx_launch(int cfg, hipStream_t stream, const void* d_table, const uin
                      int rows, int cols, int pitch, int nf, uint8_t* next_base, size_t nframe, int nrows, int ncols, int npitch) {
     if (cfg == 1) return launch<MxCfgOct0>(stream, d_table, base, bframe, oct_out, pframe, rows, cols, pitch, nf, next_base, nframe, nrows, ncols, npitch);
     if (cfg == 2) return launch<MxCfgOct1>(stream, d_table, base, bframe, oct_out, pframe, rows, cols, pitch, nf, next_base, nframe, nrows, ncols, npitch);
+    if (cfg == 3) return launch<MxCfgOct2>(stream, d_table, base, bframe, oct_out, pframe, rows, cols, pitch, nf, next_base, nframe, nrows, ncols, npitch);
+    if (cfg == 4) return launch<MxCfgOct3>(stream, d_table, base, bframe, oct_out, pframe, rows, cols, pitch, nf, next_base, nframe, nrows, ncols, npitch);
     return hipErrorInvalidValue;
 }
 
