@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void k_resize_nearest_half_v4(const uint8_t* _
 // bytes, fetched per staged row by one ds_read2_b32 of the enclosing dword pair and one v_perm
 // with a per-site selector, landing as (a, b) in 16-bit lanes for packed min/max.  A wave's 64
 // candidate flags leave as one ballot word = the bitmask layout of include/vslam.h.
-// Row pitch a multiple of 16 (any width).  grid = (ceil(words_per_row/4), lat_rows, frames).
+// Row pitch a multiple of 16 (any width).  grid = (ceil(words_per_row/4), lattice rows to scan, frames).
 typedef unsigned short us2e_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) {
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(us2e_t, a), __builtin_bit_cast(us2e_t, b)));
@@ -119,12 +119,13 @@ constexpr int EXT_PITCH = EXT_SPAN + 16; // 16 guard bytes in front: column -1 o
 template <bool LOC>
 __global__ __launch_bounds__(256) void k_extrema_w3(const uint8_t* __restrict__ pyr, size_t pframe, ExtGeom g, int o,
                                                      unsigned long long* __restrict__ bits,
-                                                     unsigned long long* __restrict__ lflags, size_t bframe) {
+                                                     unsigned long long* __restrict__ lflags, size_t bframe, int li0, int li_step) {
     constexpr int NROW = LOC ? 13 : 10;
     __shared__ __attribute__((aligned(16))) uint8_t srow[NROW * EXT_PITCH + 16];  // [level 0..4][row 0..1], then [level 1..3] row 2
     __shared__ uint2 queue[LOC ? 768 : 1];       // per wave: the sites whose localization needs the full inverse
     __shared__ uint8_t qkeep[LOC ? 768 : 1];     // per wave: their verdicts, by (level-1)*64 + lane
-    const int li = blockIdx.y, f = blockIdx.z;
+    // lattice row li0 + blockIdx.y * li_step: (0, 1) = every row; the matrix path's fused scan leaves only every 32nd row here
+    const int li = li0 + (int)blockIdx.y * li_step, f = blockIdx.z;
     const int rows = g.rows[o], cols = g.cols[o], pitch = g.pitch[o];
     const uint32_t P = (uint32_t)rows * (uint32_t)pitch;  // 11 planes of an octave stay below 2^31 bytes
     const uint8_t* dog = pyr + f * pframe + g.oct_off[o] + (size_t)VSLAM_NUM_LEVELS * P;

@@ -79,7 +79,9 @@ struct MxCfg {
     static constexpr int OBP = SW / 4 + 4;            // dwords per buffered row
     static constexpr int OBUF = 32 * OBP;             // dwords per wave
     static constexpr int STAGE_DWORDS = RQ * RWP;
-    static constexpr int LDS_BYTES = (STAGE_DWORDS + NW * (1 + DBUF) * OBUF) * 4;
+    // (+ 8 rows of slack behind the last wave's buffers: the fused lattice scan reads up to 5 rows past a strip's D buffer
+    // for lattice rows it does not own, and drops what it read)
+    static constexpr int LDS_BYTES = (STAGE_DWORDS + NW * (1 + DBUF) * OBUF + 8 * OBP) * 4;
     static_assert(LDS_BYTES <= 160 * 1024, "one workgroup's LDS");
     static_assert(TW % (32 * NWX) == 0 && TH % 32 == 0 && NT <= 1024 && NT % 256 == 0, "strips of 32-row x 32-column blocks, four waves per SIMD round");
     static_assert(SW == 128, "the output flush maps a wave's 64 lanes to 8 rows x 128 bytes");
@@ -152,6 +154,108 @@ __device__ __forceinline__ void mx_stage_tile(const uint8_t* __restrict__ src, i
     }
 }
 
+
+// ---- fused lattice scan (initialKeypointDetection, Diff_of_Gauss.cpp:254-297, window 3) -------------------------------
+// The default path's k_extrema_w3 reads two thirds of the five DoG planes back from HBM (43 MB per 1080p frame).  Here a
+// wave evaluates the lattice sites of its own strip while the DoG rows are still in its LDS buffer: site (a, b) - padded
+// (i, j) = (1 + 3a, 1 + 3b) - looks at image rows {3a-1, 3a} x columns {3b-1, 3b} (clamped at 0: padOctave's replicate
+// border) of levels c-1, c, c+1 and is a candidate iff D_c(3a, 3b) equals the minimum or the maximum of the twelve.
+// A strip owns the sites whose four pixels lie inside it; sites whose window straddles a strip's first row or first
+// column (3a = 32 s, 3b = 128 t: one lattice row in 32, one lattice column in 128) are left to k_extrema_pack, which also
+// turns this kernel's per-site bytes into the bitmask / list-flag words of include/vslam.h.
+//   lane = lattice column b_first + lane (43 of a 128-column strip), 11 lattice rows per strip, two rows per register
+//   (16-bit lanes): per DoG level and row pair 8 LDS dwords, 4 v_perm, 4 packed min / max for the rows, then the 2 x 2
+//   minima / maxima / centre values of both rows by 7 more packed operations; three levels of them roll in registers.
+struct MxExtArgs {
+    uint8_t* sitemap;   // [frames][lat_rows][mpitch]: bit 2(c-1) = candidate at level c, bit 2(c-1)+1 = also value >= min_contrast
+    size_t mframe;
+    int lat_rows, lat_cols, mpitch, min_contrast;
+    // seams: the image columns X = 3 SW s (s = 1..nseams) where a lattice column's window (X-1, X) straddles two strips.
+    // The strips on either side leave those two DoG columns of every level here, [frames][5][nseams][rows][2] bytes, and
+    // k_extrema_pack evaluates the seam sites from them (from the planes it cost a 128-byte line per byte: 18 MB per frame).
+    uint8_t* colmap;
+    size_t cframe;
+    int nseams;
+};
+
+typedef unsigned short mx_us2b __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t mx_pk_min_u16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(mx_us2b, a), __builtin_bit_cast(mx_us2b, b)));
+}
+__device__ __forceinline__ uint32_t mx_pk_max_u16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(mx_us2b, a), __builtin_bit_cast(mx_us2b, b)));
+}
+__device__ __forceinline__ uint32_t mx_pk_sub_u16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(mx_us2b, a) - __builtin_bit_cast(mx_us2b, b));
+}
+
+constexpr int MX_SITE_PAIRS = 6;  // 11 lattice rows per 32-row strip, two per register
+
+struct MxSites {
+    const uint8_t* slr;   // LDS: this lane's dword of column 3b-1 in row r0 of the wave's D buffer (r0 = image row 3 a_first - 1, may be -1)
+    const uint8_t* sla0;  // ... in row max(r0, 0): the upper row of the strip's first lattice row
+    uint32_t sel;         // v_perm selector: (column 3b-1, 0, column 3b, 0) of a dword pair
+    int nk;               // lattice rows this strip owns (wave-uniform, <= 11)
+    uint8_t* smap;        // this lane's byte of lattice row a_first (nullptr: the lane has no site)
+    uint32_t mpitch;
+    uint8_t* cdump;       // seam strips, lanes 0..31 with a row inside the image: this row's byte of DoG level 0 in the seam map
+    const uint8_t* cl;    // ... and the byte it comes from: column 0 or SW-1 of this lane's row in the wave's D buffer
+    uint32_t clevel;      // bytes per level of the seam map
+    uint32_t mc2;         // min_contrast in both 16-bit lanes
+    uint32_t mn[3][MX_SITE_PAIRS], mx[3][MX_SITE_PAIRS], sf[3][MX_SITE_PAIRS], out[MX_SITE_PAIRS];
+};
+
+// DoG level l of the strip is in the wave's D buffer: the 2 x 2 minimum, maximum and the centre value of every owned site.
+template <class CFG, int l>
+__device__ __forceinline__ void mx_sites_level(MxSites& st) {
+    constexpr int slot = l % 3, RB = CFG::OBP * 4;  // bytes per buffered row
+#pragma unroll
+    for (int p = 0; p < MX_SITE_PAIRS; ++p) {
+        uint32_t lo[2], hi[2], v1[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int k = 2 * p + j;
+            const uint32_t* qa = reinterpret_cast<const uint32_t*>(k == 0 ? st.sla0 : st.slr + 3 * k * RB);
+            const uint32_t* qb = reinterpret_cast<const uint32_t*>(st.slr + (3 * k + 1) * RB);
+            const uint32_t v0 = __builtin_amdgcn_perm(qa[1], qa[0], st.sel);  // (D(3a-1, 3b-1), D(3a-1, 3b)) in 16-bit lanes
+            v1[j] = __builtin_amdgcn_perm(qb[1], qb[0], st.sel);             // (D(3a, 3b-1), D(3a, 3b))
+            lo[j] = mx_pk_min_u16(v0, v1[j]);
+            hi[j] = mx_pk_max_u16(v0, v1[j]);
+        }
+        // lattice rows 2p (low half) and 2p+1 (high half) side by side
+        st.mn[slot][p] = mx_pk_min_u16(__builtin_amdgcn_perm(lo[1], lo[0], 0x05040100), __builtin_amdgcn_perm(lo[1], lo[0], 0x07060302));
+        st.mx[slot][p] = mx_pk_max_u16(__builtin_amdgcn_perm(hi[1], hi[0], 0x05040100), __builtin_amdgcn_perm(hi[1], hi[0], 0x07060302));
+        st.sf[slot][p] = __builtin_amdgcn_perm(v1[1], v1[0], 0x07060302);
+    }
+}
+
+// Levels c-1, c, c+1 are known: candidate and list bits of centre level c (1..3) into bits 2(c-1), 2(c-1)+1.
+template <int c>
+__device__ __forceinline__ void mx_sites_test(MxSites& st) {
+    constexpr int a = (c - 1) % 3, b = c % 3, d = (c + 1) % 3;
+#pragma unroll
+    for (int p = 0; p < MX_SITE_PAIRS; ++p) {
+        const uint32_t lo3 = mx_pk_min_u16(mx_pk_min_u16(st.mn[a][p], st.mn[b][p]), st.mn[d][p]);
+        const uint32_t hi3 = mx_pk_max_u16(mx_pk_max_u16(st.mx[a][p], st.mx[b][p]), st.mx[d][p]);
+        const uint32_t self = st.sf[b][p];
+        const uint32_t z = mx_pk_min_u16(self ^ lo3, self ^ hi3);                            // a zero lane = candidate
+        const uint32_t cand = mx_pk_sub_u16(0x00010001u, mx_pk_min_u16(z, 0x00010001u));    // 1 / 0 per lane
+        const uint32_t below = mx_pk_min_u16(mx_pk_sub_sat_u16(st.mc2, self), 0x00010001u);  // 1 iff value < min_contrast
+        const uint32_t listed = cand & ~below;
+        const uint32_t bits = cand | (listed << 1);
+        st.out[p] = c == 1 ? bits : (st.out[p] | (bits << (2 * (c - 1))));
+    }
+}
+
+__device__ __forceinline__ void mx_sites_store(const MxSites& st) {
+    if (!st.smap) return;
+#pragma unroll
+    for (int p = 0; p < MX_SITE_PAIRS; ++p) {
+        if (2 * p < st.nk) st.smap[(size_t)(2 * p) * st.mpitch] = (uint8_t)st.out[p];
+        if (2 * p + 1 < st.nk) st.smap[(size_t)(2 * p + 1) * st.mpitch] = (uint8_t)(st.out[p] >> 16);
+    }
+}
+
 // What one lane carries through the six levels.
 template <class CFG>
 struct MxLane {
@@ -174,9 +278,9 @@ struct MxLane {
 };
 
 // One Gaussian level of a wave's strip.
-template <class CFG, int L>
+template <class CFG, int L, bool EXT>
 __device__ __forceinline__ void mx_level(const MxTaps<CFG>* __restrict__ taps, const MxLane<CFG>& ln, uint32_t (&pe)[CFG::NOB][4],
-                                         uint32_t (&po)[CFG::NOB][4]) {
+                                         uint32_t (&po)[CFG::NOB][4], MxSites& st) {
     constexpr int OFF = CFG::off(L), NS = CFG::ns(L), NOB = CFG::NOB, NIN = NOB + NS - 1, R = CFG::R, RWP = CFG::RWP;
     // G = ((C2hi << 8) + C2lo) >> 16 with C2lo starting at 256 * (128 + 32768) + 32768: the biases of the two byte planes
     // (taps sum to 256) + the one round-half-up of A2-iv
@@ -242,6 +346,15 @@ __device__ __forceinline__ void mx_level(const MxTaps<CFG>* __restrict__ taps, c
             *reinterpret_cast<uint2*>(ln.nb + 16 * ob) =
                 make_uint2(__builtin_amdgcn_perm(pe[ob][1], pe[ob][0], 0x06040200), __builtin_amdgcn_perm(pe[ob][3], pe[ob][2], 0x06040200));
     }
+    if constexpr (EXT && L > 0) {  // fused lattice scan: DoG level L-1 of the strip is in the wave's D buffer now
+        static_assert(CFG::DBUF != 0, "the fused scan reads the D buffer");
+        if (st.cdump) st.cdump[(size_t)(L - 1) * st.clevel] = *st.cl;
+        if (st.nk > 0) {  // wave-uniform
+            mx_sites_level<CFG, L - 1>(st);
+            if constexpr (L >= 3) mx_sites_test<L - 2>(st);
+            if constexpr (L == 5) mx_sites_store(st);
+        }
+    }
     // ---- flush: the strip's G rows, then its D rows, from the wave's own LDS buffer with the lanes along the rows ---
     // (one wave's LDS operations execute in order: no barrier between the writes above and these reads, nor between
     // the G reads and the D writes that reuse the buffer, nor before the next level's writes)
@@ -260,16 +373,19 @@ __device__ __forceinline__ void mx_level(const MxTaps<CFG>* __restrict__ taps, c
         }
         return;
     }
-    uint4 gv[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) gv[i] = *reinterpret_cast<const uint4*>(ln.rb + 8 * i * CFG::OBP);
+    // (four named values, not an array: the conditional stores made hipcc index an array of them dynamically - through scratch)
+    const uint4 g0 = *reinterpret_cast<const uint4*>(ln.rb), g1 = *reinterpret_cast<const uint4*>(ln.rb + 8 * CFG::OBP);
+    const uint4 g2 = *reinterpret_cast<const uint4*>(ln.rb + 16 * CFG::OBP), g3 = *reinterpret_cast<const uint4*>(ln.rb + 24 * CFG::OBP);
     if (L > 0) {
 #pragma unroll
         for (int ob = 0; ob < NOB; ++ob) *reinterpret_cast<uint4*>(ln.wb + 8 * ob) = make_uint4(dd[ob][0], dd[ob][1], dd[ob][2], dd[ob][3]);
     }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-        if (ln.col_ok && 8 * i < ln.rows_left) *reinterpret_cast<uint4*>(gp + ln.off + i * ln.pitch8) = gv[i];
+    if (ln.col_ok) {
+        if (0 < ln.rows_left) *reinterpret_cast<uint4*>(gp + ln.off) = g0;
+        if (8 < ln.rows_left) *reinterpret_cast<uint4*>(gp + ln.off + ln.pitch8) = g1;
+        if (16 < ln.rows_left) *reinterpret_cast<uint4*>(gp + ln.off + 2 * ln.pitch8) = g2;
+        if (24 < ln.rows_left) *reinterpret_cast<uint4*>(gp + ln.off + 3 * ln.pitch8) = g3;
+    }
     if (L > 0) {
         uint8_t* dp = ln.out + (size_t)(VSLAM_NUM_LEVELS + L - 1) * ln.P;
 #pragma unroll
@@ -282,11 +398,11 @@ __device__ __forceinline__ void mx_level(const MxTaps<CFG>* __restrict__ taps, c
 
 // grid = (ceil(cols/TW), ceil(rows/TH), frames); block = CFG::NT; dynamic LDS = CFG::LDS_BYTES.
 // rows / cols arbitrary; `pitch` and `npitch` multiples of 16 (16-byte row stores), planes 16-byte aligned.
-template <class CFG>
+template <class CFG, bool EXT>
 __global__ __launch_bounds__(CFG::NT) void k_pyr_octave_mx(const uint8_t* __restrict__ base, size_t bframe, uint8_t* __restrict__ oct_out,
                                                            size_t pframe, int rows, int cols, int pitch,
                                                            const MxTaps<CFG>* __restrict__ taps, uint8_t* __restrict__ next_base,
-                                                           size_t nframe, int nrows, int ncols, int npitch) {
+                                                           size_t nframe, int nrows, int ncols, int npitch, MxExtArgs ext) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     // XCD-aware tile order, as k_pyr_octave: every XCD walks one contiguous run of tiles (neighbours share halo lines in its L2)
     unsigned int bid = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
@@ -320,13 +436,132 @@ __global__ __launch_bounds__(CFG::NT) void k_pyr_octave_mx(const uint8_t* __rest
     ln.nob_live = min(CFG::NOB, (cols - (tile_x0 + Xw) + 31) / 32);
     ln.nb = (next_base && (m & 1) == 0 && (y >> 1) < nrows) ? next_base + fz * nframe + (size_t)(y >> 1) * npitch + (x >> 1) : nullptr;
     ln.ncols_left = ncols - (x >> 1);
+    MxSites st;
+    if (EXT) {
+        // lattice rows / columns whose 2 x 2 window lies inside this strip (all wave-uniform but the lane's column)
+        const int Y0 = tile_y0 + Yw, X0 = tile_x0 + Xw;
+        const int a_lo = (Y0 + 2) / 3, b_lo = (X0 + 2) / 3;
+        const int a_first = a_lo + ((Y0 > 0 && 3 * a_lo == Y0) ? 1 : 0);  // 3a = Y0: the window's upper row belongs to the strip above
+        const int b_first = b_lo + ((X0 > 0 && 3 * b_lo == X0) ? 1 : 0);
+        const int a_last = min((Y0 + 31) / 3, ext.lat_rows - 1);
+        st.nk = max(0, a_last - a_first + 1);
+        const int b = b_first + lane;
+        const bool has = 3 * b <= X0 + CFG::SW - 1 && b < ext.lat_cols;
+        const int xa = has ? max(3 * b - 1 - X0, 0) : 0;  // byte of column 3b-1 in a buffered row (column -1 = column 0)
+        const uint32_t sbyte = xa & 3;
+        st.sel = 0x0c000c00u | sbyte | ((sbyte + ((3 * b - 1 - X0 >= 0) ? 1u : 0u)) << 16);
+        const int r0 = 3 * a_first - 1 - Y0;
+        const uint8_t* dbuf = reinterpret_cast<const uint8_t*>(obuf + CFG::OBUF) + (xa & ~3);
+        st.slr = dbuf + r0 * (CFG::OBP * 4);
+        st.sla0 = dbuf + max(r0, 0) * (CFG::OBP * 4);
+        st.smap = has ? ext.sitemap + fz * ext.mframe + (size_t)a_first * ext.mpitch + b : nullptr;
+        st.mpitch = (uint32_t)ext.mpitch;
+        // seam strips: X0 is a seam (this strip holds its right column, image column X0) or X0 + SW is (its left column, X0 + SW - 1)
+        constexpr int SEAM = 3 * CFG::SW;
+        const bool right_of = X0 > 0 && X0 % SEAM == 0 && X0 / SEAM <= ext.nseams;
+        const bool left_of = (X0 + CFG::SW) % SEAM == 0 && (X0 + CFG::SW) / SEAM <= ext.nseams;
+        st.cdump = nullptr;
+        if ((right_of || left_of) && lane < 32 && Y0 + lane < rows) {
+            const int seam = right_of ? X0 / SEAM : (X0 + CFG::SW) / SEAM;
+            st.clevel = (uint32_t)ext.nseams * (uint32_t)rows * 2u;
+            st.cdump = ext.colmap + fz * ext.cframe + ((size_t)(seam - 1) * rows + (Y0 + lane)) * 2 + (right_of ? 1 : 0);
+            st.cl = reinterpret_cast<const uint8_t*>(obuf + CFG::OBUF) + lane * (CFG::OBP * 4) + (right_of ? 0 : CFG::SW - 1);
+        }
+        const uint32_t mc = (uint32_t)min(max(ext.min_contrast, 0), 256);
+        st.mc2 = mc | (mc << 16);
+    }
     uint32_t pe[CFG::NOB][4], po[CFG::NOB][4];
-    mx_level<CFG, 0>(taps, ln, pe, po);
-    mx_level<CFG, 1>(taps, ln, pe, po);
-    mx_level<CFG, 2>(taps, ln, pe, po);
-    mx_level<CFG, 3>(taps, ln, pe, po);
-    mx_level<CFG, 4>(taps, ln, pe, po);
-    mx_level<CFG, 5>(taps, ln, pe, po);
+    mx_level<CFG, 0, EXT>(taps, ln, pe, po, st);
+    mx_level<CFG, 1, EXT>(taps, ln, pe, po, st);
+    mx_level<CFG, 2, EXT>(taps, ln, pe, po, st);
+    mx_level<CFG, 3, EXT>(taps, ln, pe, po, st);
+    mx_level<CFG, 4, EXT>(taps, ln, pe, po, st);
+    mx_level<CFG, 5, EXT>(taps, ln, pe, po, st);
+}
+
+// ---- the other half of the fused lattice scan ---------------------------------------------------------------------------
+// One lane per EIGHT consecutive lattice sites of a lattice row (one byte of each of the six mask words), MX_PACK_ROWS
+// lattice rows per workgroup (a thread per site was bound by wave launches: 3.7 M waves per 256-frame step; one wave per
+// row piece by workgroup launches).  The lane reads its eight site bytes of every row first (independent loads), gathers
+// bit k of the eight bytes into one byte (multiply trick per dword) and stores it at its place in mask word b / 64:
+// byte (b mod 64) / 8 = the layout a wave ballot over 64 sites gives, i.e. exactly what k_extrema_w3 writes.
+// Sites the octave kernel does not own:
+//   * lattice rows whose windows straddle a strip's first image row (a > 0 a multiple of `sh`; sh, sw powers of two, so
+//     3a = 0 mod sh <=> a = 0 mod sh) are SKIPPED here: the host runs k_extrema_w3 on exactly those rows;
+//   * sites whose window straddles a strip's first column (b > 0 a multiple of `sw`: one lane in sw / 8) are evaluated
+//     here from the seam map, the two DoG columns the strips on either side left for every level (MxExtArgs::colmap).
+// grid = (ceil(8 wpr / 256), ceil(lat_rows / MX_PACK_ROWS), frames), block 256.
+constexpr int MX_PACK_ROWS = 8;
+__global__ __launch_bounds__(256) void k_extrema_pack(const uint8_t* __restrict__ sitemap, size_t mframe, int mpitch, const uint8_t* __restrict__ colmap,
+                                                      size_t cframe, int nseams, int rows, int lat_rows, int lat_cols, int wpr, int sh, int sw,
+                                                      int min_contrast, unsigned long long* __restrict__ bits, unsigned long long* __restrict__ lflags,
+                                                      size_t bframe) {
+    const int f = blockIdx.z, a0 = blockIdx.y * MX_PACK_ROWS;
+    const int g = blockIdx.x * 256 + threadIdx.x;  // byte of a lattice row's mask words
+    if (g >= 8 * wpr) return;
+    const int b0 = 8 * g, nvalid = min(8, lat_cols - b0);
+    const uint8_t* map = sitemap + f * mframe + b0;
+    uint2 v[MX_PACK_ROWS];
+#pragma unroll
+    for (int i = 0; i < MX_PACK_ROWS; ++i) {
+        const int a = a0 + i;
+        v[i] = make_uint2(0u, 0u);
+        if (nvalid > 0 && a < lat_rows) v[i] = *reinterpret_cast<const uint2*>(map + (size_t)min(a, lat_rows - 1) * mpitch);
+    }
+    if (nvalid > 0 && b0 > 0 && (b0 & (sw - 1)) == 0) {  // site b0 of every row: the window straddles a strip's first column (a seam)
+        const size_t lstride = (size_t)nseams * rows * 2;
+        const uint8_t* S = colmap + f * cframe + (size_t)(b0 / sw - 1) * rows * 2;  // seam 3 b0 / (3 sw)
+        uint32_t mn[MX_PACK_ROWS][2], mx[MX_PACK_ROWS][2], self[MX_PACK_ROWS] = {}, six[MX_PACK_ROWS] = {};
+#pragma unroll
+        for (int l = 0; l < 5; ++l) {
+            uint32_t m0[MX_PACK_ROWS], m1[MX_PACK_ROWS], sf[MX_PACK_ROWS];
+#pragma unroll
+            for (int i = 0; i < MX_PACK_ROWS; ++i) {
+                const int a = min(a0 + i, lat_rows - 1);
+                const uint8_t* r0 = S + l * lstride + (size_t)max(3 * a - 1, 0) * 2;
+                const uint8_t* r1 = S + l * lstride + (size_t)(3 * a) * 2;
+                const uint32_t v00 = r0[0], v01 = r0[1], v10 = r1[0], v11 = r1[1];
+                m0[i] = min(min(v00, v01), min(v10, v11));
+                m1[i] = max(max(v00, v01), max(v10, v11));
+                sf[i] = v11;
+            }
+#pragma unroll
+            for (int i = 0; i < MX_PACK_ROWS; ++i) {
+                if (l >= 2) {  // levels l-2, l-1, l are known: centre level c = l-1
+                    const uint32_t lo = min(mn[i][0], min(mn[i][1], m0[i])), hi = max(mx[i][0], max(mx[i][1], m1[i]));
+                    const uint32_t cand = (self[i] == lo || self[i] == hi) ? 1u : 0u;
+                    six[i] |= (cand | ((cand && (int)self[i] >= min_contrast) ? 2u : 0u)) << (2 * (l - 2));
+                }
+                mn[i][0] = mn[i][1], mx[i][0] = mx[i][1];
+                mn[i][1] = m0[i], mx[i][1] = m1[i];
+                self[i] = sf[i];  // the centre value of the NEXT test is this level's
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MX_PACK_ROWS; ++i) v[i].x = (v[i].x & ~0xffu) | six[i];
+    }
+    uint8_t* bb = bits ? reinterpret_cast<uint8_t*>(bits + f * bframe) : nullptr;
+    uint8_t* lb = reinterpret_cast<uint8_t*>(lflags + f * bframe);
+#pragma unroll
+    for (int i = 0; i < MX_PACK_ROWS; ++i) {
+        const int a = a0 + i;
+        if (a >= lat_rows) break;
+        if (a > 0 && (a & (sh - 1)) == 0) continue;  // k_extrema_w3 writes this row's words
+        uint32_t xl = v[i].x, xh = v[i].y;  // sites b0..b0+3, b0+4..b0+7, one byte each
+        if (nvalid < 8) {  // the row's last sites (or none): what lies behind them in the map is not a site
+            const unsigned long long keep = nvalid > 0 ? ~0ull >> (8 * (8 - nvalid)) : 0ull;
+            xl &= (uint32_t)keep, xh &= (uint32_t)(keep >> 32);
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            // bit k of bytes 0..3 -> bits 28..31 of the product (the partial products below bit 28 sum to less than 2^24)
+            const uint32_t lo4 = (((xl >> k) & 0x01010101u) * 0x10204080u) >> 28, hi4 = (((xh >> k) & 0x01010101u) * 0x10204080u) >> 28;
+            const uint8_t byte = (uint8_t)(lo4 | (hi4 << 4));
+            const size_t at = (((size_t)(k >> 1) * lat_rows + a) * wpr) * 8 + g;
+            if (k & 1) lb[at] = byte;
+            else if (bb) bb[at] = byte;
+        }
+    }
 }
 
 // Host side: the quantised taps as MFMA operand fragments.

@@ -640,7 +640,27 @@ struct DogScratch {
     unsigned long long* lflags = nullptr;
     unsigned int* cws = nullptr;  // compaction chunk totals / offsets
     unsigned int* pbegin = nullptr;  // localize mode: per-frame list length before the current octave
+    // matrix path with the lattice scan fused into the octave kernel: one byte per lattice site of the octaves that kernel covers
+    uint8_t* sitemap = nullptr;
+    size_t site_frame = 0, site_off[VSLAM_MAX_OCTAVES] = {};
+    int site_pitch[VSLAM_MAX_OCTAVES] = {};
+    // ... and the two DoG columns on either side of every seam between its 128-column strips (vslam_mx.h: MxScan::colmap)
+    uint8_t* colmap = nullptr;
+    size_t col_frame = 0, col_off[VSLAM_MAX_OCTAVES] = {};
 };
+
+static inline int site_pitch_of(int lat_cols) { return (lat_cols + 63) & ~63; }
+static size_t site_frame_bytes(const vslam_batch_layout& L) {
+    size_t b = 0;
+    for (int o = 0; o < L.n_octaves; ++o) b += (size_t)L.lat_rows[o] * site_pitch_of(L.lat_cols[o]);
+    return b;
+}
+static size_t col_octave_bytes(const vslam_batch_layout& L, int o) { return align_up((size_t)5 * mx_seams(L.cols[o]) * L.rows[o] * 2, 16); }
+static size_t col_frame_bytes(const vslam_batch_layout& L) {
+    size_t b = 0;
+    for (int o = 0; o < L.n_octaves; ++o) b += col_octave_bytes(L, o);
+    return b;
+}
 
 // u16 scratch elements per frame: 6 row-sum images for a strip octave, 1 for a generic octave,
 // none for the LDS-tiled octaves.
@@ -655,14 +675,32 @@ static size_t dog_h_elems(const vslam_batch_layout& L, double sigma0) {
     return m;
 }
 
-static size_t dog_scratch_bytes(const vslam_batch_layout& L, double sigma0, int nf) {
+static size_t dog_scratch_bytes(const vslam_batch_layout& L, double sigma0, int nf, bool sitemap = false) {
     size_t sum_p = 0;
     for (int o = 0; o < L.n_octaves; ++o) sum_p += (size_t)L.rows[o] * L.pitch[o];
-    return ws_need((size_t)nf * sum_p) + ws_need((size_t)nf * dog_h_elems(L, sigma0) * 2 + 256) +
+    return (sitemap ? ws_need((size_t)nf * site_frame_bytes(L)) + ws_need((size_t)nf * col_frame_bytes(L) + 16) : 0) + ws_need((size_t)nf * sum_p) + ws_need((size_t)nf * dog_h_elems(L, sigma0) * 2 + 256) +
            ws_need((size_t)nf * L.bits_frame_words * 8) + ws_need(4 * compaction_ws_elems(L.bits_frame_words, nf)) + ws_need(4 * (size_t)nf);
 }
 
-static int dog_scratch_take(vslam_ctx* c, const vslam_batch_layout& L, double sigma0, int nf, DogScratch& s) {
+static int dog_scratch_take(vslam_ctx* c, const vslam_batch_layout& L, double sigma0, int nf, DogScratch& s, bool sitemap = false) {
+    if (sitemap) {
+        size_t off = 0;
+        for (int o = 0; o < L.n_octaves; ++o) {
+            s.site_off[o] = off;
+            s.site_pitch[o] = site_pitch_of(L.lat_cols[o]);
+            off += (size_t)L.lat_rows[o] * s.site_pitch[o];
+        }
+        s.site_frame = off;
+        s.sitemap = ws_take<uint8_t>(c, (size_t)nf * off);
+        size_t coff = 0;
+        for (int o = 0; o < L.n_octaves; ++o) {
+            s.col_off[o] = coff;
+            coff += col_octave_bytes(L, o);
+        }
+        s.col_frame = coff;
+        s.colmap = ws_take<uint8_t>(c, (size_t)nf * coff + 16);
+        if (!s.sitemap || !s.colmap) return fail(c, VSLAM_ERR_NOMEM, "workspace sizing error (site map)");
+    }
     size_t sum_p = 0;
     for (int o = 0; o < L.n_octaves; ++o) {
         s.base_off[o] = sum_p;  // octave bases keep the pitched rows of the pyramid planes
@@ -713,7 +751,7 @@ static int enqueue_pyr_octave(vslam_ctx* c, double sigma0, int o, const OctPlan&
 // The same octave through the matrix-core kernel (kernels_pyramid_mx.hip.h, vslam_mx.hip); `cfg` from mx_config_for.
 static int enqueue_pyr_octave_mx(vslam_ctx* c, int cfg, double sigma0, int o, const OctPlan& pl, const uint8_t* base, size_t bframe,
                                  uint8_t* oct_out, size_t pframe, int rows, int cols, int pitch, int nf, uint8_t* next_base, size_t nframe,
-                                 int nrows, int ncols, int npitch) {
+                                 int nrows, int ncols, int npitch, const MxScan* scan) {
     uint64_t sb;
     std::memcpy(&sb, &sigma0, 8);
     auto key = std::make_pair(sb, o);
@@ -732,7 +770,7 @@ static int enqueue_pyr_octave_mx(vslam_ctx* c, int cfg, double sigma0, int o, co
     hipError_t e;
     {
         TimedScope ts(c, "k_pyr_octave_mx");
-        e = mx_launch(cfg, c->stream, it->second, base, bframe, oct_out, pframe, rows, cols, pitch, nf, next_base, nframe, nrows, ncols, npitch);
+        e = mx_launch(cfg, c->stream, it->second, base, bframe, oct_out, pframe, rows, cols, pitch, nf, next_base, nframe, nrows, ncols, npitch, scan);
     }
     HIPCHK(c, e);
     return VSLAM_OK;
@@ -828,6 +866,7 @@ static int enqueue_dog(vslam_ctx* c, const vslam_params& p, const vslam_batch_la
                p.rows, p.cols, 16);
         HIPCHK(c, hipEventRecord(c->ev_up2, c->stream));
     }
+    bool fused[VSLAM_MAX_OCTAVES] = {};
     for (int o = 0; o < L.n_octaves; ++o) {
         const int rows = L.rows[o], cols = L.cols[o], pitch = L.pitch[o];
         const size_t P = (size_t)rows * pitch;
@@ -843,6 +882,15 @@ static int enqueue_dog(vslam_ctx* c, const vslam_params& p, const vslam_batch_la
         // A 384 x 32 tile (1920 = 5 x 384) on 384-thread workgroups was measured in round 3: six waves per
         // workgroup sit 2-2-1-1 on the four SIMDs and meet at every barrier: 21.3 vs 18.3 ms per step.
         const int shape = (long)((cols + 255) / 256) * ((rows + 31) / 32) <= (long)((cols + 127) / 128) * ((rows + 63) / 64) ? 1 : 0;
+        // matrix path: the plain lattice scan (window 3, candidates + contrast list) runs inside the octave kernel
+        // while the DoG rows are in LDS (kernels_pyramid_mx.hip.h); k_extrema_pack then replaces k_extrema_w3
+        MxScan scan{};
+        const bool fused_scan = c->mx && s.sitemap && do_extrema && !p.localize && !p.extrema_dense && p.extrema_window == 3 && L.lat_rows[o] > 0 &&
+                                L.lat_cols[o] > 0 && pl.path != OctPath::Generic && mx_scan_supported(mx_config_for(pl.ke));
+        if (fused_scan)
+            scan = MxScan{s.sitemap + s.site_off[o], s.site_frame, L.lat_rows[o], L.lat_cols[o], s.site_pitch[o], p.min_contrast,
+                          s.colmap + s.col_off[o], s.col_frame, mx_seams(cols)};
+        fused[o] = fused_scan;
         // frames [f_lo, f_lo + n) of this octave through the LDS-tiled kernel
         auto tiled = [&](int f_lo, int n) -> int {
             const uint8_t* b = base + (size_t)f_lo * s.bases_frame;
@@ -850,7 +898,13 @@ static int enqueue_dog(vslam_ctx* c, const vslam_params& p, const vslam_batch_la
             uint8_t* nbh = nb ? nb + (size_t)f_lo * s.bases_frame : nullptr;
             if (c->mx)
                 if (const int cfg = mx_config_for(pl.ke))
-                    return enqueue_pyr_octave_mx(c, cfg, p.sigma0, o, pl, b, s.bases_frame, oc, pframe, rows, cols, pitch, n, nbh, s.bases_frame, nr, nc, np);
+                {
+                    MxScan sc = scan;
+                    sc.sitemap += (size_t)f_lo * s.site_frame;
+                    sc.colmap += (size_t)f_lo * s.col_frame;
+                    return enqueue_pyr_octave_mx(c, cfg, p.sigma0, o, pl, b, s.bases_frame, oc, pframe, rows, cols, pitch, n, nbh, s.bases_frame, nr, nc, np,
+                                                 fused_scan ? &sc : nullptr);
+                }
 #define VSLAM_TILED(CFG) enqueue_pyr_octave<CFG>(c, p.sigma0, o, pl, b, s.bases_frame, oc, pframe, rows, cols, pitch, n, nbh, s.bases_frame, nr, nc, np)
             if (pl.path == OctPath::Tile0) return shape == 1 ? VSLAM_TILED(PyrCfgOct0W) : VSLAM_TILED(PyrCfgOct0);
             return shape == 1 ? VSLAM_TILED(PyrCfgOct1W) : VSLAM_TILED(PyrCfgOct1);
@@ -899,12 +953,23 @@ static int enqueue_dog(vslam_ctx* c, const vslam_params& p, const vslam_batch_la
                 const DenseGeom dg = dense_geom(L, o, p.min_contrast, nf);
                 hipLaunchKernelGGL(k_extrema_dense, dim3(((dg.cols + 3) / 4 + 255) / 256, (dg.rows + dg.seg - 1) / dg.seg, nf), dim3(256), 0, es,
                                    pyr, pframe, dg, bits ? bits + L.bits_offset[o] : nullptr, s.lflags + L.bits_offset[o], L.bits_frame_words);
+            } else if (fused[o]) {
+                const MxScan sc{s.sitemap + s.site_off[o], s.site_frame, L.lat_rows[o], L.lat_cols[o], s.site_pitch[o], p.min_contrast,
+                                s.colmap + s.col_off[o], s.col_frame, mx_seams(L.cols[o])};
+                HIPCHK(c, mx_launch_pack(es, sc, L.rows[o], L.lat_words[o], nf, bits ? bits + L.bits_offset[o] : nullptr, s.lflags + L.bits_offset[o],
+                                         L.bits_frame_words));
+                // the lattice rows whose windows straddle a strip's first image row (every 32nd: a = 32, 64, ...) are not in
+                // the site map: the plain scan kernel runs on exactly those rows
+                const int n_straddle = (L.lat_rows[o] - 1) / 32;
+                if (n_straddle > 0)
+                    hipLaunchKernelGGL(k_extrema_w3<false>, dim3((L.lat_words[o] + 3) / 4, n_straddle, nf), dim3(256), 0, es, pyr, pframe, g, o, bits, s.lflags,
+                                       L.bits_frame_words, 32, 32);
             } else if (p.extrema_window == 3) {
                 const dim3 eg((L.lat_words[o] + 3) / 4, L.lat_rows[o], nf);
                 if (p.localize)
-                    hipLaunchKernelGGL(k_extrema_w3<true>, eg, dim3(256), 0, es, pyr, pframe, g, o, bits, s.lflags, L.bits_frame_words);
+                    hipLaunchKernelGGL(k_extrema_w3<true>, eg, dim3(256), 0, es, pyr, pframe, g, o, bits, s.lflags, L.bits_frame_words, 0, 1);
                 else
-                    hipLaunchKernelGGL(k_extrema_w3<false>, eg, dim3(256), 0, es, pyr, pframe, g, o, bits, s.lflags, L.bits_frame_words);
+                    hipLaunchKernelGGL(k_extrema_w3<false>, eg, dim3(256), 0, es, pyr, pframe, g, o, bits, s.lflags, L.bits_frame_words, 0, 1);
             } else
                 hipLaunchKernelGGL(k_extrema, dim3((L.lat_cols[o] + 255) / 256, L.lat_rows[o], nf * 3), dim3(256), 0, es, pyr,
                                    pframe, g, o, bits, s.lflags, L.bits_frame_words);
@@ -1475,9 +1540,9 @@ static int dog_points_host(vslam_ctx* c, const vslam_pyramid* py, int octave, in
         if (window == 3) {
             const dim3 eg((L.lat_words[octave] + 3) / 4, L.lat_rows[octave], 1);
             if (localize)
-                LAUNCH(c, "k_extrema_w3", k_extrema_w3<true>, eg, dim3(256), py->d_block, L.pyramid_frame_bytes, g, octave, d_bits, d_lf, words);
+                LAUNCH(c, "k_extrema_w3", k_extrema_w3<true>, eg, dim3(256), py->d_block, L.pyramid_frame_bytes, g, octave, d_bits, d_lf, words, 0, 1);
             else
-                LAUNCH(c, "k_extrema_w3", k_extrema_w3<false>, eg, dim3(256), py->d_block, L.pyramid_frame_bytes, g, octave, d_bits, d_lf, words);
+                LAUNCH(c, "k_extrema_w3", k_extrema_w3<false>, eg, dim3(256), py->d_block, L.pyramid_frame_bytes, g, octave, d_bits, d_lf, words, 0, 1);
         } else {
             LAUNCH(c, "k_extrema", k_extrema, dim3((L.lat_cols[octave] + 255) / 256, L.lat_rows[octave], 3), dim3(256),
                    py->d_block, L.pyramid_frame_bytes, g, octave, d_bits, d_lf, words);
@@ -1927,7 +1992,8 @@ int vslam_detect_batch_dev(vslam_ctx* c, const vslam_params* pp, const uint8_t* 
     // octaves fill the chip.  Scratch: octave bases (+ u16 row sums of the non-tiled octaves).
     const int chunk = std::min(n_frames, 256);
     size_t need = 0;
-    if (dog) need += dog_scratch_bytes(L, p.sigma0, chunk);
+    const bool want_sitemap = dog && c->mx && !p.localize && !p.extrema_dense && p.extrema_window == 3;
+    if (dog) need += dog_scratch_bytes(L, p.sigma0, chunk, want_sitemap);
     if (harris)
         need += (out->response ? 0 : ws_need((size_t)chunk * N * 4)) + ws_need((size_t)chunk * harris_flag_words(p.rows, p.cols) * 8) +
                 ws_need(4 * compaction_ws_elems(harris_flag_words(p.rows, p.cols), chunk));
@@ -1935,7 +2001,7 @@ int vslam_detect_batch_dev(vslam_ctx* c, const vslam_params* pp, const uint8_t* 
     c->phase_marked = false;
     TRY(ws_reserve(c, need));
     DogScratch s;
-    if (dog) TRY(dog_scratch_take(c, L, p.sigma0, chunk, s));
+    if (dog) TRY(dog_scratch_take(c, L, p.sigma0, chunk, s, want_sitemap));
     OrientScratch os;
     if (orient) TRY(orient_scratch_take(c, p, chunk, os));
     OrientPlan opl;
@@ -1994,6 +2060,8 @@ int vslam_detect_batch_dev(vslam_ctx* c, const vslam_params* pp, const uint8_t* 
         // them it goes to its own stream - at once for small batches, behind the last LDS-tiled octave
         // kernel for large ones (enqueue_dog explains the gate) - and is enqueued from inside enqueue_dog,
         // right after that octave's event, so that nothing enqueued on its stream later can get in front of it.
+        // (matrix path: starting the Harris chain at once, or behind octave 0 / 2 / 3 instead of 1, moved the step by less than
+        // +-1.5 % - 14.54 .. 14.90 ms on one box - so the gate stays where the default path has it)
         const int harris_gate = (dog && use_aux) ? dog_side_gate(p, L, nf) : -1;
         if (harris && harris_gate < 0) TRY(do_harris());
         if (dog) {

@@ -14,9 +14,27 @@ int mx_config_for(const int ke[6]);
 // Bytes of the device table of configuration `cfg`; mx_pack fills a host copy (false: a tap does not fit a signed byte).
 size_t mx_taps_bytes(int cfg);
 bool mx_pack(int cfg, const uint16_t* const taps[6], void* host_table);
-// Raises the kernel's dynamic-LDS ceiling (once per device) and launches it on `stream`.
+// The lattice scan fused into the octave kernel (kernels_pyramid_mx.hip.h): the kernel leaves one byte per lattice site in
+// `sitemap` ([frames][lat_rows][mpitch]) and mx_launch_pack turns them - and the few sites the octave kernel cannot own -
+// into the candidate / list-flag words.  Window 3 only, candidates + min_contrast list (no localization).
+struct MxScan {
+    uint8_t* sitemap;
+    size_t mframe;
+    int lat_rows, lat_cols, mpitch, min_contrast;
+    uint8_t* colmap;  // [frames][5][nseams][rows][2]: the DoG columns on either side of every seam (image column 384 s)
+    size_t cframe;
+    int nseams;
+};
+// Seams of an octave `cols` wide: lattice columns whose window straddles two 128-column strips (3b = 384 s <= cols - 2).
+inline int mx_seams(int cols) { return cols >= 2 ? (cols - 2) / 384 : 0; }
+bool mx_scan_supported(int cfg);
+// Raises the kernel's dynamic-LDS ceiling (once per device) and launches it on `stream`; scan = nullptr: no fused scan.
 hipError_t mx_prepare(int cfg);
 hipError_t mx_launch(int cfg, hipStream_t stream, const void* d_table, const uint8_t* base, size_t bframe, uint8_t* oct_out, size_t pframe,
-                     int rows, int cols, int pitch, int nf, uint8_t* next_base, size_t nframe, int nrows, int ncols, int npitch);
+                     int rows, int cols, int pitch, int nf, uint8_t* next_base, size_t nframe, int nrows, int ncols, int npitch,
+                     const MxScan* scan);
+// bits / lflags: word 0 of frame 0's octave (bits may be nullptr).
+hipError_t mx_launch_pack(hipStream_t stream, const MxScan& scan, int rows, int wpr, int nf, unsigned long long* bits, unsigned long long* lflags,
+                          size_t bframe);
 
 }  // namespace vslam

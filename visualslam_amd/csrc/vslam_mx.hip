@@ -37,9 +37,15 @@ bool mx_pack(int cfg, const uint16_t* const taps[6], void* host_table) {
     return false;
 }
 
+bool mx_scan_supported(int cfg) { return cfg == 1 || cfg == 2; }  // the configurations with a D buffer in LDS (MxCfg::DBUF)
+
 template <class CFG>
 static hipError_t prepare() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pyr_octave_mx<CFG>), hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES);
+    if (CFG::DBUF) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pyr_octave_mx<CFG, CFG::DBUF != 0>), hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES);
+        if (e != hipSuccess) return e;
+    }
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pyr_octave_mx<CFG, false>), hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES);
 }
 
 hipError_t mx_prepare(int cfg) {
@@ -49,19 +55,37 @@ hipError_t mx_prepare(int cfg) {
 
 template <class CFG>
 static hipError_t launch(hipStream_t stream, const void* d_table, const uint8_t* base, size_t bframe, uint8_t* oct_out, size_t pframe, int rows,
-                         int cols, int pitch, int nf, uint8_t* next_base, size_t nframe, int nrows, int ncols, int npitch) {
+                         int cols, int pitch, int nf, uint8_t* next_base, size_t nframe, int nrows, int ncols, int npitch, const MxScan* scan) {
     const dim3 grid((cols + CFG::TW - 1) / CFG::TW, (rows + CFG::TH - 1) / CFG::TH, nf);
-    hipLaunchKernelGGL(k_pyr_octave_mx<CFG>, grid, dim3(CFG::NT), CFG::LDS_BYTES, stream, base, bframe, oct_out, pframe, rows, cols, pitch,
-                       static_cast<const MxTaps<CFG>*>(d_table), next_base, nframe, nrows, ncols, npitch);
+    MxExtArgs ext{};
+    if (scan && CFG::DBUF) {
+        ext = MxExtArgs{scan->sitemap, scan->mframe, scan->lat_rows, scan->lat_cols, scan->mpitch, scan->min_contrast, scan->colmap, scan->cframe, scan->nseams};
+        hipLaunchKernelGGL((k_pyr_octave_mx<CFG, CFG::DBUF != 0>), grid, dim3(CFG::NT), CFG::LDS_BYTES, stream, base, bframe, oct_out, pframe, rows, cols, pitch,
+                           static_cast<const MxTaps<CFG>*>(d_table), next_base, nframe, nrows, ncols, npitch, ext);
+    } else {
+        if (scan) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((k_pyr_octave_mx<CFG, false>), grid, dim3(CFG::NT), CFG::LDS_BYTES, stream, base, bframe, oct_out, pframe, rows, cols, pitch,
+                           static_cast<const MxTaps<CFG>*>(d_table), next_base, nframe, nrows, ncols, npitch, ext);
+    }
+    return hipGetLastError();
+}
+
+hipError_t mx_launch_pack(hipStream_t stream, const MxScan& scan, int rows, int wpr, int nf, unsigned long long* bits, unsigned long long* lflags,
+                          size_t bframe) {
+    // strips of 32 rows x 128 columns in every configuration with a fused scan (MxCfgOct0 / MxCfgOct1)
+    static_assert(MxCfgOct0::SW == 128 && MxCfgOct1::SW == 128, "k_extrema_pack's straddle rule, mx_seams");
+    hipLaunchKernelGGL(k_extrema_pack, dim3((8 * wpr + 255) / 256, (scan.lat_rows + MX_PACK_ROWS - 1) / MX_PACK_ROWS, nf), dim3(256), 0, stream, scan.sitemap,
+                       scan.mframe, scan.mpitch, scan.colmap, scan.cframe, scan.nseams, rows, scan.lat_rows, scan.lat_cols, wpr, 32, 128, scan.min_contrast, bits,
+                       lflags, bframe);
     return hipGetLastError();
 }
 
 hipError_t mx_launch(int cfg, hipStream_t stream, const void* d_table, const uint8_t* base, size_t bframe, uint8_t* oct_out, size_t pframe,
-                     int rows, int cols, int pitch, int nf, uint8_t* next_base, size_t nframe, int nrows, int ncols, int npitch) {
-    if (cfg == 1) return launch<MxCfgOct0>(stream, d_table, base, bframe, oct_out, pframe, rows, cols, pitch, nf, next_base, nframe, nrows, ncols, npitch);
-    if (cfg == 2) return launch<MxCfgOct1>(stream, d_table, base, bframe, oct_out, pframe, rows, cols, pitch, nf, next_base, nframe, nrows, ncols, npitch);
-    if (cfg == 3) return launch<MxCfgOct2>(stream, d_table, base, bframe, oct_out, pframe, rows, cols, pitch, nf, next_base, nframe, nrows, ncols, npitch);
-    if (cfg == 4) return launch<MxCfgOct3>(stream, d_table, base, bframe, oct_out, pframe, rows, cols, pitch, nf, next_base, nframe, nrows, ncols, npitch);
+                     int rows, int cols, int pitch, int nf, uint8_t* next_base, size_t nframe, int nrows, int ncols, int npitch, const MxScan* scan) {
+    if (cfg == 1) return launch<MxCfgOct0>(stream, d_table, base, bframe, oct_out, pframe, rows, cols, pitch, nf, next_base, nframe, nrows, ncols, npitch, scan);
+    if (cfg == 2) return launch<MxCfgOct1>(stream, d_table, base, bframe, oct_out, pframe, rows, cols, pitch, nf, next_base, nframe, nrows, ncols, npitch, scan);
+    if (cfg == 3) return launch<MxCfgOct2>(stream, d_table, base, bframe, oct_out, pframe, rows, cols, pitch, nf, next_base, nframe, nrows, ncols, npitch, scan);
+    if (cfg == 4) return launch<MxCfgOct3>(stream, d_table, base, bframe, oct_out, pframe, rows, cols, pitch, nf, next_base, nframe, nrows, ncols, npitch, scan);
     return hipErrorInvalidValue;
 }
 

@@ -137,6 +137,23 @@ int main(int argc, char** argv) {
                 ++col;
                 if (sub < tot2) det.submit(src[sub & 1], n), ++sub;
             }
+            // a result outlives the next submit(): with slots - 1 batches in flight the slot just collected is the one the
+            // next submit() takes, and its pack-stream copies used to land in the offsets / counts the caller still held
+            {
+                det.submit(h_frames, n);                       // A
+                det.submit(hB, n);                             // B
+                const vslam::BatchResult& ra = det.collect();  // A: its slot is free again
+                det.submit(hB, n);                             // B into A's slot
+                det.sync();                                    // ... and all of it has run
+                EXPECT(ra.n_frames == n && ra.harris_records == kp0.size() && ra.dog_records == pt0.size());
+                for (int f = 0; f <= n; ++f) EXPECT(ra.harris_offsets[f] == hoff[f] && ra.dog_offsets[f] == doff[f]);
+                for (int f = 0; f < n; ++f) EXPECT(ra.harris_counts[f] == hoff[f + 1] - hoff[f] && ra.dog_counts[f] == doff[f + 1] - doff[f]);
+                const vslam::FrameKeypoints fk = ra.frame(n - 1);
+                EXPECT(fk.n_harris == hoff[n] - hoff[n - 1] && fk.n_dog == doff[n] - doff[n - 1] && fk.harris_total == fk.n_harris && fk.dog_total == fk.n_dog);
+                det.collect();
+                det.collect();
+                EXPECT(det.in_flight() == 0);
+            }
             // device-resident: A and B back to back without a sync in between, each on its own pipeline
             uint8_t* dAB = nullptr;
             EXPECT(hipMalloc((void**)&dAB, 2 * (size_t)n * N) == hipSuccess);

@@ -248,6 +248,11 @@ void BatchDetector::detect_device(const uint8_t* d_frames, size_t frame_stride, 
     // device-resident batches use the lists of slot = pipeline: a batch's outputs stay valid until `pipelines` calls later
     Slot& s = begin_batch(next_pipe(), n);
     vslam_ctx* ctx = pipes_[(size_t)last_pipe_].ctx;
+    if (opt_.host_fed) {  // a host-fed batch may still be packing or downloading this slot's lists
+        const hipStream_t cs = (hipStream_t)pipes_[(size_t)last_pipe_].stream;
+        if (s.comp_done) HIPX(hipStreamWaitEvent(cs, (hipEvent_t)s.comp_done, 0));
+        if (s.down_done) HIPX(hipStreamWaitEvent(cs, (hipEvent_t)s.down_done, 0));
+    }
     check(vslam_detect_batch_dev(ctx, &p_, d_frames, frame_stride, n, &s.out), ctx, "vslam_detect_batch_dev");
     check(vslam_count_totals_dev(ctx, s.out.harris_counts, s.out.dog_counts, n, d_totals_), ctx, "vslam_count_totals_dev");
 }
@@ -314,10 +319,16 @@ const BatchResult& BatchDetector::collect() {
     BatchResult& r = s.res;
     r = BatchResult{};
     r.n_frames = s.n;
-    r.harris_offsets = s.h_off;
-    r.dog_offsets = s.h_off + (nb + 1);
-    r.harris_counts = s.h_cnt;
-    r.dog_counts = s.h_cnt + nb;
+    // out of the pinned staging buffers: this slot's next submit() - possible right after this call, with `slots` - 1
+    // batches still in flight - overwrites them from the pack stream while the caller reads the result
+    s.res_off.assign(s.h_off, s.h_off + 3 * (nb + 1));
+    s.res_cnt.assign(s.h_cnt, s.h_cnt + 4 * nb);
+    const uint64_t* h_off = s.res_off.data();
+    const uint32_t* h_cnt = s.res_cnt.data();
+    r.harris_offsets = h_off;
+    r.dog_offsets = h_off + (nb + 1);
+    r.harris_counts = h_cnt;
+    r.dog_counts = h_cnt + nb;
     r.harris = s.h_hpacked;
     r.dog = s.h_ppacked;
     const uint64_t th = s.out.harris_kps ? r.harris_offsets[s.n] : 0, tp = s.out.dog_points ? r.dog_offsets[s.n] : 0;
@@ -332,10 +343,10 @@ const BatchResult& BatchDetector::collect() {
     if (r.dog_records)
         HIPX(hipMemcpyAsync(s.h_ppacked, s.d_ppacked, r.dog_records * sizeof(vslam_point), hipMemcpyDeviceToHost, ds));
     if (s.out.oriented_points) {
-        r.oriented_offsets = s.h_off + 2 * (nb + 1);
+        r.oriented_offsets = h_off + 2 * (nb + 1);
         r.oriented = s.h_opacked;
-        r.oriented_counts = s.h_cnt + 2 * nb;
-        r.oriented_survivors = s.h_cnt + 3 * nb;
+        r.oriented_counts = h_cnt + 2 * nb;
+        r.oriented_survivors = h_cnt + 3 * nb;
         r.oriented_cap = p_.oriented_cap;
         const uint64_t to = r.oriented_offsets[s.n];
         r.oriented_records = std::min<uint64_t>(to, packed_cap_o_);

@@ -122,8 +122,8 @@ public:
     // Enqueues upload + detection + list packing of one batch.  host_frames: n dense frames; pinned memory
     // (alloc_pinned) for an asynchronous upload.  Throws if `slots` batches are already in flight.
     void submit(const uint8_t* host_frames, int n);
-    // Waits for the oldest batch in flight, downloads its lists and returns them.  The result stays valid
-    // until `slots` further collect() calls have been made.
+    // Waits for the oldest batch in flight, downloads its lists and returns them.  The result (offsets, counts and the
+    // packed records alike) stays valid until `slots` further collect() calls have been made, whatever is submitted meanwhile.
     const BatchResult& collect();
     int in_flight() const { return (int)(submitted_ - collected_); }
 
@@ -150,6 +150,10 @@ private:
         void* totals_read = nullptr;    // caller's event (hold_totals_until), not owned
         int n = 0;
         BatchResult res;
+        // collect() copies the offsets and counts out of the pinned buffers above: the slot's NEXT submit() overwrites those
+        // asynchronously (pack stream) while the caller may still be reading the result
+        std::vector<uint64_t> res_off;
+        std::vector<uint32_t> res_cnt;
     };
     struct Pipe {
         vslam_ctx* ctx = nullptr;
