@@ -82,11 +82,15 @@ int vslam_ctx_create(int device, void* stream, vslam_ctx** out);
 int vslam_ctx_destroy(vslam_ctx* ctx);
 int vslam_ctx_sync(vslam_ctx* ctx);
 /* The batched path runs its Harris chain and its scans / lists on two low-priority side streams.  HIP binds a stream to a
- * hardware queue of its choosing, and on an unlucky queue those kernels crawl (up to -20 %), so a
- * context times its 2nd to 5th full-size batch call on three candidate pairs of side streams and keeps the fastest from the
- * 6th call on (one host-side wait for the 5th call's end happens there; results never depend on the pair).
- * Reports the index of the pair in use (0 = the first created) and the state of the comparison (0 not started,
- * 1 measuring, 2 decided).  VSLAM_STREAM_TUNER=0 switches the comparison off.  Diagnostic only. */
+ * hardware queue of its choosing, and on an unlucky queue those kernels crawl (up to -20 %).  A host
+ * that wants the library to look for a better pair opts in with vslam_ctx_tune_side_streams(ctx, 1) (off by default; the
+ * environment variable VSLAM_STREAM_TUNER=1 switches it on for contexts created afterwards): the context then times its
+ * 2nd to 5th full-size batch call of one shape on three candidate pairs of side streams and adopts the fastest at the first
+ * later call that finds those calls finished (an event query: no call ever waits on the host, and nothing is timed
+ * while the context's stream is being captured; results never depend on the pair).
+ * vslam_ctx_side_stream_report: the index of the pair in use (0 = the first created) and the state of the comparison
+ * (0 off or not started, 1 measuring, 2 decided).  Diagnostic only. */
+int vslam_ctx_tune_side_streams(vslam_ctx* ctx, int on);
 int vslam_ctx_side_stream_report(const vslam_ctx* ctx, int* pair, int* state);
 /* Two batches in flight: a second context (own stream, own output buffers) whose batch starts when `leader`'s most
  * recent vslam_detect_batch_dev call is past its octave-0 kernels - the long, issue-bound part - instead of beside

@@ -22,12 +22,24 @@ def test_bench_two_ranks_share_one_gpu():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--frames", "4", "--rows", "240", "--cols", "320",
            "--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--live-traffic", "0"]
+    import time
+
+    t0 = time.time()
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    wall = time.time() - t0
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout  # rank 0 prints the one JSON line
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    # a scaling run must not spend minutes in secondary figures.  At N > 1 the list modes, two-in-flight and
+    # the matrix-path leg are skipped, the C++ children are bounded (20 s rendezvous, 45 s per child) and the line says
+    # where the time went
+    assert wall < 120, wall
+    assert d["modes"] is None and d["two_in_flight"] is None and d["mx_path"] is None
+    bw = d["bench_wall_s"]
+    assert {"value", "modes", "two_in_flight", "mx_path", "live_traffic", "cxx_host", "cpu_baseline"} <= set(bw), bw
+    assert bw["cxx_host"] < 60 and bw["modes"] < 1 and bw["two_in_flight"] < 1
     # the C++ host after the measurement: one Stream process per rank, their own communicator (here the TCP rehearsal
     # exchange), rank 0's child reports the job: two ranks, two different camera streams, the same totals as the Python ranks
     cx = d["cxx_host"]["device"]
@@ -65,6 +77,9 @@ def test_bench_one_rank_goes_through_rccl():
     assert d["n_gpus"] == 1 and d["value"] > 0
     assert d["distributed"] == {"initialized": True, "world_size": 1, "backend": "nccl", "ranks_gathered": 1}
     assert d["two_in_flight"]["frames_per_sec"] > 0 and d["two_in_flight"]["same_counts_on_both_contexts"] is True  # secondary figure, DESIGN 5.4
+    # the opt-in matrix path beside the headline: same counts, its own kernel figures, never `value`
+    assert d["config"]["matrix_path"] is False and d["mx_path"]["same_keypoint_counts_as_value"] is True and d["mx_path"]["frames_per_sec"] > 0
+    assert d["mx_path"]["k_pyr_octave_mx"]["launches_per_step"] >= 2
     assert d["cxx_host"]["device"]["frames_per_sec"] > 0 and "RCCL" in d["cxx_host"]["device"]["host"]
     assert d["cxx_host"]["device"]["keypoints_per_batch"] == {"harris": d["keypoints_per_step"]["harris"], "dog": d["keypoints_per_step"]["dog"]}
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--frames", "8", "--rows", "240", "--cols", "320", "--steps", "2",

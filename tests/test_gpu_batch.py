@@ -475,10 +475,11 @@ def test_detect_batch_host_lists(env, localize):
 
 
 def test_stream_tuner_compares_side_stream_pairs_without_touching_the_results():
-    # a context runs its 2nd to 5th full-size batch call on three candidate pairs of side streams and
-    # adopts the fastest at the 6th.  Seven identical calls on a fresh context: every call's outputs are byte-identical
-    # (the pair never matters for results), the report goes 0 -> 1 -> 2, and a context with the tuner's shape changing
-    # under it (another batch size in the middle) simply starts over
+    # a context that opted in (vslam_ctx_tune_side_streams) runs its 2nd to 5th full-size batch call on
+    # three candidate pairs of side streams and adopts the fastest at the first later call that finds them finished (here
+    # the 6th: run_batch synchronises after every call).  Seven identical calls on a fresh context: every call's outputs
+    # are byte-identical (the pair never matters for results), the report goes 0 -> 1 -> 2, and a context with the
+    # tuner's shape changing under it (another batch size in the middle) simply starts over.  Off by default.
     import torch
 
     capi.build()
@@ -486,6 +487,14 @@ def test_stream_tuner_compares_side_stream_pairs_without_touching_the_results():
     try:
         frames = synth.frames_np(32, 120, 160, stream_id=5)
         assert ctx.side_stream_report() == (0, 0)
+        for _ in range(7):  # not asked for: nothing is compared
+            run_batch(ctx, torch, frames)
+        assert ctx.side_stream_report() == (0, 0)
+    finally:
+        ctx.close()
+    ctx = capi.Context(0, torch.cuda.current_stream().cuda_stream)
+    try:
+        ctx.tune_side_streams(True)
         first = None
         states = []
         for call in range(7):
@@ -501,10 +510,64 @@ def test_stream_tuner_compares_side_stream_pairs_without_touching_the_results():
         ctx.close()
     ctx = capi.Context(0, torch.cuda.current_stream().cuda_stream)
     try:
+        ctx.tune_side_streams(True)
         a, b = synth.frames_np(32, 120, 160, stream_id=6), synth.frames_np(40, 120, 160, stream_id=6)
-        for fr in (a, a, a, b, b, a, a, a, a, a, a):
+        small = synth.frames_np(3, 120, 160, stream_id=6)
+        for fr in (a, a, small, a, b, b, a, a, small, a, a, a, a):  # small calls run on the pair in use and do not restart anything
             run_batch(ctx, torch, fr)
         assert ctx.side_stream_report()[1] == 2
+    finally:
+        ctx.close()
+    ctx = capi.Context(0, torch.cuda.current_stream().cuda_stream)
+    try:
+        ctx.tune_side_streams(True)
+        a, b = synth.frames_np(32, 120, 160, stream_id=6), synth.frames_np(40, 120, 160, stream_id=6)
+        for fr in (a, a, b, a, b, a, b):  # a caller whose full-size shape keeps changing: given up on the first pair
+            run_batch(ctx, torch, fr)
+        assert ctx.side_stream_report() == (0, 2)
+    finally:
+        ctx.close()
+
+
+def test_stream_tuner_never_blocks_the_host():
+    # the comparison used to wait on the host (hipEventSynchronize) inside the 6th call of an asynchronous
+    # entry point.  Eight calls of ~4 ms of GPU work each are enqueued back to back with no synchronisation: no call's
+    # enqueue may take anywhere near one call's GPU time (it decides by hipEventQuery when it finds the timed calls finished)
+    import time
+
+    import torch
+
+    capi.build()
+    ctx = capi.Context(0, torch.cuda.current_stream().cuda_stream)
+    try:
+        ctx.tune_side_streams(True)
+        rows, cols, n = 1080, 1920, 64
+        p = capi.default_params(rows, cols)
+        L = capi.batch_layout(p)
+        dev = "cuda:0"
+        frames = synth.frames_torch(n, rows, cols, stream_id=2, device=torch.device(dev))
+        o = dict(response=torch.empty((n, rows, cols), dtype=torch.float32, device=dev), nms_mask=torch.empty((n, rows, cols), dtype=torch.uint8, device=dev),
+                 harris_kps=torch.zeros((n, p.harris_cap, 3), dtype=torch.int32, device=dev), harris_counts=torch.zeros(n, dtype=torch.int32, device=dev),
+                 pyramid=torch.empty((n, L.pyramid_frame_bytes), dtype=torch.uint8, device=dev),
+                 extrema_bits=torch.zeros((n, L.bits_frame_words), dtype=torch.int64, device=dev),
+                 dog_points=torch.zeros((n, p.dog_cap, 6), dtype=torch.int32, device=dev), dog_counts=torch.zeros(n, dtype=torch.int32, device=dev))
+        ctx.detect_batch(p, frames, **o)  # first call: workspace, tables
+        torch.cuda.synchronize()
+        ref = (o["dog_counts"].clone(), o["harris_counts"].clone(), o["extrema_bits"].clone())
+        t0 = time.perf_counter()
+        enq = []
+        for _ in range(8):
+            t = time.perf_counter()
+            ctx.detect_batch(p, frames, **o)
+            enq.append(time.perf_counter() - t)
+        torch.cuda.synchronize()
+        per_call = (time.perf_counter() - t0) / 8
+        assert max(enq) < 0.5 * per_call, (enq, per_call)  # a host-side wait for the previous call would cost a whole per_call
+        assert ctx.side_stream_report()[1] in (1, 2)
+        ctx.detect_batch(p, frames, **o)  # everything has finished: this call decides
+        torch.cuda.synchronize()
+        assert ctx.side_stream_report()[1] == 2
+        assert torch.equal(o["dog_counts"], ref[0]) and torch.equal(o["harris_counts"], ref[1]) and torch.equal(o["extrema_bits"], ref[2])
     finally:
         ctx.close()
 

@@ -130,6 +130,7 @@ SIGNATURES = {
     "vslam_ctx_set_matrix_path": (_I, [_P, _I]),
     "vslam_ctx_get_matrix_path": (_I, [_P]),
     "vslam_ctx_side_stream_report": (_I, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "vslam_ctx_tune_side_streams": (_I, [_P, _I]),
     "vslam_detect_batch_host": (_I, [_P, C.POINTER(Params), _P, _Z, _I, C.POINTER(HostLists)]),
     "vslam_pack_lists_dev": (_I, [_P, _P, _Z, C.c_uint32, _P, _I, _P, _Z, _P]),
     "vslam_count_totals_dev": (_I, [_P, _P, _P, _I, _P]),
@@ -490,6 +491,10 @@ class Context:
 
     def matrix_path(self) -> bool:
         return bool(lib().vslam_ctx_get_matrix_path(self._h))
+
+    def tune_side_streams(self, on: bool = True):
+        """vslam_ctx_tune_side_streams: opt in to (or out of) the library's comparison of side-stream pairs; off by default."""
+        self._chk(lib().vslam_ctx_tune_side_streams(self._h, 1 if on else 0), "vslam_ctx_tune_side_streams")
 
     def follow(self, leader: "Context"):
         """vslam_ctx_follow: this context's next work starts once `leader`'s latest batch is past its octave-0 kernels."""

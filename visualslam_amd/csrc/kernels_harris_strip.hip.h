@@ -272,7 +272,7 @@ __device__ __forceinline__ void harris_strip_rows(const HarrisStripArgs& a, cons
                 }
             }
             if (lane_out) {
-                // row start on the scalar unit (a full 32-bit multiply is quarter rate on the vector unit; rows * cols < 2^32)
+                // row start on the scalar unit (one scalar multiply instead of a v_mul_lo + v_mul_hi + add-with-carry per lane: fewer instructions, not a faster one; rows * cols < 2^32)
                 const size_t off = blockIdx.z * N + __builtin_amdgcn_readfirstlane((uint32_t)y * (uint32_t)cols) + x0;
                 const float4 rv = make_float4(__uint_as_float(Ry[0]), __uint_as_float(Ry[1]), __uint_as_float(Ry[2]), __uint_as_float(Ry[3]));
                 const float4 nv = make_float4(__uint_as_float(n2[0]), __uint_as_float(n2[1]), __uint_as_float(n2[2]), __uint_as_float(n2[3]));

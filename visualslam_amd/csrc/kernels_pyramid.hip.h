@@ -307,7 +307,7 @@ __global__ __launch_bounds__(CFG::NT) void k_pyr_octave(const uint8_t* __restric
     uint8_t* nb = next_base ? next_base + fz * nframe : nullptr;
     uint32_t prev_e[4][2], prev_o[4][2];
     // byte offsets of this thread's four output rows inside a plane (pass 2 / epilogue mapping of pyr_level):
-    // 32-bit multiplies are quarter rate, and the offsets do not depend on the level
+    // formed once per thread, not per level: the offsets do not depend on the level (instruction count, not a slow multiply)
     uint32_t row_off[4];
     {
         const int xg = tid % (CFG::TW / 8), rg = tid / (CFG::TW / 8);

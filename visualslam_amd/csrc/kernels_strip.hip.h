@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void k_gauss_v_strip(const uint8_t* __restrict
             }
             const int gx = x0 + 4 * cg;
             if (gx < cols) {
-                const int off0 = ty0 * pitch + gx;  // one multiply per item (quarter rate), rows by addition; a level's scratch is far below 2^31 elements
+                const int off0 = ty0 * pitch + gx;  // one multiply per item, rows by addition (fewer instructions); a level's scratch is far below 2^31 elements
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int y = ty0 + j;
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void k_gauss_h_strip(const uint16_t* __restric
     const int ncg = (cols + 7) >> 3, items = ncg * (SH / RI);
     uint32_t prev_e[2][RI][2], prev_o[2][RI][2];
     // this thread's (at most two) items and the plane offset of each item's first row: the same for every
-    // level, so the division and the multiply (quarter rate) are done once
+    // level, so the division and the multiply are done once (a dozen instructions saved per level)
     int item_cg[2], item_rg[2];
     uint32_t item_off[2];
 #pragma unroll

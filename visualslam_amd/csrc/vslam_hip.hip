@@ -40,10 +40,11 @@ struct StreamTuner {
     hipEvent_t t0[M] = {}, t1[M] = {};
     int measured = 0;                                // calls measured so far
     int measuring = -1;                              // slot being measured by the current call
+    bool enabled = false;                            // vslam_ctx_tune_side_streams (or VSLAM_STREAM_TUNER=1 when the context was created)
     bool done = false;
     int chosen = 0;
-    unsigned long long key = 0;                      // shape of the calls being compared
-    int calls = 0;
+    unsigned long long key = 0;                      // shape of the calls being compared (0: none yet)
+    int calls = 0, resets = 0;
 };
 
 struct vslam_ctx {
@@ -171,13 +172,14 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 // HIP binds every stream to one of GPU_MAX_HW_QUEUES hardware queues per priority level, and the placement is not ours to
 // choose.  Measured: depending on the queue a LOW-priority side stream lands on, the batch runs up
 // to 20 % slower (the same binary: 11.4 k frames/s with 3 queues per level, 14.2 k with 12) - on one bad queue the side
-// kernels crawl while the main stream's queue sits on the barrier that waits for them.  A synthetic probe of that
-// effect (tools/queue_probe.hip) finds the bad queue in some layouts and condemns a good one in others, so the library
-// measures the real thing instead: the 2nd to 5th batch call of a context run on three candidate pairs of side streams
-// (the first pair twice), each call timed with events on the main stream, and the 6th call adopts the fastest pair -
-// the first one unless another is at least 3 % faster.  The calls must have the same shape; the results of a call do not
-// depend on the streams it runs on.  One host-side wait (for the 5th call's end) happens at the 6th call.
-// VSLAM_STREAM_TUNER=0 keeps the first pair.
+// kernels crawl while the main stream's queue sits on the barrier that waits for them.  A host that wants the library to
+// look for a better pair OPTS IN (vslam_ctx_tune_side_streams; the Stream executable does): the 2nd to 5th full-size batch
+// call of the context then run on three candidate pairs of side streams (the first pair twice), each call bracketed by two
+// events on the main stream, and the first later call that finds all of them complete (hipEventQuery: the entry point stays
+// asynchronous, nothing waits on the host) adopts the fastest pair - the first one unless another is at least 3 % faster.
+// Only calls of one shape are compared (calls of another shape, small or odd calls run on the pair in use and do not
+// disturb the comparison; a caller whose full-size shape keeps changing ends it on the first pair after three restarts);
+// nothing is timed while the stream is being captured.  Results never depend on the streams a call runs on.
 static int tuner_pair_of(int slot) { return slot == StreamTuner::K ? 0 : slot; }
 
 static int create_side_stream(vslam_ctx* c, int prio_lo, hipStream_t* out) {
@@ -205,24 +207,25 @@ static void tuner_finish(vslam_ctx* c, int chosen) {
     }
 }
 
-// Before the fork of a batch call (ensure_aux has run): picks the pair of side streams this call uses.
+// Before the fork of a batch call (ensure_aux has run): picks the pair of side streams this call uses.  Never blocks.
 static int tuner_before_call(vslam_ctx* c, unsigned long long key, bool eligible) {
     StreamTuner& t = c->tuner;
-    static const bool enabled = [] {
-        const char* e = getenv("VSLAM_STREAM_TUNER");
-        return !(e && e[0] == '0');
-    }();
-    if (t.done) return VSLAM_OK;
-    ++t.calls;
-    if (!enabled || c->prio_lo == 0) {
+    if (t.done || !t.enabled) return VSLAM_OK;
+    if (c->prio_lo == 0) {  // no priority levels: one pair is as good as another
         t.done = true;
         return VSLAM_OK;
     }
-    if (t.calls == 1 || !eligible) {  // the first call pays one-time costs; small / odd calls are not what is being tuned
-        t.key = key;
-        return VSLAM_OK;
-    }
-    if (key != t.key) {  // the shape changed in the middle: start over with the new one (the pairs created so far stay)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(c->stream, &cap) != hipSuccess) (void)hipGetLastError();
+    if (cap != hipStreamCaptureStatusNone) return VSLAM_OK;  // a captured call records no timing events and runs on the pair in use
+    ++t.calls;
+    if (t.calls == 1 || !eligible) return VSLAM_OK;  // the first call pays one-time costs; small / odd calls are not what is being tuned
+    if (t.key == 0) t.key = key;
+    if (key != t.key) {  // another full-size shape: start over with it (the pairs created so far stay), but not for ever
+        if (++t.resets > 3) {
+            tuner_finish(c, 0);
+            return VSLAM_OK;
+        }
         t.key = key;
         t.measured = 0;
         c->aux[0] = t.cand[0][0], c->aux[1] = t.cand[0][1];
@@ -239,9 +242,15 @@ static int tuner_before_call(vslam_ctx* c, unsigned long long key, bool eligible
         t.measuring = m;
         return VSLAM_OK;
     }
-    // every candidate has been timed: wait (once) for the last measured call and keep the fastest pair
+    // every candidate has been timed: decide once the last measured call has finished - until then on the first pair
+    c->aux[0] = t.cand[0][0], c->aux[1] = t.cand[0][1];
+    const hipError_t q = hipEventQuery(t.t1[StreamTuner::M - 1]);
+    if (q == hipErrorNotReady) {
+        (void)hipGetLastError();
+        return VSLAM_OK;
+    }
     float ms[StreamTuner::M] = {};
-    bool ok = hipEventSynchronize(t.t1[StreamTuner::M - 1]) == hipSuccess;
+    bool ok = q == hipSuccess;
     for (int m = 0; m < StreamTuner::M && ok; ++m) ok = hipEventElapsedTime(&ms[m], t.t0[m], t.t1[m]) == hipSuccess;
     int best = 0;
     if (ok) {
@@ -252,7 +261,7 @@ static int tuner_before_call(vslam_ctx* c, unsigned long long key, bool eligible
     } else {
         (void)hipGetLastError();
     }
-    tuner_finish(c, best);
+    tuner_finish(c, best);  // the discarded streams are idle (every measured call has joined them back): nothing to wait for
     return VSLAM_OK;
 }
 
@@ -1093,6 +1102,8 @@ int vslam_ctx_create(int device, void* stream, vslam_ctx** out) {
     {
         const char* e = std::getenv("VSLAM_MX");
         c->mx = e && e[0] == '1';
+        const char* t = std::getenv("VSLAM_STREAM_TUNER");
+        c->tuner.enabled = t && t[0] == '1';
     }
     *out = c;
     return VSLAM_OK;
@@ -2114,10 +2125,16 @@ int vslam_detect_batch_dev(vslam_ctx* c, const vslam_params* pp, const uint8_t* 
     return VSLAM_OK;
 }
 
-int vslam_ctx_side_stream_report(const vslam_ctx* c, int* replaced, int* at_main_priority) {  // = (chosen pair, tuner state)
+int vslam_ctx_side_stream_report(const vslam_ctx* c, int* pair, int* state) {
     if (!c) return VSLAM_ERR_INVALID;
-    if (replaced) *replaced = c->tuner.chosen;
-    if (at_main_priority) *at_main_priority = c->tuner.done ? 2 : (c->tuner.calls > 1 ? 1 : 0);
+    if (pair) *pair = c->tuner.chosen;
+    if (state) *state = c->tuner.done ? 2 : ((c->tuner.enabled && c->tuner.calls > 1) ? 1 : 0);
+    return VSLAM_OK;
+}
+
+int vslam_ctx_tune_side_streams(vslam_ctx* c, int on) {
+    if (!c) return VSLAM_ERR_INVALID;
+    if (!c->tuner.done) c->tuner.enabled = on != 0;  // a finished comparison stays finished
     return VSLAM_OK;
 }
 

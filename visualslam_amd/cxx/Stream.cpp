@@ -44,7 +44,7 @@ namespace {
 struct Args {
     std::string mode = "device", source = "synth", dump, lists = "candidates";
     int frames = 256, batches = 8, warmup = 6, rows = 1080, cols = 1920, octaves = 4, pipelines = 1;
-    bool rdv_selftest = false, no_allgather = false, no_rccl = false;
+    bool rdv_selftest = false, no_allgather = false, no_rccl = false, no_tuner = false;
 };
 
 Args parse(int argc, char** argv) {
@@ -68,6 +68,7 @@ Args parse(int argc, char** argv) {
         else if (k == "--lists") a.lists = val();  // candidates (default) | localize | orient | describe: how much of the DoG executable runs per frame
         else if (k == "--rdv-selftest") a.rdv_selftest = true;
         else if (k == "--no-allgather") a.no_allgather = true;  // diagnosis only: the per-step collective left out
+        else if (k == "--no-tuner") a.no_tuner = true;          // diagnosis only: keep the first pair of side streams
         else if (k == "--no-rccl") a.no_rccl = true;            // diagnosis only: single rank without a communicator
         else throw std::runtime_error("unknown argument " + k);
     }
@@ -160,6 +161,7 @@ int main(int argc, char** argv) {
         opt.rows = a.rows, opt.cols = a.cols, opt.batch = a.frames;
         opt.host_fed = hostfed;
         opt.pipelines = a.pipelines;
+        opt.tune_side_streams = !a.no_tuner;  // this host opts in: the library compares three pairs of side streams during the warm-up
         opt.localize = a.lists != "candidates", opt.orient = a.lists == "orient" || a.lists == "describe", opt.describe = a.lists == "describe";
         if (a.octaves != 4) {
             opt.custom_params = true;
@@ -280,7 +282,7 @@ int main(int argc, char** argv) {
             bool truncated = false;
             auto submit = [&] {
                 det.submit(h_frames, a.frames);
-                gather_counts();
+                if (!a.no_allgather) gather_counts();
             };
             std::vector<double> t_collect;
             auto run = [&](int nb) {

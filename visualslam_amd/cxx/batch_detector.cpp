@@ -87,6 +87,7 @@ void BatchDetector::init(const Options& opt) {
         pp.stream = cs;
         rc = vslam_ctx_create(opt.device, cs, &pp.ctx);
         if (rc != VSLAM_OK) throw Error(rc, std::string("vslam_ctx_create: ") + vslam_status_string(rc) + " (no usable HIP device: there is no CPU fallback)");
+        (void)vslam_ctx_tune_side_streams(pp.ctx, opt.tune_side_streams ? 1 : 0);
     }
     if (opt.host_fed) {
         HIPX(hipStreamCreateWithFlags(&us, hipStreamNonBlocking));

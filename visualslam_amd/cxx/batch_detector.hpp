@@ -74,6 +74,7 @@ public:
         bool custom_params = false;      // false: vslam_params_default(rows, cols)
         vslam_params params{};
         int slots = 3;                   // host-fed batches in flight (>= 1); device buffers of frames + lists per slot
+        bool tune_side_streams = false;  // vslam_ctx_tune_side_streams on every pipeline's context (include/vslam.h; Stream sets it)
         // Batches whose KERNELS may run at the same time (1..4).  Each pipeline is a context + compute stream + set of
         // image buffers (response, mask, pyramid, bitmask: 33 GB for 256 x 1080p) of its own; consecutive batches
         // alternate between them, each starting once its predecessor is past octave 0 (vslam_ctx_follow), so that the

@@ -37,9 +37,26 @@ void ncclx(ncclResult_t r, const char* what) {
 // 60 s to let slow ranks start; VSLAM_RDV_TIMEOUT_MS overrides (tests)
 const int kTimeoutMs = env_int("VSLAM_RDV_TIMEOUT_MS", 60000);
 
-bool io_all(int fd, void* buf, size_t n, bool writing) {
+// What a rank says first: the id is handed only to a peer of THIS job (the token comes from VSLAM_JOB_TOKEN, or else from
+// what every rank of a torchrun job shares: MASTER_ADDR, MASTER_PORT, WORLD_SIZE and the launcher's run id).
+struct Hello {
+    uint32_t magic;
+    uint32_t token;
+    int32_t rank;
+};
+constexpr uint32_t kHelloMagic = 0x56534c4du;  // "VSLM"
+uint32_t job_token() {
+    std::string s;
+    for (const char* k : {"VSLAM_JOB_TOKEN", "TORCHELASTIC_RUN_ID", "MASTER_ADDR", "MASTER_PORT", "WORLD_SIZE"})
+        if (const char* v = std::getenv(k)) s += std::string(k) + "=" + v + ";";
+    uint32_t h = 2166136261u;  // FNV-1a
+    for (unsigned char c : s) h = (h ^ c) * 16777619u;
+    return h;
+}
+
+bool io_all(int fd, void* buf, size_t n, bool writing, int timeout_ms = -1) {
     char* p = static_cast<char*>(buf);
-    const auto t_end = std::chrono::steady_clock::now() + std::chrono::milliseconds(kTimeoutMs);
+    const auto t_end = std::chrono::steady_clock::now() + std::chrono::milliseconds(timeout_ms >= 0 ? timeout_ms : kTimeoutMs);
     while (n) {
         pollfd pf{fd, (short)(writing ? POLLOUT : POLLIN), 0};
         const int left = (int)std::chrono::duration_cast<std::chrono::milliseconds>(t_end - std::chrono::steady_clock::now()).count();
@@ -88,34 +105,39 @@ static void tcp_rendezvous(const RankEnv& env, void* bytes, size_t n, std::vecto
             ::close(ls);
             fail(msg);
         }
-        // every peer introduces itself with its rank; each rank is served exactly once
+        // every peer introduces itself with {magic, job token, rank}; each rank is served exactly once.  A connection
+        // that does not (a port scanner, a late rank of another job, a duplicate) is closed and ignored: the loop keeps
+        // accepting until every rank has been served or the deadline passes.
         std::vector<char> seen(env.world, 0);
-        for (int served = 1; served < env.world; ++served) {
+        const auto t_end = std::chrono::steady_clock::now() + std::chrono::milliseconds(kTimeoutMs);
+        int served = 1, ignored = 0;
+        while (served < env.world) {
             pollfd pf{ls, POLLIN, 0};
-            if (::poll(&pf, 1, kTimeoutMs) <= 0) {
+            const int left = (int)std::chrono::duration_cast<std::chrono::milliseconds>(t_end - std::chrono::steady_clock::now()).count();
+            if (left <= 0 || ::poll(&pf, 1, left) <= 0) {
                 ::close(ls);
-                fail("rendezvous: rank 0 timed out waiting for " + std::to_string(env.world - served) + " rank(s)");
+                fail("rendezvous: rank 0 timed out waiting for " + std::to_string(env.world - served) + " rank(s)" +
+                     (ignored ? " (" + std::to_string(ignored) + " foreign connection(s) ignored)" : ""));
             }
             const int fd = ::accept(ls, nullptr, nullptr);
-            if (fd < 0) {
-                ::close(ls);
-                fail("rendezvous: accept()");
-            }
-            int32_t peer = -1;
-            const bool ok = io_all(fd, &peer, sizeof(peer), false) && peer > 0 && peer < env.world && !seen[peer] && io_all(fd, bytes, n, true);
+            if (fd < 0) continue;
+            Hello h{};
+            const bool ok = io_all(fd, &h, sizeof(h), false, 2000) && h.magic == kHelloMagic && h.token == job_token() && h.rank > 0 && h.rank < env.world &&
+                            !seen[h.rank] && io_all(fd, bytes, n, true);
             if (!ok) {
                 ::close(fd);
-                ::close(ls);
-                fail("rendezvous: bad or duplicate peer (rank " + std::to_string(peer) + ")");
+                ++ignored;
+                continue;
             }
             if (keep) {
                 const int one_ = 1;
                 ::setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one_, sizeof(one_));
-                (*keep)[peer] = fd;
+                (*keep)[h.rank] = fd;
             } else {
                 ::close(fd);
             }
-            seen[peer] = 1;
+            seen[h.rank] = 1;
+            ++served;
         }
         ::close(ls);
     } else {
@@ -124,7 +146,7 @@ static void tcp_rendezvous(const RankEnv& env, void* bytes, size_t n, std::vecto
             const int fd = ::socket(AF_INET, SOCK_STREAM, 0);
             if (fd < 0) fail("rendezvous: socket()");
             if (::connect(fd, reinterpret_cast<sockaddr*>(&sa), sizeof(sa)) == 0) {
-                int32_t me = env.rank;
+                Hello me{kHelloMagic, job_token(), env.rank};
                 const bool ok = io_all(fd, &me, sizeof(me), true) && io_all(fd, bytes, n, false);
                 if (!ok) {
                     ::close(fd);
