@@ -83,7 +83,7 @@ struct MxCfg {
     // for lattice rows it does not own, and drops what it read)
     static constexpr int LDS_BYTES = (STAGE_DWORDS + NW * (1 + DBUF) * OBUF + 8 * OBP) * 4;
     static_assert(LDS_BYTES <= 160 * 1024, "one workgroup's LDS");
-    static_assert(TW % (32 * NWX) == 0 && TH % 32 == 0 && NT <= 1024 && NT % 256 == 0, "strips of 32-row x 32-column blocks, four waves per SIMD round");
+    static_assert(TW % (32 * NWX) == 0 && TH % 32 == 0 && NT <= 1024 && NT % 128 == 0, "strips of 32-row x 32-column blocks");
     static_assert(SW == 128, "the output flush maps a wave's 64 lanes to 8 rows x 128 bytes");
     static_assert(r(0) >= 1 && (N0 & 1) && (N1 & 1) && (N2 & 1) && (N3 & 1) && (N4 & 1) && (N5 & 1), "odd kernels");
 };
@@ -97,6 +97,25 @@ struct MxTaps {
 
 // Stages the TW x TH tile with halo R, byte-transposed (a dword = 4 vertically adjacent pixels of one column),
 // BORDER_REFLECT_101 resolved at fill time, every byte ^ bias (0x80: pixels - 128 as signed bytes).
+// Four pixels of one image row at columns x .. x+3 under BORDER_REFLECT_101: one dword load where the four lie inside the
+// row, one dword load of the mirrored run with its bytes reversed where they lie wholly in the first reflection on either
+// side, byte by byte (repeated reflection) only where they straddle an edge or the row is shorter than the halo.
+__device__ __forceinline__ uint32_t mx_load4_reflect(const uint8_t* __restrict__ row, int x, int cols) {
+    if (x >= 0 && x + 3 < cols) return *reinterpret_cast<const uint32_t*>(row + x);
+    if (x + 3 < 0 && -x < cols) {  // columns x..x+3 mirror to -x, -x-1, -x-2, -x-3 (all >= 1)
+        uint32_t v;
+        __builtin_memcpy(&v, row + (-x - 3), 4);
+        return __builtin_amdgcn_perm(0u, v, 0x00010203);
+    }
+    if (x >= cols && 2 * (cols - 1) - x - 3 >= 0) {  // mirror to 2(cols-1)-x, ... - 3 (all <= cols - 2)
+        uint32_t v;
+        __builtin_memcpy(&v, row + (2 * (cols - 1) - x - 3), 4);
+        return __builtin_amdgcn_perm(0u, v, 0x00010203);
+    }
+    return (uint32_t)row[mx_reflect101(x, cols)] | ((uint32_t)row[mx_reflect101(x + 1, cols)] << 8) | ((uint32_t)row[mx_reflect101(x + 2, cols)] << 16) |
+           ((uint32_t)row[mx_reflect101(x + 3, cols)] << 24);
+}
+
 template <int TW, int TH, int R, int RWP, int NT>
 __device__ __forceinline__ void mx_stage_tile(const uint8_t* __restrict__ src, int rows, int cols, int pitch, int tile_x0, int tile_y0,
                                               uint32_t* __restrict__ rp, uint32_t bias) {
@@ -125,23 +144,14 @@ __device__ __forceinline__ void mx_stage_tile(const uint8_t* __restrict__ src, i
             }
         }
     } else {
-        // border tiles: one dword column (4 pixels) x 4 rows per item; the rows are reflected per row, the columns per
-        // dword where the four pixels lie inside the image and per byte only where they straddle its edge
+        // border tiles (most tiles of the coarse octaves): one dword column (4 pixels) x 4 rows per item, rows reflected per
+        // row, columns per dword (mx_load4_reflect)
         for (int it = tid; it < RQ * (RW / 4); it += NT) {
             const int yq = it / (RW / 4), xq = it - yq * (RW / 4);
             const int gy = tile_y0 - R + 4 * yq, gx = tile_x0 - R + 4 * xq;
             uint32_t a[4];
-            if (gx >= 0 && gx + 3 < cols) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) a[k] = *reinterpret_cast<const uint32_t*>(src + (size_t)mx_reflect101(gy + k, rows) * pitch + gx);
-            } else {
-                const int x0 = mx_reflect101(gx, cols), x1 = mx_reflect101(gx + 1, cols), x2 = mx_reflect101(gx + 2, cols), x3 = mx_reflect101(gx + 3, cols);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const uint8_t* row = src + (size_t)mx_reflect101(gy + k, rows) * pitch;
-                    a[k] = (uint32_t)row[x0] | ((uint32_t)row[x1] << 8) | ((uint32_t)row[x2] << 16) | ((uint32_t)row[x3] << 24);
-                }
-            }
+            for (int k = 0; k < 4; ++k) a[k] = mx_load4_reflect(src + (size_t)mx_reflect101(gy + k, rows) * pitch, gx, cols);
             const uint32_t p01l = __builtin_amdgcn_perm(a[1], a[0], 0x05010400), p01h = __builtin_amdgcn_perm(a[1], a[0], 0x07030602);
             const uint32_t p23l = __builtin_amdgcn_perm(a[3], a[2], 0x05010400), p23h = __builtin_amdgcn_perm(a[3], a[2], 0x07030602);
             uint4 t;
@@ -153,7 +163,6 @@ __device__ __forceinline__ void mx_stage_tile(const uint8_t* __restrict__ src, i
         }
     }
 }
-
 
 // ---- fused lattice scan (initialKeypointDetection, Diff_of_Gauss.cpp:254-297, window 3) -------------------------------
 // The default path's k_extrema_w3 reads two thirds of the five DoG planes back from HBM (43 MB per 1080p frame).  Here a
