@@ -211,13 +211,17 @@ struct MxSites {
     const uint8_t* cl;    // ... and the byte it comes from: column 0 or SW-1 of this lane's row in the wave's D buffer
     uint32_t clevel;      // bytes per level of the seam map
     uint32_t mc2;         // min_contrast in both 16-bit lanes
-    uint32_t mn[3][MX_SITE_PAIRS], mx[3][MX_SITE_PAIRS], sf[3][MX_SITE_PAIRS], out[MX_SITE_PAIRS];
+    // 2 x 2 minima, maxima and centre values of the two previous DoG levels (slot = level % 2), two lattice rows per register
+    uint32_t mn[2][MX_SITE_PAIRS], mx[2][MX_SITE_PAIRS], sf[2][MX_SITE_PAIRS], out[MX_SITE_PAIRS];
 };
 
-// DoG level l of the strip is in the wave's D buffer: the 2 x 2 minimum, maximum and the centre value of every owned site.
+// DoG level l of the strip is in the wave's D buffer: the 2 x 2 minimum, maximum and the centre value of every owned site;
+// from level 2 on, with the two levels before it, the candidate and list bits of centre level c = l - 1 (bits 2(c-1),
+// 2(c-1)+1 of the site's byte); then level l takes the place of level l - 2.
 template <class CFG, int l>
 __device__ __forceinline__ void mx_sites_level(MxSites& st) {
-    constexpr int slot = l % 3, RB = CFG::OBP * 4;  // bytes per buffered row
+    constexpr int RB = CFG::OBP * 4;  // bytes per buffered row
+    constexpr int old = l % 2, mid = (l + 1) % 2;  // slots of levels l - 2 and l - 1
 #pragma unroll
     for (int p = 0; p < MX_SITE_PAIRS; ++p) {
         uint32_t lo[2], hi[2], v1[2];
@@ -232,27 +236,22 @@ __device__ __forceinline__ void mx_sites_level(MxSites& st) {
             hi[j] = mx_pk_max_u16(v0, v1[j]);
         }
         // lattice rows 2p (low half) and 2p+1 (high half) side by side
-        st.mn[slot][p] = mx_pk_min_u16(__builtin_amdgcn_perm(lo[1], lo[0], 0x05040100), __builtin_amdgcn_perm(lo[1], lo[0], 0x07060302));
-        st.mx[slot][p] = mx_pk_max_u16(__builtin_amdgcn_perm(hi[1], hi[0], 0x05040100), __builtin_amdgcn_perm(hi[1], hi[0], 0x07060302));
-        st.sf[slot][p] = __builtin_amdgcn_perm(v1[1], v1[0], 0x07060302);
-    }
-}
-
-// Levels c-1, c, c+1 are known: candidate and list bits of centre level c (1..3) into bits 2(c-1), 2(c-1)+1.
-template <int c>
-__device__ __forceinline__ void mx_sites_test(MxSites& st) {
-    constexpr int a = (c - 1) % 3, b = c % 3, d = (c + 1) % 3;
-#pragma unroll
-    for (int p = 0; p < MX_SITE_PAIRS; ++p) {
-        const uint32_t lo3 = mx_pk_min_u16(mx_pk_min_u16(st.mn[a][p], st.mn[b][p]), st.mn[d][p]);
-        const uint32_t hi3 = mx_pk_max_u16(mx_pk_max_u16(st.mx[a][p], st.mx[b][p]), st.mx[d][p]);
-        const uint32_t self = st.sf[b][p];
-        const uint32_t z = mx_pk_min_u16(self ^ lo3, self ^ hi3);                            // a zero lane = candidate
-        const uint32_t cand = mx_pk_sub_u16(0x00010001u, mx_pk_min_u16(z, 0x00010001u));    // 1 / 0 per lane
-        const uint32_t below = mx_pk_min_u16(mx_pk_sub_sat_u16(st.mc2, self), 0x00010001u);  // 1 iff value < min_contrast
-        const uint32_t listed = cand & ~below;
-        const uint32_t bits = cand | (listed << 1);
-        st.out[p] = c == 1 ? bits : (st.out[p] | (bits << (2 * (c - 1))));
+        const uint32_t mn = mx_pk_min_u16(__builtin_amdgcn_perm(lo[1], lo[0], 0x05040100), __builtin_amdgcn_perm(lo[1], lo[0], 0x07060302));
+        const uint32_t mx = mx_pk_max_u16(__builtin_amdgcn_perm(hi[1], hi[0], 0x05040100), __builtin_amdgcn_perm(hi[1], hi[0], 0x07060302));
+        const uint32_t sf = __builtin_amdgcn_perm(v1[1], v1[0], 0x07060302);
+        if constexpr (l >= 2) {
+            constexpr int c = l - 1;
+            const uint32_t lo3 = mx_pk_min_u16(mx_pk_min_u16(st.mn[old][p], st.mn[mid][p]), mn);
+            const uint32_t hi3 = mx_pk_max_u16(mx_pk_max_u16(st.mx[old][p], st.mx[mid][p]), mx);
+            const uint32_t self = st.sf[mid][p];
+            const uint32_t z = mx_pk_min_u16(self ^ lo3, self ^ hi3);                            // a zero lane = candidate
+            const uint32_t cand = mx_pk_sub_u16(0x00010001u, mx_pk_min_u16(z, 0x00010001u));    // 1 / 0 per lane
+            const uint32_t below = mx_pk_min_u16(mx_pk_sub_sat_u16(st.mc2, self), 0x00010001u);  // 1 iff value < min_contrast
+            const uint32_t listed = cand & ~below;
+            const uint32_t bits = cand | (listed << 1);
+            st.out[p] = c == 1 ? bits : (st.out[p] | (bits << (2 * (c - 1))));
+        }
+        st.mn[old][p] = mn, st.mx[old][p] = mx, st.sf[old][p] = sf;
     }
 }
 
@@ -287,9 +286,18 @@ struct MxLane {
 };
 
 // One Gaussian level of a wave's strip.
-template <class CFG, int L, bool EXT>
+// tcur: this level's operand fragments (b1[0..NS), a2[0..NS) of level L), loaded by the previous level; tnext: the next level's,
+// loaded here BEFORE this level's stores are issued.  vmcnt counts loads and stores together in issue order, so a
+// fragment load issued behind the flush waited for every store of the level to be acknowledged by a saturated HBM - the
+// waves spent 45 % of their cycles in s_waitcnt.
+// FULL: the strip lies wholly inside the image (wave-uniform; all but the last tile row and column): every store is
+// unconditional, so the level is straight-line code and the s_waitcnt in front of the next level's first MFMA counts exactly
+// the stores that may stay in flight.  Behind conditional stores (exec-masked regions with skip branches) the counter state is
+// a range and the wait degrades to vmcnt(0).
+template <class CFG, int L, bool EXT, bool FULL>
 __device__ __forceinline__ void mx_level(const MxTaps<CFG>* __restrict__ taps, const MxLane<CFG>& ln, uint32_t (&pe)[CFG::NOB][4],
-                                         uint32_t (&po)[CFG::NOB][4], MxSites& st) {
+                                         uint32_t (&po)[CFG::NOB][4], MxSites& st, const mx_v4i (&tcur)[2 * CFG::NSMAX],
+                                         mx_v4i (&tnext)[2 * CFG::NSMAX]) {
     constexpr int OFF = CFG::off(L), NS = CFG::ns(L), NOB = CFG::NOB, NIN = NOB + NS - 1, R = CFG::R, RWP = CFG::RWP;
     // G = ((C2hi << 8) + C2lo) >> 16 with C2lo starting at 256 * (128 + 32768) + 32768: the biases of the two byte planes
     // (taps sum to 256) + the one round-half-up of A2-iv
@@ -297,7 +305,7 @@ __device__ __forceinline__ void mx_level(const MxTaps<CFG>* __restrict__ taps, c
     const int lane = threadIdx.x & 63;
     mx_v4i b1[NS], a2[NS];
 #pragma unroll
-    for (int s = 0; s < NS; ++s) b1[s] = taps->b1[L][s][lane], a2[s] = taps->a2[L][s][lane];
+    for (int s = 0; s < NS; ++s) b1[s] = tcur[s], a2[s] = tcur[CFG::NSMAX + s];
     mx_v4i hi[NS], lo[NS];
     uint32_t dd[NOB][4] = {};  // the level's D values wait in registers while G passes through the wave's LDS buffer
 #pragma unroll
@@ -322,7 +330,7 @@ __device__ __forceinline__ void mx_level(const MxTaps<CFG>* __restrict__ taps, c
         }
         if (ib < NS - 1) continue;
         const int ob = ib - (NS - 1);
-        if (ob >= ln.nob_live) continue;  // wave-uniform: the block lies right of the image
+        if (!FULL && ob >= ln.nob_live) continue;  // wave-uniform: the block lies right of the image
         // ---- pass 2 on output block ob ------------------------------------------------------------------------
         mx_v16i chi = {}, clo;
 #pragma unroll
@@ -355,12 +363,15 @@ __device__ __forceinline__ void mx_level(const MxTaps<CFG>* __restrict__ taps, c
             *reinterpret_cast<uint2*>(ln.nb + 16 * ob) =
                 make_uint2(__builtin_amdgcn_perm(pe[ob][1], pe[ob][0], 0x06040200), __builtin_amdgcn_perm(pe[ob][3], pe[ob][2], 0x06040200));
     }
+    if constexpr (L < 5) {  // the next level's fragments, in front of this level's stores (see above)
+#pragma unroll
+        for (int s = 0; s < CFG::ns(L + 1); ++s) tnext[s] = taps->b1[L + 1][s][lane], tnext[CFG::NSMAX + s] = taps->a2[L + 1][s][lane];
+    }
     if constexpr (EXT && L > 0) {  // fused lattice scan: DoG level L-1 of the strip is in the wave's D buffer now
         static_assert(CFG::DBUF != 0, "the fused scan reads the D buffer");
         if (st.cdump) st.cdump[(size_t)(L - 1) * st.clevel] = *st.cl;
         if (st.nk > 0) {  // wave-uniform
             mx_sites_level<CFG, L - 1>(st);
-            if constexpr (L >= 3) mx_sites_test<L - 2>(st);
             if constexpr (L == 5) mx_sites_store(st);
         }
     }
@@ -375,7 +386,7 @@ __device__ __forceinline__ void mx_level(const MxTaps<CFG>* __restrict__ taps, c
             const uint4 gv = *reinterpret_cast<const uint4*>(ln.rb + 8 * i * CFG::OBP);
             uint4 dv;
             if (L > 0) dv = *reinterpret_cast<const uint4*>(ln.rb + CFG::OBUF + 8 * i * CFG::OBP);
-            if (ln.col_ok && 8 * i < ln.rows_left) {
+            if (FULL || (ln.col_ok && 8 * i < ln.rows_left)) {
                 *reinterpret_cast<uint4*>(gp + ln.off + i * ln.pitch8) = gv;
                 if (L > 0) *reinterpret_cast<uint4*>(dp + ln.off + i * ln.pitch8) = dv;
             }
@@ -389,18 +400,18 @@ __device__ __forceinline__ void mx_level(const MxTaps<CFG>* __restrict__ taps, c
 #pragma unroll
         for (int ob = 0; ob < NOB; ++ob) *reinterpret_cast<uint4*>(ln.wb + 8 * ob) = make_uint4(dd[ob][0], dd[ob][1], dd[ob][2], dd[ob][3]);
     }
-    if (ln.col_ok) {
-        if (0 < ln.rows_left) *reinterpret_cast<uint4*>(gp + ln.off) = g0;
-        if (8 < ln.rows_left) *reinterpret_cast<uint4*>(gp + ln.off + ln.pitch8) = g1;
-        if (16 < ln.rows_left) *reinterpret_cast<uint4*>(gp + ln.off + 2 * ln.pitch8) = g2;
-        if (24 < ln.rows_left) *reinterpret_cast<uint4*>(gp + ln.off + 3 * ln.pitch8) = g3;
+    if (FULL || ln.col_ok) {
+        if (FULL || 0 < ln.rows_left) *reinterpret_cast<uint4*>(gp + ln.off) = g0;
+        if (FULL || 8 < ln.rows_left) *reinterpret_cast<uint4*>(gp + ln.off + ln.pitch8) = g1;
+        if (FULL || 16 < ln.rows_left) *reinterpret_cast<uint4*>(gp + ln.off + 2 * ln.pitch8) = g2;
+        if (FULL || 24 < ln.rows_left) *reinterpret_cast<uint4*>(gp + ln.off + 3 * ln.pitch8) = g3;
     }
     if (L > 0) {
         uint8_t* dp = ln.out + (size_t)(VSLAM_NUM_LEVELS + L - 1) * ln.P;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const uint4 dv = *reinterpret_cast<const uint4*>(ln.rb + 8 * i * CFG::OBP);
-            if (ln.col_ok && 8 * i < ln.rows_left) *reinterpret_cast<uint4*>(dp + ln.off + i * ln.pitch8) = dv;
+            if (FULL || (ln.col_ok && 8 * i < ln.rows_left)) *reinterpret_cast<uint4*>(dp + ln.off + i * ln.pitch8) = dv;
         }
     }
 }
@@ -480,12 +491,24 @@ __global__ __launch_bounds__(CFG::NT) void k_pyr_octave_mx(const uint8_t* __rest
         st.mc2 = mc | (mc << 16);
     }
     uint32_t pe[CFG::NOB][4], po[CFG::NOB][4];
-    mx_level<CFG, 0, EXT>(taps, ln, pe, po, st);
-    mx_level<CFG, 1, EXT>(taps, ln, pe, po, st);
-    mx_level<CFG, 2, EXT>(taps, ln, pe, po, st);
-    mx_level<CFG, 3, EXT>(taps, ln, pe, po, st);
-    mx_level<CFG, 4, EXT>(taps, ln, pe, po, st);
-    mx_level<CFG, 5, EXT>(taps, ln, pe, po, st);
+    mx_v4i ta[2 * CFG::NSMAX], tb[2 * CFG::NSMAX];
+#pragma unroll
+    for (int s = 0; s < CFG::ns(0); ++s) ta[s] = taps->b1[0][s][lane], ta[CFG::NSMAX + s] = taps->a2[0][s][lane];
+    if (tile_y0 + Yw + 32 <= rows && tile_x0 + Xw + CFG::SW <= cols) {  // wave-uniform
+        mx_level<CFG, 0, EXT, true>(taps, ln, pe, po, st, ta, tb);
+        mx_level<CFG, 1, EXT, true>(taps, ln, pe, po, st, tb, ta);
+        mx_level<CFG, 2, EXT, true>(taps, ln, pe, po, st, ta, tb);
+        mx_level<CFG, 3, EXT, true>(taps, ln, pe, po, st, tb, ta);
+        mx_level<CFG, 4, EXT, true>(taps, ln, pe, po, st, ta, tb);
+        mx_level<CFG, 5, EXT, true>(taps, ln, pe, po, st, tb, ta);
+    } else {
+        mx_level<CFG, 0, EXT, false>(taps, ln, pe, po, st, ta, tb);
+        mx_level<CFG, 1, EXT, false>(taps, ln, pe, po, st, tb, ta);
+        mx_level<CFG, 2, EXT, false>(taps, ln, pe, po, st, ta, tb);
+        mx_level<CFG, 3, EXT, false>(taps, ln, pe, po, st, tb, ta);
+        mx_level<CFG, 4, EXT, false>(taps, ln, pe, po, st, ta, tb);
+        mx_level<CFG, 5, EXT, false>(taps, ln, pe, po, st, tb, ta);
+    }
 }
 
 // ---- the other half of the fused lattice scan ---------------------------------------------------------------------------
