@@ -31,6 +31,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "kernels_generic.hip.h"
 
 namespace vslam {
@@ -54,6 +56,7 @@ struct HarrisStripArgs {
     unsigned long long* flags;  // [frame][rows][nstrips][4]
     size_t fframe;
     int nstrips, seg;
+    uint8_t* dump;  // 64 writable bytes nobody reads (may be null): where the four margin lanes of a strip "store" in the steady rows
 };
 
 typedef unsigned short hs_us2_t __attribute__((ext_vector_type(2)));
@@ -126,13 +129,26 @@ __device__ __forceinline__ void harris_strip_rows(const HarrisStripArgs& a, cons
     // Six rows per trip of the outer loop: the rolling state is 2 and 3 rows deep, so after 6 fully
     // unrolled rows every value is back in its own register and the per-row state copies disappear.
     // The last trip may run up to 5 rows past t_end: they load reflected rows and store nothing.
-    for (int t0 = t_begin; t0 <= t_end; t0 += 6)
+    // STEADY trips (interior strips of an aligned image with response + mask + keypoint flags and no NMS2 map - the batched
+    // path's outputs - and all six rows of the trip far from the image's and the segment's first and last rows): no
+    // conditional memory operation at all.  The four margin lanes store to a dump slot instead of being masked off and every
+    // lane stores the (wave-uniform) flag words, so the trip is straight-line code and the compiler's s_waitcnt in front of a
+    // prefetched row counts exactly the stores that may stay in flight.  Behind conditional stores it could not, and
+    // drained the whole queue (vmcnt(0), twice per trip, right behind the newest prefetch): the kernel sat in s_waitcnt
+    // for 47 % of its cycles waiting for its own response stores to be acknowledged.
+    auto trip = [&](auto steady_tag, const int t0) {
+    constexpr bool STEADY = decltype(steady_tag)::value;
 #pragma unroll
     for (int u = 0; u < 6; ++u) {
         const int t = t0 + u;
         const uint32_t raw = nxt0;
         nxt0 = nxt1;
-        nxt1 = load_row(t + 2);
+        if constexpr (STEADY) {  // 0 <= t + 2 < rows: no reflection (its loop would be a branch in front of every prefetch)
+            const uint32_t roff = __builtin_amdgcn_readfirstlane((uint32_t)(t + 2) * (uint32_t)cols);
+            __builtin_memcpy(&nxt1, src + roff + (uint32_t)x0, 4);
+        } else {
+            nxt1 = load_row(t + 2);
+        }
 
         // ---- blur row t-1: vertical [1 2 1] on rows t-2,t-1,t, then horizontal -------------------
         const uint32_t e3 = raw & 0x00ff00ffu, o3 = (raw >> 8) & 0x00ff00ffu;
@@ -165,9 +181,9 @@ __device__ __forceinline__ void harris_strip_rows(const HarrisStripArgs& a, cons
         // 0 / rows-1, columns likewise
         const int b = t - 3;
         uint32_t Rb[4];
-        if (b >= 0 && b < rows) {  // wave-uniform
+        if (STEADY || (b >= 0 && b < rows)) {  // wave-uniform
             int V[3][4];
-            if (b - 1 < 0 || b + 1 >= rows) {  // wave-uniform: first / last image row
+            if (!STEADY && (b - 1 < 0 || b + 1 >= rows)) {  // wave-uniform: first / last image row
                 asm volatile("");              // keeps this a branch: if-converted it is 24 selects on every row
                 const bool top_rep = b - 1 < 0, bot_rep = b + 1 >= rows;
 #pragma unroll
@@ -252,7 +268,7 @@ __device__ __forceinline__ void harris_strip_rows(const HarrisStripArgs& a, cons
 
         // ---- finalise row y = t-4 ------------------------------------------------------------------
         const int y = t - 4;
-        if (y >= y_begin && y < y_end) {  // wave-uniform
+        if (STEADY || (y >= y_begin && y < y_end)) {  // wave-uniform
             uint32_t mword = 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -261,7 +277,7 @@ __device__ __forceinline__ void harris_strip_rows(const HarrisStripArgs& a, cons
             }
             uint32_t n2[4] = {0u, 0u, 0u, 0u};
             unsigned long long kpw[4] = {0ull, 0ull, 0ull, 0ull};
-            if (y >= 2 && y < rows - 2) {  // wave-uniform: NMS2 rows [2, rows-2) (:94)
+            if (STEADY || (y >= 2 && y < rows - 2)) {  // wave-uniform: NMS2 rows [2, rows-2) (:94)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const uint32_t w4 = max(umax3(h4a[k], h4b[k], h4c[k]), h4n[k]);  // rows y-2..y+1, cols x-2..x+1
@@ -271,6 +287,16 @@ __device__ __forceinline__ void harris_strip_rows(const HarrisStripArgs& a, cons
                     kpw[k] = __builtin_amdgcn_ballot_w64(Ry[k] >= w4) & __builtin_amdgcn_ballot_w64(w4 - 0x437d8000u < 0x4f000000u - 0x437d8000u) & inter_m[k];
                 }
             }
+            if constexpr (STEADY) {
+                const size_t off = blockIdx.z * N + __builtin_amdgcn_readfirstlane((uint32_t)y * (uint32_t)cols) + x0;
+                // (one base pointer and a selected DISTANCE: a select between two pointers came back as two conditional stores)
+                const ptrdiff_t dr = lane_out ? reinterpret_cast<const uint8_t*>(a.resp + off) - a.dump : 0;
+                const ptrdiff_t dm = lane_out ? (a.mask + off) - a.dump : 16;
+                *reinterpret_cast<float4*>(a.dump + dr) = make_float4(__uint_as_float(Ry[0]), __uint_as_float(Ry[1]), __uint_as_float(Ry[2]), __uint_as_float(Ry[3]));
+                *reinterpret_cast<uint32_t*>(a.dump + dm) = mword;
+                unsigned long long* F = a.flags + blockIdx.z * a.fframe + ((size_t)y * a.nstrips + strip) * 4;
+                F[0] = kpw[0], F[1] = kpw[1], F[2] = kpw[2], F[3] = kpw[3];  // every lane, the same four words
+            } else {
             if (lane_out) {
                 // row start on the scalar unit (one scalar multiply instead of a v_mul_lo + v_mul_hi + add-with-carry per lane: fewer instructions, not a faster one; rows * cols < 2^32)
                 const size_t off = blockIdx.z * N + __builtin_amdgcn_readfirstlane((uint32_t)y * (uint32_t)cols) + x0;
@@ -298,6 +324,7 @@ __device__ __forceinline__ void harris_strip_rows(const HarrisStripArgs& a, cons
                 unsigned long long* F = a.flags + blockIdx.z * a.fframe + ((size_t)y * a.nstrips + strip) * 4;
                 F[0] = kpw[0], F[1] = kpw[1], F[2] = kpw[2], F[3] = kpw[3];
             }
+            }
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -306,6 +333,22 @@ __device__ __forceinline__ void harris_strip_rows(const HarrisStripArgs& a, cons
             Ry[k] = Rb[k], Cy[k] = Cb[k], nby[k] = nbn[k];
         }
     }
+    };  // trip
+    const bool fast_ok = !EDGE && !ANYW && a.resp && a.mask && a.flags && !a.nms2 && a.dump;  // wave-uniform
+    const int y_lo = max(y_begin, 2), y_hi = min(y_end, rows - 2);
+    int t0 = t_begin;
+    const int t_hi = min(y_hi + 3, rows - 7);  // a steady trip starts at t0 <= t_hi: its last row y = t0 + 1 < y_hi, its last prefetch t0 + 7 < rows
+    for (; t0 <= t_end && !(fast_ok && t0 - 4 >= y_lo && t0 < t_hi && t0 + 2 >= 0); t0 += 6) trip(std::false_type{}, t0);
+    if constexpr (!EDGE && !ANYW) {
+        // one steady trip peeled in front of the loop: the loop header's counter state is the join of the entry edge and the
+        // back edge, and entering from guarded code would make every wait of the loop as strict as the entry's (vmcnt(2))
+        if (fast_ok && t0 <= t_end && t0 < t_hi) {
+            trip(std::true_type{}, t0);
+            t0 += 6;
+        }
+        for (; fast_ok && t0 <= t_end && t0 < t_hi; t0 += 6) trip(std::true_type{}, t0);
+    }
+    for (; t0 <= t_end; t0 += 6) trip(std::false_type{}, t0);
 }
 
 // grid = (ceil(nstrips*nseg / 4), 1, frames), block = 256 (4 independent waves).

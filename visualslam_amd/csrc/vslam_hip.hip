@@ -81,6 +81,7 @@ struct vslam_ctx {
     // kernels whose dynamic-LDS ceiling has been raised on this device (once, not per launch)
     std::set<const void*> lds_raised;
     float* loc_lut = nullptr;  // FeaturePointLocalization table (kernels_localize.hip.h), built on first use
+    uint8_t* dump = nullptr;   // 256 bytes nobody reads: where the Harris kernel's margin lanes store in its steady rows
     std::map<std::pair<uint64_t, int>, float*> orient_taps;  // (sigma bits, kernel width) -> f32 Gaussian taps on the device
     // bench timing hook
     std::string timing_name;
@@ -1028,6 +1029,8 @@ static int enqueue_harris(vslam_ctx* c, const uint8_t* frames, size_t fframe, in
     a.flags = hflags;
     a.nstrips = (cols + HS_STRIP_W - 1) / HS_STRIP_W;
     a.fframe = (size_t)rows * a.nstrips * 4;
+    if (!c->dump) HIPCHK(c, hipMalloc((void**)&c->dump, 256));
+    a.dump = c->dump;
     // enough waves to fill the chip several times over, long enough strips to amortise the
     // 9-row pipeline fill
     const long want_seg = std::max<long>(1, 12288 / ((long)a.nstrips * nf));
@@ -1134,6 +1137,7 @@ int vslam_ctx_destroy(vslam_ctx* c) {
     if (c->ws) (void)hipFree(c->ws);
     for (auto& b : c->block_cache) (void)hipFree(b.second);
     if (c->loc_lut) (void)hipFree(c->loc_lut);
+    if (c->dump) (void)hipFree(c->dump);
     for (auto& kv : c->orient_taps) (void)hipFree(kv.second);
     if (c->ev_fork && !c->tuner.done) tuner_finish(c, 0);  // candidate pairs of an unfinished comparison go first (aux = pair 0 again)
     for (int i = 0; i < vslam_ctx::kAux; ++i) {
