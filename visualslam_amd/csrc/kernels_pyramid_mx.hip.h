@@ -164,6 +164,148 @@ __device__ __forceinline__ void mx_stage_tile(const uint8_t* __restrict__ src, i
     }
 }
 
+// ---- octave 0's base formed while the tile is staged: createPyramid's 2x bilinear upsample (GaussPyramid.cpp:110) -----------
+// cv::resize(img, Size(), 2, 2, INTER_LINEAR) on CV_8U, bit for bit as k_resize_linear2x_slide (kernels_aux.hip.h): with
+// A = s_i + 3 s_{i+1} (or 3 s_i + s_{i+1}) per source row, X = A >> 2, Y = 3A >> 2, the destination rows are
+//   dst(2m) = (X(m-1) + Y(m) + 2) >> 2,   dst(2m+1) = (Y(m) + X(m+1) + 2) >> 2
+// and clamped source reads reproduce OpenCV's border rule.  The default path writes that base to HBM (8.3 MB per 1080p
+// frame) and the octave kernel reads it back with its halo (13 MB); here the tile's base pixels are computed from the
+// SOURCE frame into the same byte-transposed LDS image, and the base never exists in HBM.
+typedef unsigned short mx_us2c __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t mx_pk_lshr2_u16(uint32_t a) {
+    return __builtin_bit_cast(uint32_t, (mx_us2c)(__builtin_bit_cast(mx_us2c, a) >> (unsigned short)2));
+}
+// A of source row m (clamped) for base columns 2 c0 .. 2 c0 + 7 as (j0,j2) (j1,j3) (j4,j6) (j5,j7) 16-bit pairs; c0..c0+3 inside the row
+__device__ __forceinline__ void mx_up_hrow(const uint8_t* __restrict__ s, int sstep, int rows_s, int cols_s, int m, int c0, uint32_t (&A)[4]) {
+    const uint8_t* r = s + (size_t)min(max(m, 0), rows_s - 1) * sstep;
+    uint32_t w;
+    __builtin_memcpy(&w, r + c0, 4);
+    const uint32_t s0 = r[max(c0 - 1, 0)], s5 = r[min(c0 + 4, cols_s - 1)];
+    const uint32_t P = __builtin_amdgcn_perm(w, w, 0x0c010c00);   // (s1, s2)
+    const uint32_t Q = __builtin_amdgcn_perm(w, w, 0x0c030c02);   // (s3, s4)
+    const uint32_t Qm = __builtin_amdgcn_perm(w, w, 0x0c020c01);  // (s2, s3)
+    const uint32_t Pm = s0 | ((w & 0xffu) << 16);                  // (s0, s1)
+    const uint32_t Qp = (w >> 24) | (s5 << 16);                    // (s4, s5)
+    const uint32_t P3 = P + (P << 1), Q3 = Q + (Q << 1);
+    A[0] = Pm + P3, A[1] = P3 + Qm, A[2] = Qm + Q3, A[3] = Q3 + Qp;
+}
+// eight base pixels of one row from the two source rows' terms: bytes 0..7 in two dwords
+__device__ __forceinline__ uint2 mx_up_emit(const uint32_t (&U)[4], const uint32_t (&V)[4]) {
+    uint32_t v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = mx_pk_lshr2_u16(U[i] + V[i] + 0x00020002u);
+    return make_uint2(v[0] | (v[1] << 8), v[2] | (v[3] << 8));
+}
+// one base pixel, the literal formula (k_resize_linear2x): dy, dx inside the upsampled image
+__device__ __forceinline__ uint32_t mx_up_pixel(const uint8_t* __restrict__ s, int sstep, int rows_s, int cols_s, int dy, int dx) {
+    int sx = (dx >> 1) - 1 + (dx & 1), a1 = (dx & 1) ? 512 : 1536;
+    if (sx < 0) sx = 0, a1 = 0;
+    if (sx >= cols_s - 1) sx = cols_s - 1, a1 = 0;
+    const int a0 = 2048 - a1, sx1 = sx + 1 < cols_s ? sx + 1 : sx;
+    const int sy = (dy >> 1) - 1 + (dy & 1), b1 = (dy & 1) ? 512 : 1536, b0 = 2048 - b1;
+    const uint8_t* r0 = s + (size_t)min(max(sy, 0), rows_s - 1) * sstep;
+    const uint8_t* r1 = s + (size_t)min(max(sy + 1, 0), rows_s - 1) * sstep;
+    const int h0 = r0[sx] * a0 + r0[sx1] * a1, h1 = r1[sx] * a0 + r1[sx1] * a1;
+    const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+    return (uint32_t)min(max(v, 0), 255);
+}
+
+// Stages the tile of the UPSAMPLED image (2 rows_s x 2 cols_s) from the source frame.  Item = 16 base rows x 8 base columns
+// (thread = row segment * (RW / 8) + column group): a sliding pass down 8 source rows (+ one above, one below) where the
+// item's rows and columns lie inside the upsampled image; row by row (two source rows recomputed per base row) where some of
+// its rows are BORDER_REFLECT_101 images of rows inside; pixel by pixel where its columns are.
+template <int TW, int TH, int R, int RWP, int NT>
+__device__ __forceinline__ void mx_stage_tile_up2(const uint8_t* __restrict__ s, int sstep, int rows_s, int cols_s, int tile_x0, int tile_y0,
+                                                  uint32_t* __restrict__ rp, uint32_t bias) {
+    constexpr int RW = TW + 2 * R, RH = TH + 2 * R, NG = RW / 8, NSEG = RH / 16;
+    static_assert(RW % 8 == 0 && RH % 16 == 0, "16 x 8 staging items");
+    const int H2 = 2 * rows_s, W2 = 2 * cols_s;
+    for (int it = threadIdx.x; it < NSEG * NG; it += NT) {
+        const int seg = it / NG, g = it - seg * NG;
+        const int by = tile_y0 - R + 16 * seg, bx = tile_x0 - R + 8 * g;  // both even
+        // four base rows of the item (8 columns each): two 4 x 4 byte transposes, 8 columns x 4 vertical pixels = two 16-byte LDS stores
+        auto put_quad = [&](int q, const uint2& a0, const uint2& a1, const uint2& a2, const uint2& a3) {
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const uint32_t r0 = hh ? a0.y : a0.x, r1 = hh ? a1.y : a1.x, r2 = hh ? a2.y : a2.x, r3 = hh ? a3.y : a3.x;
+                const uint32_t p01l = __builtin_amdgcn_perm(r1, r0, 0x05010400), p01h = __builtin_amdgcn_perm(r1, r0, 0x07030602);
+                const uint32_t p23l = __builtin_amdgcn_perm(r3, r2, 0x05010400), p23h = __builtin_amdgcn_perm(r3, r2, 0x07030602);
+                uint4 t;
+                t.x = __builtin_amdgcn_perm(p23l, p01l, 0x05040100) ^ bias;
+                t.y = __builtin_amdgcn_perm(p23l, p01l, 0x07060302) ^ bias;
+                t.z = __builtin_amdgcn_perm(p23h, p01h, 0x05040100) ^ bias;
+                t.w = __builtin_amdgcn_perm(p23h, p01h, 0x07060302) ^ bias;
+                *reinterpret_cast<uint4*>(rp + (4 * seg + q) * RWP + 8 * g + 4 * hh) = t;
+            }
+        };
+        if (bx >= 0 && bx + 7 < W2) {
+            const int c0 = bx >> 1;
+            if (by >= 0 && by + 15 < H2) {
+                const int m0 = by >> 1;
+                uint32_t Ap[4], Ac[4], An[4], Xp[4], Yc[4], Xc[4];
+                mx_up_hrow(s, sstep, rows_s, cols_s, m0 - 1, c0, Ap);
+                mx_up_hrow(s, sstep, rows_s, cols_s, m0, c0, Ac);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) Xp[i] = mx_pk_lshr2_u16(Ap[i]), Xc[i] = mx_pk_lshr2_u16(Ac[i]), Yc[i] = mx_pk_lshr2_u16(Ac[i] + (Ac[i] << 1));
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    uint2 row[4];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        mx_up_hrow(s, sstep, rows_s, cols_s, m0 + 2 * q + j + 1, c0, An);
+                        uint32_t Xn[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) Xn[i] = mx_pk_lshr2_u16(An[i]);
+                        row[2 * j] = mx_up_emit(Xp, Yc);      // rows (m-1, m), weights (512, 1536)
+                        row[2 * j + 1] = mx_up_emit(Yc, Xn);  // rows (m, m+1), weights (1536, 512)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) Xp[i] = Xc[i], Xc[i] = Xn[i], Yc[i] = mx_pk_lshr2_u16(An[i] + (An[i] << 1));
+                    }
+                    put_quad(q, row[0], row[1], row[2], row[3]);
+                }
+            } else {
+#pragma unroll 1
+                for (int q = 0; q < 4; ++q) {
+                    uint2 row[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int yr = mx_reflect101(by + 4 * q + j, H2), m = yr >> 1;
+                        uint32_t A0[4], A1[4], U[4], V[4];
+                        // even row 2m: X(m-1) + Y(m); odd row 2m+1: Y(m) + X(m+1)
+                        mx_up_hrow(s, sstep, rows_s, cols_s, (yr & 1) ? m : m - 1, c0, A0);
+                        mx_up_hrow(s, sstep, rows_s, cols_s, (yr & 1) ? m + 1 : m, c0, A1);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const uint32_t x0 = mx_pk_lshr2_u16(A0[i]), y0 = mx_pk_lshr2_u16(A0[i] + (A0[i] << 1));
+                            const uint32_t x1 = mx_pk_lshr2_u16(A1[i]), y1 = mx_pk_lshr2_u16(A1[i] + (A1[i] << 1));
+                            U[i] = (yr & 1) ? y0 : x0, V[i] = (yr & 1) ? x1 : y1;
+                        }
+                        row[j] = mx_up_emit(U, V);
+                    }
+                    put_quad(q, row[0], row[1], row[2], row[3]);
+                }
+            }
+        } else {
+#pragma unroll 1
+            for (int q = 0; q < 4; ++q) {
+                uint2 row[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int yr = mx_reflect101(by + 4 * q + j, H2);
+                    uint32_t lo = 0, hi = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        lo |= mx_up_pixel(s, sstep, rows_s, cols_s, yr, mx_reflect101(bx + k, W2)) << (8 * k);
+                        hi |= mx_up_pixel(s, sstep, rows_s, cols_s, yr, mx_reflect101(bx + 4 + k, W2)) << (8 * k);
+                    }
+                    row[j] = make_uint2(lo, hi);
+                }
+                put_quad(q, row[0], row[1], row[2], row[3]);
+            }
+        }
+    }
+}
+
 // ---- fused lattice scan (initialKeypointDetection, Diff_of_Gauss.cpp:254-297, window 3) -------------------------------
 // The default path's k_extrema_w3 reads two thirds of the five DoG planes back from HBM (43 MB per 1080p frame).  Here a
 // wave evaluates the lattice sites of its own strip while the DoG rows are still in its LDS buffer: site (a, b) - padded
@@ -418,11 +560,13 @@ __device__ __forceinline__ void mx_level(const MxTaps<CFG>* __restrict__ taps, c
 
 // grid = (ceil(cols/TW), ceil(rows/TH), frames); block = CFG::NT; dynamic LDS = CFG::LDS_BYTES.
 // rows / cols arbitrary; `pitch` and `npitch` multiples of 16 (16-byte row stores), planes 16-byte aligned.
-template <class CFG, bool EXT>
+// UP2: `base` is the SOURCE frame (rows / 2 x cols / 2, dense rows of `pitch / 2`... see the launch: sstep) and the octave's base
+// is its 2x bilinear upsample, formed while the tile is staged (octave 0 of createPyramid).
+template <class CFG, bool EXT, bool UP2>
 __global__ __launch_bounds__(CFG::NT) void k_pyr_octave_mx(const uint8_t* __restrict__ base, size_t bframe, uint8_t* __restrict__ oct_out,
                                                            size_t pframe, int rows, int cols, int pitch,
                                                            const MxTaps<CFG>* __restrict__ taps, uint8_t* __restrict__ next_base,
-                                                           size_t nframe, int nrows, int ncols, int npitch, MxExtArgs ext) {
+                                                           size_t nframe, int nrows, int ncols, int npitch, MxExtArgs ext, int sstep) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     // XCD-aware tile order, as k_pyr_octave: every XCD walks one contiguous run of tiles (neighbours share halo lines in its L2)
     unsigned int bid = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
@@ -433,7 +577,10 @@ __global__ __launch_bounds__(CFG::NT) void k_pyr_octave_mx(const uint8_t* __rest
     const unsigned int by = rem / gridDim.x, bx = rem - by * gridDim.x;
     const int tile_x0 = bx * CFG::TW, tile_y0 = by * CFG::TH;
 
-    mx_stage_tile<CFG::TW, CFG::TH, CFG::R, CFG::RWP, CFG::NT>(base + fz * bframe, rows, cols, pitch, tile_x0, tile_y0, smem, 0x80808080u);
+    if constexpr (UP2)
+        mx_stage_tile_up2<CFG::TW, CFG::TH, CFG::R, CFG::RWP, CFG::NT>(base + fz * bframe, sstep, rows / 2, cols / 2, tile_x0, tile_y0, smem, 0x80808080u);
+    else
+        mx_stage_tile<CFG::TW, CFG::TH, CFG::R, CFG::RWP, CFG::NT>(base + fz * bframe, rows, cols, pitch, tile_x0, tile_y0, smem, 0x80808080u);
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

@@ -761,7 +761,7 @@ static int enqueue_pyr_octave(vslam_ctx* c, double sigma0, int o, const OctPlan&
 // The same octave through the matrix-core kernel (kernels_pyramid_mx.hip.h, vslam_mx.hip); `cfg` from mx_config_for.
 static int enqueue_pyr_octave_mx(vslam_ctx* c, int cfg, double sigma0, int o, const OctPlan& pl, const uint8_t* base, size_t bframe,
                                  uint8_t* oct_out, size_t pframe, int rows, int cols, int pitch, int nf, uint8_t* next_base, size_t nframe,
-                                 int nrows, int ncols, int npitch, const MxScan* scan) {
+                                 int nrows, int ncols, int npitch, const MxScan* scan, int up2_step = 0) {
     uint64_t sb;
     std::memcpy(&sb, &sigma0, 8);
     auto key = std::make_pair(sb, o);
@@ -780,7 +780,7 @@ static int enqueue_pyr_octave_mx(vslam_ctx* c, int cfg, double sigma0, int o, co
     hipError_t e;
     {
         TimedScope ts(c, "k_pyr_octave_mx");
-        e = mx_launch(cfg, c->stream, it->second, base, bframe, oct_out, pframe, rows, cols, pitch, nf, next_base, nframe, nrows, ncols, npitch, scan);
+        e = mx_launch(cfg, c->stream, it->second, base, bframe, oct_out, pframe, rows, cols, pitch, nf, next_base, nframe, nrows, ncols, npitch, scan, up2_step);
     }
     HIPCHK(c, e);
     return VSLAM_OK;
@@ -836,7 +836,8 @@ static int enqueue_dog(vslam_ctx* c, const vslam_params& p, const vslam_batch_la
                        size_t fstep, size_t fframe, int nf, uint8_t* pyr, size_t pframe, DogScratch& s,
                        unsigned long long* bits, bool do_extrema, vslam_point* points, unsigned int* counts,
                        hipStream_t side = nullptr, const std::function<int(int)>& after_list = nullptr,
-                       const std::function<int(int)>& after_octave = nullptr, hipStream_t up = nullptr, bool later_chunk = false) {
+                       const std::function<int(int)>& after_octave = nullptr, hipStream_t up = nullptr, bool later_chunk = false,
+                       bool bases_are_scratch = false) {
     // `side`: stream for the extrema scans and the list compaction (they only read what the
     // octave kernels wrote); ordered after the octave kernels by events.  nullptr = same stream.
     //
@@ -865,9 +866,17 @@ static int enqueue_dog(vslam_ctx* c, const vslam_params& p, const vslam_batch_la
     // waiting on ev_oct - so it waits for ev_chunk, recorded at the end of every chunk's main-stream work.
     // (quarters and eighths were measured again in round 3 with the side upsample at normal priority: 21.41 /
     // 21.44 ms against 21.29 for halves in the same configuration - no gain)
-    const int nf_a = (side && up && nf >= 64) ? nf / 2 : nf;
-    LAUNCH(c, "k_resize_linear2x_slide", k_resize_linear2x_slide, dim3(((p.cols + 3) / 4 + 255) / 256, (p.rows + 15) / 16, nf_a), dim3(256),
-           frames, fstep, fframe, s.bases + s.base_off[0], s.bases_frame, L.pitch[0], p.rows, p.cols, 16);
+    // Matrix path, batched entry (the octave bases are scratch nobody reads afterwards): octave 0's kernel forms its base from
+    // the frame while it stages a tile (kernels_pyramid_mx.hip.h: mx_stage_tile_up2) - no upsample kernel, no base in HBM.
+    const bool up2_fused = c->mx && bases_are_scratch && L.n_octaves > 0 && L.rows[0] == 2 * p.rows && L.cols[0] == 2 * p.cols && fstep <= 0x7fffffff &&
+                           [&] {
+                               const OctPlan pl0 = plan_octave(p.sigma0, 0, L.rows[0], L.cols[0]);
+                               return pl0.path != OctPath::Generic && mx_up2_supported(mx_config_for(pl0.ke));
+                           }();
+    const int nf_a = (!up2_fused && side && up && nf >= 64) ? nf / 2 : nf;
+    if (!up2_fused)
+        LAUNCH(c, "k_resize_linear2x_slide", k_resize_linear2x_slide, dim3(((p.cols + 3) / 4 + 255) / 256, (p.rows + 15) / 16, nf_a), dim3(256),
+               frames, fstep, fframe, s.bases + s.base_off[0], s.bases_frame, L.pitch[0], p.rows, p.cols, 16);
     if (nf_a < nf) {
         if (later_chunk) HIPCHK(c, hipStreamWaitEvent(up, c->ev_chunk, 0));
         StreamSwap sw(c, up);
@@ -912,6 +921,9 @@ static int enqueue_dog(vslam_ctx* c, const vslam_params& p, const vslam_batch_la
                     MxScan sc = scan;
                     sc.sitemap += (size_t)f_lo * s.site_frame;
                     sc.colmap += (size_t)f_lo * s.col_frame;
+                    if (o == 0 && up2_fused)
+                        return enqueue_pyr_octave_mx(c, cfg, p.sigma0, o, pl, frames + (size_t)f_lo * fframe, fframe, oc, pframe, rows, cols, pitch, n, nbh,
+                                                     s.bases_frame, nr, nc, np, fused_scan ? &sc : nullptr, (int)fstep);
                     return enqueue_pyr_octave_mx(c, cfg, p.sigma0, o, pl, b, s.bases_frame, oc, pframe, rows, cols, pitch, n, nbh, s.bases_frame, nr, nc, np,
                                                  fused_scan ? &sc : nullptr);
                 }
@@ -2101,7 +2113,7 @@ int vslam_detect_batch_dev(vslam_ctx* c, const vslam_params* pp, const uint8_t* 
                             out->extrema_bits ? (unsigned long long*)out->extrema_bits + (size_t)f0 * L.bits_frame_words : nullptr,
                             ext, out->dog_points ? out->dog_points + (size_t)f0 * p.dog_cap : nullptr,
                             out->dog_counts ? out->dog_counts + f0 : nullptr, sx, after_list, after_octave,
-                            use_aux ? c->aux[2] : nullptr, f0 > 0));
+                            use_aux ? c->aux[2] : nullptr, f0 > 0, /*bases_are_scratch=*/true));
             if (orient) {  // filterKeypoints behind the list, on the stream that produced it
                 StreamSwap sw(c, sx ? sx : c->stream);
                 TRY(enqueue_orient_batch(c, p, L, opl, nf, out->pyramid + (size_t)f0 * L.pyramid_frame_bytes, L.pyramid_frame_bytes,

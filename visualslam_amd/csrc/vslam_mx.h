@@ -30,9 +30,12 @@ inline int mx_seams(int cols) { return cols >= 2 ? (cols - 2) / 384 : 0; }
 bool mx_scan_supported(int cfg);
 // Raises the kernel's dynamic-LDS ceiling (once per device) and launches it on `stream`; scan = nullptr: no fused scan.
 hipError_t mx_prepare(int cfg);
+// up2_step > 0: `base` / `bframe` are the SOURCE frames (rows / 2 x cols / 2 pixels, `up2_step` bytes per row) and the octave's base is
+// their 2x bilinear upsample, formed while each tile is staged (configuration 1 only: octave 0 of createPyramid).
 hipError_t mx_launch(int cfg, hipStream_t stream, const void* d_table, const uint8_t* base, size_t bframe, uint8_t* oct_out, size_t pframe,
                      int rows, int cols, int pitch, int nf, uint8_t* next_base, size_t nframe, int nrows, int ncols, int npitch,
-                     const MxScan* scan);
+                     const MxScan* scan, int up2_step = 0);
+bool mx_up2_supported(int cfg);
 // bits / lflags: word 0 of frame 0's octave (bits may be nullptr).
 hipError_t mx_launch_pack(hipStream_t stream, const MxScan& scan, int rows, int wpr, int nf, unsigned long long* bits, unsigned long long* lflags,
                           size_t bframe);

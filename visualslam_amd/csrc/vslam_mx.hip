@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include "kernels_pyramid_mx.hip.h"
 
@@ -38,14 +39,20 @@ bool mx_pack(int cfg, const uint16_t* const taps[6], void* host_table) {
 }
 
 bool mx_scan_supported(int cfg) { return cfg == 1 || cfg == 2; }  // the configurations with a D buffer in LDS (MxCfg::DBUF)
+bool mx_up2_supported(int cfg) { return cfg == 1; }                // the reference's pyramid upsamples in front of octave 0 only
 
 template <class CFG>
 static hipError_t prepare() {
     if (CFG::DBUF) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pyr_octave_mx<CFG, CFG::DBUF != 0>), hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES);
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pyr_octave_mx<CFG, CFG::DBUF != 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES);
         if (e != hipSuccess) return e;
     }
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pyr_octave_mx<CFG, false>), hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES);
+    if (std::is_same<CFG, MxCfgOct0>::value) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pyr_octave_mx<MxCfgOct0, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pyr_octave_mx<MxCfgOct0, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES);
+        if (e != hipSuccess) return e;
+    }
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pyr_octave_mx<CFG, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES);
 }
 
 hipError_t mx_prepare(int cfg) {
@@ -55,17 +62,29 @@ hipError_t mx_prepare(int cfg) {
 
 template <class CFG>
 static hipError_t launch(hipStream_t stream, const void* d_table, const uint8_t* base, size_t bframe, uint8_t* oct_out, size_t pframe, int rows,
-                         int cols, int pitch, int nf, uint8_t* next_base, size_t nframe, int nrows, int ncols, int npitch, const MxScan* scan) {
+                         int cols, int pitch, int nf, uint8_t* next_base, size_t nframe, int nrows, int ncols, int npitch, const MxScan* scan, int up2_step) {
     const dim3 grid((cols + CFG::TW - 1) / CFG::TW, (rows + CFG::TH - 1) / CFG::TH, nf);
     MxExtArgs ext{};
+    if (up2_step > 0) {
+        if (!std::is_same<CFG, MxCfgOct0>::value || (rows & 1) || (cols & 1)) return hipErrorInvalidValue;
+        if (scan) {
+            ext = MxExtArgs{scan->sitemap, scan->mframe, scan->lat_rows, scan->lat_cols, scan->mpitch, scan->min_contrast, scan->colmap, scan->cframe, scan->nseams};
+            hipLaunchKernelGGL((k_pyr_octave_mx<MxCfgOct0, true, true>), grid, dim3(CFG::NT), CFG::LDS_BYTES, stream, base, bframe, oct_out, pframe, rows, cols, pitch,
+                               static_cast<const MxTaps<MxCfgOct0>*>(d_table), next_base, nframe, nrows, ncols, npitch, ext, up2_step);
+        } else {
+            hipLaunchKernelGGL((k_pyr_octave_mx<MxCfgOct0, false, true>), grid, dim3(CFG::NT), CFG::LDS_BYTES, stream, base, bframe, oct_out, pframe, rows, cols, pitch,
+                               static_cast<const MxTaps<MxCfgOct0>*>(d_table), next_base, nframe, nrows, ncols, npitch, ext, up2_step);
+        }
+        return hipGetLastError();
+    }
     if (scan && CFG::DBUF) {
         ext = MxExtArgs{scan->sitemap, scan->mframe, scan->lat_rows, scan->lat_cols, scan->mpitch, scan->min_contrast, scan->colmap, scan->cframe, scan->nseams};
-        hipLaunchKernelGGL((k_pyr_octave_mx<CFG, CFG::DBUF != 0>), grid, dim3(CFG::NT), CFG::LDS_BYTES, stream, base, bframe, oct_out, pframe, rows, cols, pitch,
-                           static_cast<const MxTaps<CFG>*>(d_table), next_base, nframe, nrows, ncols, npitch, ext);
+        hipLaunchKernelGGL((k_pyr_octave_mx<CFG, CFG::DBUF != 0, false>), grid, dim3(CFG::NT), CFG::LDS_BYTES, stream, base, bframe, oct_out, pframe, rows, cols, pitch,
+                           static_cast<const MxTaps<CFG>*>(d_table), next_base, nframe, nrows, ncols, npitch, ext, 0);
     } else {
         if (scan) return hipErrorInvalidValue;
-        hipLaunchKernelGGL((k_pyr_octave_mx<CFG, false>), grid, dim3(CFG::NT), CFG::LDS_BYTES, stream, base, bframe, oct_out, pframe, rows, cols, pitch,
-                           static_cast<const MxTaps<CFG>*>(d_table), next_base, nframe, nrows, ncols, npitch, ext);
+        hipLaunchKernelGGL((k_pyr_octave_mx<CFG, false, false>), grid, dim3(CFG::NT), CFG::LDS_BYTES, stream, base, bframe, oct_out, pframe, rows, cols, pitch,
+                           static_cast<const MxTaps<CFG>*>(d_table), next_base, nframe, nrows, ncols, npitch, ext, 0);
     }
     return hipGetLastError();
 }
@@ -81,11 +100,11 @@ hipError_t mx_launch_pack(hipStream_t stream, const MxScan& scan, int rows, int 
 }
 
 hipError_t mx_launch(int cfg, hipStream_t stream, const void* d_table, const uint8_t* base, size_t bframe, uint8_t* oct_out, size_t pframe,
-                     int rows, int cols, int pitch, int nf, uint8_t* next_base, size_t nframe, int nrows, int ncols, int npitch, const MxScan* scan) {
-    if (cfg == 1) return launch<MxCfgOct0>(stream, d_table, base, bframe, oct_out, pframe, rows, cols, pitch, nf, next_base, nframe, nrows, ncols, npitch, scan);
-    if (cfg == 2) return launch<MxCfgOct1>(stream, d_table, base, bframe, oct_out, pframe, rows, cols, pitch, nf, next_base, nframe, nrows, ncols, npitch, scan);
-    if (cfg == 3) return launch<MxCfgOct2>(stream, d_table, base, bframe, oct_out, pframe, rows, cols, pitch, nf, next_base, nframe, nrows, ncols, npitch, scan);
-    if (cfg == 4) return launch<MxCfgOct3>(stream, d_table, base, bframe, oct_out, pframe, rows, cols, pitch, nf, next_base, nframe, nrows, ncols, npitch, scan);
+                     int rows, int cols, int pitch, int nf, uint8_t* next_base, size_t nframe, int nrows, int ncols, int npitch, const MxScan* scan, int up2_step) {
+    if (cfg == 1) return launch<MxCfgOct0>(stream, d_table, base, bframe, oct_out, pframe, rows, cols, pitch, nf, next_base, nframe, nrows, ncols, npitch, scan, up2_step);
+    if (cfg == 2) return launch<MxCfgOct1>(stream, d_table, base, bframe, oct_out, pframe, rows, cols, pitch, nf, next_base, nframe, nrows, ncols, npitch, scan, up2_step);
+    if (cfg == 3) return launch<MxCfgOct2>(stream, d_table, base, bframe, oct_out, pframe, rows, cols, pitch, nf, next_base, nframe, nrows, ncols, npitch, scan, up2_step);
+    if (cfg == 4) return launch<MxCfgOct3>(stream, d_table, base, bframe, oct_out, pframe, rows, cols, pitch, nf, next_base, nframe, nrows, ncols, npitch, scan, up2_step);
     return hipErrorInvalidValue;
 }
 
