@@ -450,9 +450,8 @@ __device__ __forceinline__ void mx_level(const MxTaps<CFG>* __restrict__ taps, c
     for (int s = 0; s < NS; ++s) b1[s] = tcur[s], a2[s] = tcur[CFG::NSMAX + s];
     mx_v4i hi[NS], lo[NS];
     uint32_t dd[NOB][4] = {};  // the level's D values wait in registers while G passes through the wave's LDS buffer
-#pragma unroll
-    for (int ib = 0; ib < NIN; ++ib) {
-        // ---- pass 1 on input block ib: columns [-OFF + 32 ib, +32) of the strip, rows [-OFF, -OFF + 32 NS) ----
+    // pass 1 on input block ib: columns [-OFF + 32 ib, +32) of the strip, rows [-OFF, -OFF + 32 NS)
+    auto pass1 = [&](int ib) {
         mx_v16i c1 = {};
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
@@ -461,6 +460,11 @@ __device__ __forceinline__ void mx_level(const MxTaps<CFG>* __restrict__ taps, c
             for (int k = 0; k < 4; ++k) a[k] = (int)ln.lp[((R - OFF + 32 * s) / 4 + k) * RWP + (R - OFF + 32 * ib)];
             c1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b1[s], c1, 0, 0, 0);
         }
+        return c1;
+    };
+    mx_v16i c1 = pass1(0);
+#pragma unroll
+    for (int ib = 0; ib < NIN; ++ib) {
         // C1 = H - 32768 in [-32768, 32512]: signed high byte as it is, low byte - 128 (x ^ 0x80)
         const int slot = ib % NS;
 #pragma unroll
@@ -470,18 +474,23 @@ __device__ __forceinline__ void mx_level(const MxTaps<CFG>* __restrict__ taps, c
             lo[slot][d] = (int)(__builtin_amdgcn_perm(t23, t01, 0x05040100) ^ 0x80808080u);
             hi[slot][d] = (int)__builtin_amdgcn_perm(t23, t01, 0x07060302);
         }
-        if (ib < NS - 1) continue;
         const int ob = ib - (NS - 1);
-        if (!FULL && ob >= ln.nob_live) continue;  // wave-uniform: the block lies right of the image
-        // ---- pass 2 on output block ob ------------------------------------------------------------------------
+        const bool have_ob = ib >= NS - 1 && (FULL || ob < ln.nob_live);  // wave-uniform: the block exists and does not lie right of the image
+        // ---- pass 2 on output block ob; the NEXT input block's pass 1 is issued right behind it, in front of this block's
+        // epilogue: its MFMAs run in the matrix pipe while the vector unit packs and stores, and are finished when the
+        // next iteration's split asks for them
         mx_v16i chi = {}, clo;
+        if (have_ob) {
 #pragma unroll
-        for (int v = 0; v < 16; ++v) clo[v] = kLoInit;
+            for (int v = 0; v < 16; ++v) clo[v] = kLoInit;
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            chi = __builtin_amdgcn_mfma_i32_32x32x32_i8(a2[s], hi[(ob + s) % NS], chi, 0, 0, 0);
-            clo = __builtin_amdgcn_mfma_i32_32x32x32_i8(a2[s], lo[(ob + s) % NS], clo, 0, 0, 0);
+            for (int s = 0; s < NS; ++s) {
+                chi = __builtin_amdgcn_mfma_i32_32x32x32_i8(a2[s], hi[(ob + s) % NS], chi, 0, 0, 0);
+                clo = __builtin_amdgcn_mfma_i32_32x32x32_i8(a2[s], lo[(ob + s) % NS], clo, 0, 0, 0);
+            }
         }
+        if (ib + 1 < NIN) c1 = pass1(ib + 1);
+        if (!have_ob) continue;
         // ---- epilogue: register v = column 16 h + v of this lane's row --------------------------------------------
         uint32_t g[4];
 #pragma unroll
