@@ -567,9 +567,9 @@ def main():
             },
             "roofline": roof,
             "roofline_valu": valu,
-            "cpu_baseline": cpu_baseline(rows, cols, args.octaves, cs, gpu_kp_sample) if (world == 1 and args.cpu_sample > 0) else None,
+            "cpu_baseline": None,  # filled in below, after the C++ host's runs: 18 s of 64 busy OpenMP threads right in front of the
+                                   # host-fed pipeline cost it 10 % (11.3 k against 13.0 k stand-alone on the same box)
         }
-        leg("cpu_baseline")
     # The same workload driven by the C++ host (visualslam_amd/cxx: BatchDetector + Stream, RCCL from librccl,
     # no torch in that process): device-resident, and host-fed (pinned frames in, packed lists out).  Child
     # processes, after this process has released the GPU memory; N = 1 only; never part of `value`.
@@ -589,6 +589,9 @@ def main():
         if rank == 0:
             line["cxx_host"] = cxx
     leg("cxx_host")
+    if rank == 0 and world == 1 and args.cpu_sample > 0:
+        line["cpu_baseline"] = cpu_baseline(rows, cols, args.octaves, cs, gpu_kp_sample)
+    leg("cpu_baseline")
     if rank == 0:
         line["bench_wall_s"] = {k: round(v, 2) for k, v in wall.items()}
         print(json.dumps(line))
