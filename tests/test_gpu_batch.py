@@ -664,8 +664,10 @@ def test_matrix_core_octave_kernel_matches_oracle():
     env = dict(os.environ, VSLAM_MX="1")
     sel = ("random_shapes or ragged or tiny_frames or config2_and_3 or small_frames_all_outputs or matrix_kernel_is_dispatched "
            "or two_full_chunks or batch_on_the_reference_images")
+    sel += " or pyramid or golden_fixtures or filter_keypoints or feature_point_localization or process_gradients"  # the per-image API too
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_batch.py"),
-                        os.path.join(root, "tests", "test_gpu_ref_images.py"), "-m", "gpu", "-q", "-x", "-k", sel],
+                        os.path.join(root, "tests", "test_gpu_ref_images.py"), os.path.join(root, "tests", "test_gpu_parity.py"),
+                        "-m", "gpu", "-q", "-x", "-k", sel],
                        capture_output=True, text=True, timeout=1500, env=env, cwd=root)
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
