@@ -1,4 +1,8 @@
-"""One-off randomized parity soak of the batched path (not part of the test suite)."""
+"""One-off randomized parity soak of the batched path (not part of the test suite).
+
+    [VSLAM_MX=1] python tools/soak_batch.py <seed> <seconds> [big]
+`big`: frames up to 400 x 700 in batches of 1-9 (octave 0 up to 800 x 1400: several seams and straddling lattice rows of the
+matrix path's fused scan per frame); with VSLAM_MX=1 the whole sweep runs on the opt-in matrix path."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -9,8 +13,9 @@ ctx = capi.Context(0)
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 t0 = time.time(); it = 0
 while time.time() - t0 < (float(sys.argv[2]) if len(sys.argv) > 2 else 120):
-    rows, cols = int(rng.integers(17, 140)), int(rng.integers(17, 200))
-    n = int(rng.choice([1, 2, 5, 31, 32, 33, 63, 64, 65, 90]))
+    big = len(sys.argv) > 3 and sys.argv[3] == "big"
+    rows, cols = (int(rng.integers(17, 400)), int(rng.integers(17, 700))) if big else (int(rng.integers(17, 140)), int(rng.integers(17, 200)))
+    n = int(rng.choice([1, 2, 3, 9])) if big else int(rng.choice([1, 2, 5, 31, 32, 33, 63, 64, 65, 90]))
     n_oct = int(rng.integers(1, max(1, min(4, capi.auto_num_octaves(rows, cols))) + 1))
     mode = int(rng.integers(0, 3))
     kinds = ["checker", "noise"]
@@ -55,6 +60,6 @@ while time.time() - t0 < (float(sys.argv[2]) if len(sys.argv) > 2 else 120):
             want = np.concatenate([out[key][f][: m[f]] for f in range(n)]).reshape(-1)
             assert rec.view(np.int32).reshape(-1).tobytes() == want.astype(np.int32).tobytes()
     it += 1
-    if it % 500 == 0:
+    if it % (25 if big else 500) == 0:
         print(f"... {it} cases, {time.time() - t0:.0f} s", flush=True)  # gpurun takes a silent run for a hung one
-print("soak ok", it, "cases")
+print("soak ok", it, "cases", "(matrix path)" if ctx.matrix_path() else "(default path)")
