@@ -1,4 +1,4 @@
-// Exhaustive check of sqrt_rn_small (visualslam_amd/csrc/kernels_generic.hip.h): for every argument the
+// Exhaustive check of sqrt_rn_small and sqrt_rn_small_pk (visualslam_amd/csrc/kernels_generic.hip.h): for every argument the
 // library can form - x*x + y*y of integer Sobel differences, integers 0 .. 2*255^2 - it must equal the
 // correctly rounded f32 square root (f64 sqrt rounded once: 53 >= 2*24 + 2 bits).  Prints the number of
 // mismatches; exit code 0 iff none.
@@ -15,7 +15,10 @@ __global__ void k_check(int n, unsigned int* bad, float* first) {
     if (i > n) return;
     const float x = (float)i;
     const float a = vslam::sqrt_rn_small(x), b = (float)sqrt((double)x);
-    if (__float_as_uint(a) != __float_as_uint(b)) {
+    // the packed form (k_orient_survivors_pk), the argument in either half beside another one
+    const vslam::vslam_f2 p = vslam::sqrt_rn_small_pk(vslam::vslam_f2{x, (float)(n - i)});
+    const float c = (float)sqrt((double)(n - i));
+    if (__float_as_uint(a) != __float_as_uint(b) || __float_as_uint(p.x) != __float_as_uint(b) || __float_as_uint(p.y) != __float_as_uint(c)) {
         if (atomicAdd(bad, 1u) == 0) *first = x;
     }
 }

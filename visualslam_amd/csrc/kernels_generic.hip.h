@@ -37,6 +37,22 @@ __device__ __forceinline__ float sqrt_rn_small(float x) {
     return s;
 }
 
+// The same square root for two arguments at once in packed-f32 form (gfx90a+: v_pk_mul_f32 / v_pk_fma_f32 do two
+// lanes' worth per issue): r = rsq(max(x, tiny)) (within one ulp), s = x * r, then ONE Newton step on the exact
+// residual, s' = fma(fma(-s, s, x), r / 2, s).  6 issue slots per PAIR instead of 18.  That this is the correctly
+// rounded root for every argument the library can form is checked exhaustively by tools/sqrt_check.hip (on the GPU:
+// it depends on this chip's v_rsq_f32); x = 0 gives s = 0 * rsq(tiny) = 0 and a zero residual.
+typedef float vslam_f2 __attribute__((ext_vector_type(2)));
+typedef float vslam_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ vslam_f2 sqrt_rn_small_pk(vslam_f2 x) {
+    vslam_f2 r;
+    r.x = __builtin_amdgcn_rsqf(fmaxf(x.x, 1e-30f));
+    r.y = __builtin_amdgcn_rsqf(fmaxf(x.y, 1e-30f));
+    const vslam_f2 s = x * r, h = r * 0.5f;
+    const vslam_f2 e = __builtin_elementwise_fma(-s, s, x);
+    return __builtin_elementwise_fma(e, h, s);
+}
+
 // cv::convertScaleAbs element as the reference's x86-64 OpenCV evaluates it: cvRound (cvtss2si /
 // cvtps2dq, round half even) returns INT_MIN for NaN and for |x| >= 2^31, which
 // saturate_cast<uchar> maps to 0; [255.5, 2^31) saturates to 255.

@@ -22,6 +22,7 @@
 #include "kernels_harris_strip.hip.h"
 #include "kernels_orient.hip.h"
 #include "kernels_orient_batch.hip.h"
+#include "kernels_orient_pk.hip.h"
 #include "kernels_compact.hip.h"
 #include "kernels_sift.hip.h"
 #include "kernels_extrema_dense.hip.h"
@@ -60,6 +61,7 @@ struct vslam_ctx {
     std::map<std::pair<uint64_t, int>, void*> tile_taps;        // (sigma0 bits, octave) -> PyrTaps<CFG>
     // OPT-IN matrix-core form of the LDS-tiled octave kernels (VSLAM_MX=1 / vslam_ctx_set_matrix_path): never the default
     bool mx = false;
+    bool orient_scalar_form = false;  // VSLAM_ORIENT_SCALAR=1: k_orient_survivors for every octave (the round-3 form, kept for comparison)
     std::map<std::pair<uint64_t, int>, void*> mx_taps;          // (sigma0 bits, octave) -> MxTaps<CFG>
     // auxiliary streams of the batched path: the HBM-bound chains (Harris; extrema + compaction)
     // run beside the VALU-bound pyramid kernels; forked from / joined to `stream` by events
@@ -1117,6 +1119,8 @@ int vslam_ctx_create(int device, void* stream, vslam_ctx** out) {
     {
         const char* e = std::getenv("VSLAM_MX");
         c->mx = e && e[0] == '1';
+        const char* es = std::getenv("VSLAM_ORIENT_SCALAR");
+        c->orient_scalar_form = es && es[0] == '1';
         const char* t = std::getenv("VSLAM_STREAM_TUNER");
         c->tuner.enabled = t && t[0] == '1';
     }
@@ -1828,6 +1832,10 @@ static int get_orient_taps(vslam_ctx* c, double sigma, const float** out, int* n
     if (it == c->orient_taps.end()) {
         std::vector<float> t;
         if (!gauss_kernel_f32(n, sigma, t)) return fail(c, VSLAM_ERR_INVALID, "filterKeypoints: bad blur kernel");
+        // behind the taps: the zero-padded row / column forms k_orient_survivors_pk reads through scalar loads
+        t.resize((size_t)orient_taps_pk_floats(n), 0.0f);
+        for (int i = 0; i < n; ++i) t[(size_t)orient_taps_row_off(n) + 3 + i] = t[(size_t)i];
+        for (int i = 1; i <= n / 2; ++i) t[(size_t)orient_taps_col_off(n) + i - 1] = t[(size_t)(n / 2 + i)];
         float* d = nullptr;
         HIPCHK(c, hipMalloc((void**)&d, 4 * t.size()));
         HIPCHK(c, hipMemcpy(d, t.data(), 4 * t.size(), hipMemcpyHostToDevice));
@@ -1875,6 +1883,7 @@ static int orient_scratch_take(vslam_ctx* c, const vslam_params& p, int nf, Orie
 struct OrientPlan {
     OrientBatchGeom g;
     int need[VSLAM_MAX_OCTAVES] = {};  // LDS floats of octave o's launch of k_orient_survivors
+    int smax[VSLAM_MAX_OCTAVES] = {};  // largest span (16 + 2 R) of the octave's levels: <= OR_PK_MAX_SPAN -> k_orient_survivors_pk
 };
 static int make_orient_plan(vslam_ctx* c, const vslam_params& p, const vslam_batch_layout& L, OrientPlan& pl) {
     OrientBatchGeom& g = pl.g;
@@ -1893,6 +1902,7 @@ static int make_orient_plan(vslam_ctx* c, const vslam_params& p, const vslam_bat
             // maps + taps + strip + region + the u8 patch of interior survivors (k_orient_survivors)
             worst = std::max(worst, 3 * span + span * OR_WIN + span * span + (span + 2) * ((span + 8) >> 2));
             strip = std::max(strip, span * (OR_WIN + 3));
+            pl.smax[o] = std::max(pl.smax[o], span);
         }
         // regions that exceed even the big budget are read tap by tap; the strip, the maps and the taps still need room
         pl.need[o] = worst <= kBigLds ? worst : std::max(strip, std::min(worst, kBigLds));
@@ -1941,6 +1951,11 @@ static int enqueue_orient_batch(vslam_ctx* c, const vslam_params& p, const vslam
     const int gwg = (int)std::min<long>(1024, std::max<long>(16, 8192 / nf));
     for (int o = 0; o < L.n_octaves; ++o) {  // one launch per octave: its own survivors, its own LDS footprint
         TimedScope ts(c, "k_orient_survivors");
+        if (pl.smax[o] <= OR_PK_MAX_SPAN && !c->orient_scalar_form) {  // the fine octaves: packed-f32 form, two waves per survivor
+            hipLaunchKernelGGL(k_orient_survivors_pk, dim3(2 * gwg, nf), dim3(128), (size_t)orient_pk_lds_floats(pl.smax[o]) * 4, c->stream, points,
+                               p.dog_cap, s.surv, s.ranges, (unsigned int)scap, pyr, pframe, g, pl.smax[o], o, s.masks);
+            continue;
+        }
         hipLaunchKernelGGL(k_orient_survivors, dim3(gwg, nf), dim3(256), (size_t)pl.need[o] * 4, c->stream, points, p.dog_cap, s.surv, s.ranges,
                            (unsigned int)scap, pyr, pframe, g, pl.need[o], o, s.masks);
     }
