@@ -55,6 +55,7 @@ def main():
             res.update(step_ms_localize=dt * 1e3)
         del out
     print(json.dumps(res))
+    ctx.close()
 
 
 if __name__ == "__main__":

@@ -80,26 +80,39 @@ __device__ __forceinline__ float magnitude_at(const uint8_t* __restrict__ G, int
     return sqrt_rn_small(xx + yy);  // correctly rounded f32 square root
 }
 
-// The survivor list of a frame is in list order, i.e. octave by octave: ranges[f][o] = index of the first survivor whose
-// octave is >= o (o = 0 .. n_oct; ranges[f][n_oct] = the survivor count).  grid = (frames), 64 threads: lane o searches
-// boundary o.  One launch of k_orient_survivors per octave then takes exactly its own survivors with the LDS budget of
-// that octave (round 2 ran two launches that each walked the whole list and skipped the other's octaves - two dependent
-// loads per skipped survivor - and gave octave 0 the LDS footprint of octave 1: 3 workgroups per CU instead of 8).
-__global__ __launch_bounds__(64) void k_survivor_ranges(const vslam_point* __restrict__ pts, unsigned int cap, const unsigned int* __restrict__ surv,
-                                                         const unsigned int* __restrict__ scounts, unsigned int scap, int n_oct,
-                                                         unsigned int* __restrict__ ranges) {
-    const int f = blockIdx.x, o = threadIdx.x;
-    if (o > n_oct) return;
+// The survivor list of a frame is in list order, i.e. octave by octave and, inside an octave, level by level
+// (initialKeypointDetection's loops, Diff_of_Gauss.cpp:264-267).  ranges[f][o] = index of the first survivor whose octave is
+// >= o (o = 0 .. n_oct; ranges[f][n_oct] = the survivor count); ranges[f][OR_LEVEL_RANGES + 4 o + j] = the first one at or
+// past (octave o, level j + 1), j = 0 .. 3 (j = 3: the next octave's first).  grid = (frames), 128 threads, one boundary
+// each.  One launch of k_orient_survivors per octave - of k_orient_survivors_pk per octave and level - then takes exactly
+// its own survivors with the LDS budget of that octave / level (round 2 ran two launches that each walked the whole list
+// and skipped the other's octaves - two dependent loads per skipped survivor - and gave octave 0 the LDS footprint of
+// octave 1: 3 workgroups per CU instead of 8).
+constexpr int OR_LEVEL_RANGES = VSLAM_MAX_OCTAVES + 1;
+constexpr int OR_RANGE_STRIDE = OR_LEVEL_RANGES + 4 * VSLAM_MAX_OCTAVES;
+__global__ __launch_bounds__(128) void k_survivor_ranges(const vslam_point* __restrict__ pts, unsigned int cap, const unsigned int* __restrict__ surv,
+                                                          const unsigned int* __restrict__ scounts, unsigned int scap, int n_oct,
+                                                          unsigned int* __restrict__ ranges) {
+    const int f = blockIdx.x, t = threadIdx.x;
+    int ko, kl;  // the boundary's key
+    if (t <= n_oct) {
+        ko = t, kl = 0;
+    } else if (t >= OR_LEVEL_RANGES && t - OR_LEVEL_RANGES < 4 * n_oct) {
+        ko = (t - OR_LEVEL_RANGES) >> 2, kl = ((t - OR_LEVEL_RANGES) & 3) + 1;
+    } else {
+        return;
+    }
     const unsigned int ns = min(scounts[f], scap);
-    unsigned int lo = 0, hi = ns;  // first index with octave >= o
+    unsigned int lo = 0, hi = ns;  // first index with (octave, level) >= (ko, kl)
     while (lo < hi) {
         const unsigned int mid = (lo + hi) >> 1;
-        if (pts[(size_t)f * cap + surv[(size_t)f * scap + mid]].octave >= o)
+        const vslam_point q = pts[(size_t)f * cap + surv[(size_t)f * scap + mid]];
+        if (q.octave > ko || (q.octave == ko && q.level >= kl))
             hi = mid;
         else
             lo = mid + 1;
     }
-    ranges[(size_t)f * (VSLAM_MAX_OCTAVES + 1) + o] = lo;
+    ranges[(size_t)f * OR_RANGE_STRIDE + t] = lo;
 }
 
 // grid = (G, frames), 256 threads, dynamic LDS = lds_floats * 4 bytes (row / column maps + taps + strip + region + patch);
@@ -113,7 +126,7 @@ __global__ __launch_bounds__(256) void k_orient_survivors(const vslam_point* __r
     __shared__ float mw[OR_WIN * OR_WIN];
     __shared__ unsigned long long binmask[OR_BINS][4];  // per bin, per wave: which of the wave's 64 pixels fall into it
     const int f = blockIdx.y;
-    const unsigned int k_begin = ranges[(size_t)f * (VSLAM_MAX_OCTAVES + 1) + oct], k_end = ranges[(size_t)f * (VSLAM_MAX_OCTAVES + 1) + oct + 1];
+    const unsigned int k_begin = ranges[(size_t)f * OR_RANGE_STRIDE + oct], k_end = ranges[(size_t)f * OR_RANGE_STRIDE + oct + 1];
     // the next survivor's record is fetched while the current one is processed (two dependent loads: index, record)
     vslam_point kp_next{};
     if (k_begin + blockIdx.x < k_end) kp_next = pts[(size_t)f * cap + surv[(size_t)f * scap + k_begin + blockIdx.x]];

@@ -79,35 +79,42 @@ __host__ __device__ inline int orient_taps_col_off(int n) { return orient_taps_r
 __host__ __device__ inline int orient_taps_pk_floats(int n) { return orient_taps_col_off(n) + (((n >> 1) + 3) & ~3) + 4; }
 
 constexpr int OR_PK_MAX_SPAN = 60;  // 16 four-column groups cover byte sh + span of a patch row (sh <= 3)
-// LDS floats of a launch whose largest span is smax (even, <= OR_PK_MAX_SPAN): magnitude region as row pairs, patch / strip overlay, window
-// weights, bin masks.
-__host__ __device__ inline int orient_pk_mp(int smax) { return (smax + 11) | 1; }           // 8-byte words per row pair (odd: bank spread)
-__host__ __device__ inline int orient_pk_pp(int smax) { return (((smax + 8) >> 2) + 2) | 1; }  // dwords per patch row, one pad dword either side
-__host__ __device__ inline int orient_pk_m2_floats(int smax) { return ((smax >> 1) * orient_pk_mp(smax) * 2 + 3) & ~3; }  // what follows stays 16-byte aligned
-__host__ __device__ inline int orient_pk_lds_floats(int smax) {
-    const int m2 = orient_pk_m2_floats(smax), patch = (smax + 2) * orient_pk_pp(smax), strip = smax * OR_WIN;
-    return m2 + (patch > strip ? patch : strip) + OR_WIN * OR_WIN + OR_BINS * 4 * 2;
+// LDS floats of a launch for one level's span (even, <= OR_PK_MAX_SPAN): magnitude region as row pairs (the window's
+// weights take its place once the row pass has read it), patch / strip overlay, bin masks.  One launch per level: 11 / 14 /
+// 18 KB for the three levels of octave 0 = 14 / 11 / 9 workgroups per CU, where one launch per octave had 8.
+__host__ __device__ inline int orient_pk_mp(int span) { return span + 7; }                     // 8-byte words per row pair: the row pass reads up to column span + 6; odd: bank spread
+__host__ __device__ inline int orient_pk_pp(int span) { return (((span + 8) >> 2) + 2) | 1; }  // dwords per patch row, one pad dword either side
+__host__ __device__ inline int orient_pk_m2_floats(int span) { return ((span >> 1) * orient_pk_mp(span) * 2 + 3) & ~3; }  // what follows stays 16-byte aligned
+__host__ __device__ inline int orient_pk_lds_floats(int span) {
+    const int m2 = orient_pk_m2_floats(span), patch = (span + 2) * orient_pk_pp(span), strip = span * OR_WIN;
+    return m2 + (patch > strip ? patch : strip) + OR_BINS * 4 * 2;
 }
 
-// grid = (G, frames), 128 threads, dynamic LDS = orient_pk_lds_floats(smax) * 4 bytes; the survivors of octave `oct`.
+// grid = (G, frames), 128 threads, dynamic LDS = orient_pk_lds_floats(span of the level) * 4 bytes; the survivors of
+// (octave `oct`, level `level`) (k_survivor_ranges).
 __global__ __launch_bounds__(128) void k_orient_survivors_pk(const vslam_point* __restrict__ pts, unsigned int cap,
                                                               const unsigned int* __restrict__ surv, const unsigned int* __restrict__ ranges,
                                                               unsigned int scap, const uint8_t* __restrict__ pyr, size_t pframe,
-                                                              OrientBatchGeom g, int smax, int oct, unsigned long long* __restrict__ masks) {
+                                                              OrientBatchGeom g, int oct, int level, unsigned long long* __restrict__ masks) {
     extern __shared__ __attribute__((aligned(16))) float orient_smem[];
-    const int MP = orient_pk_mp(smax), PP = orient_pk_pp(smax);
+    const int o = oct;
+    const int kn = g.kn[o][level], R = kn >> 1, span = OR_WIN + 2 * R, hs = span >> 1, pdw = (span + 2 + 6) >> 2;
+    const int MP = orient_pk_mp(span), PP = orient_pk_pp(span);
     vslam_f2* const M2 = reinterpret_cast<vslam_f2*>(orient_smem);                 // [span / 2][MP] {row 2p, row 2p + 1}
-    float* const ov = orient_smem + orient_pk_m2_floats(smax);                       // patch, then the row-filtered strip
+    float* const mw = orient_smem;                                                 // [16][16] blurred magnitudes of the window: written when the region has been read
+    float* const ov = orient_smem + orient_pk_m2_floats(span);                     // patch, then the row-filtered strip
     uint32_t* const Pw = reinterpret_cast<uint32_t*>(ov);                          // [span + 2][PP]
     float* const rb = ov;                                                          // [span][16]
-    const int ovf = max((smax + 2) * PP, smax * OR_WIN);
-    float* const mw = ov + ovf;                                                    // [16][16] blurred magnitudes of the window
-    unsigned long long* const binmask = reinterpret_cast<unsigned long long*>(mw + OR_WIN * OR_WIN);  // [36][4]
+    const int ovf = max((span + 2) * PP, span * OR_WIN);
+    unsigned long long* const binmask = reinterpret_cast<unsigned long long*>(ov + ovf);  // [36][4]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int f = blockIdx.y, o = oct;
-    const unsigned int k_begin = ranges[(size_t)f * (VSLAM_MAX_OCTAVES + 1) + oct], k_end = ranges[(size_t)f * (VSLAM_MAX_OCTAVES + 1) + oct + 1];
+    const int f = blockIdx.y;
+    const unsigned int k_begin = ranges[(size_t)f * OR_RANGE_STRIDE + OR_LEVEL_RANGES + 4 * oct + level - 1],
+                       k_end = ranges[(size_t)f * OR_RANGE_STRIDE + OR_LEVEL_RANGES + 4 * oct + level];
     const int rows = g.rows[o], cols = g.cols[o], gpitch = g.pitch[o];
     const int prows = rows + 2 * OR_PAD, pcols = cols + 2 * OR_PAD;
+    const uint8_t* __restrict__ G = pyr + f * pframe + g.oct_off[o] + (size_t)level * rows * gpitch;
+    const float* __restrict__ kt = g.kern[o][level];
     unsigned int nsel[6];
 #pragma unroll
     for (int b = 0; b < 6; ++b) nsel[b] = ((lane >> b) & 1) ? 0u : ~0u;
@@ -115,27 +122,25 @@ __global__ __launch_bounds__(128) void k_orient_survivors_pk(const vslam_point* 
     // trip - a good part of a survivor's whole time - runs beside the previous survivor's passes.  So the records are
     // fetched two ahead.
     struct Geo {
-        int level, x, y, kn, R, span, pdw, py0, px0, sh;
+        int x, y, py0, px0, sh;
         bool interior;
     };
     auto geo_of = [&](const vslam_point& r) {
         Geo q;
-        q.level = __builtin_amdgcn_readfirstlane(r.level), q.x = __builtin_amdgcn_readfirstlane(r.col), q.y = __builtin_amdgcn_readfirstlane(r.row);
-        q.kn = g.kn[o][q.level], q.R = q.kn >> 1, q.span = OR_WIN + 2 * q.R, q.pdw = (q.span + 2 + 6) >> 2;
-        q.py0 = q.y - q.R - OR_PAD - 1, q.px0 = q.x - q.R - OR_PAD - 1;  // image coordinates of the patch origin
-        q.interior = q.py0 >= 0 && q.px0 >= 0 && q.py0 + q.span + 2 <= rows && q.px0 + q.span + 2 <= cols;
+        q.x = __builtin_amdgcn_readfirstlane(r.col), q.y = __builtin_amdgcn_readfirstlane(r.row);  // the record is the same in every lane
+        q.py0 = q.y - R - OR_PAD - 1, q.px0 = q.x - R - OR_PAD - 1;  // image coordinates of the patch origin
+        q.interior = q.py0 >= 0 && q.px0 >= 0 && q.py0 + span + 2 <= rows && q.px0 + span + 2 <= cols;
         q.sh = q.interior ? (q.px0 & 3) : 0;  // region column cc is column cc + sh + 1 of M2 and byte cc + sh + 1 of a patch row
         return q;
     };
     constexpr int PDW_MAX = (OR_PK_MAX_SPAN + 8) >> 2;
     uint32_t pre[PDW_MAX];
     auto fetch_patch = [&](const Geo& q) {  // wave 1, lane = patch row
-        if (q.interior && lane < q.span + 2) {
-            const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(pyr + f * pframe + g.oct_off[o] + (size_t)q.level * rows * gpitch +
-                                                                                 (size_t)(q.py0 + lane) * gpitch + (q.px0 - q.sh));  // pitch % 16 == 0
+        if (q.interior && lane < span + 2) {
+            const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(G + (size_t)(q.py0 + lane) * gpitch + (q.px0 - q.sh));  // pitch % 16 == 0
 #pragma unroll
             for (int d = 0; d < PDW_MAX; ++d)
-                if (d < q.pdw) pre[d] = src[d];
+                if (d < pdw) pre[d] = src[d];
         }
     };
     unsigned int k = k_begin + blockIdx.x;
@@ -150,12 +155,9 @@ __global__ __launch_bounds__(128) void k_orient_survivors_pk(const vslam_point* 
         const vslam_point kp = rec0;
         rec0 = rec1;
         if (k + 2 * gridDim.x < k_end) rec1 = pts[(size_t)f * cap + surv[(size_t)f * scap + k + 2 * gridDim.x]];
-        // the record is the same in every lane: scalar registers for everything derived from it
         const Geo cur = geo_of(kp);
-        const int level = cur.level, x = cur.x, y = cur.y, kn = cur.kn, R = cur.R, span = cur.span, hs = span >> 1, sh = cur.sh;
+        const int x = cur.x, y = cur.y, sh = cur.sh;
         const bool interior = cur.interior;
-        const uint8_t* __restrict__ G = pyr + f * pframe + g.oct_off[o] + (size_t)level * rows * gpitch;
-        const float* __restrict__ kt = g.kern[o][level];
         // ---- [A] wave 1: this survivor's patch from its registers to the LDS, the next one's loads; wave 0: the previous
         // survivor's histogram and peaks
         if (wave == 1) {
@@ -163,7 +165,7 @@ __global__ __launch_bounds__(128) void k_orient_survivors_pk(const vslam_point* 
                 uint32_t* dst = Pw + lane * PP + 1;
 #pragma unroll
                 for (int d = 0; d < PDW_MAX; ++d)
-                    if (d < cur.pdw) dst[d] = pre[d];
+                    if (d < pdw) dst[d] = pre[d];
             }
             if (k + gridDim.x < k_end) fetch_patch(geo_of(rec0));
         } else if (has_prev) {

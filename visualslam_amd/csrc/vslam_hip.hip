@@ -1853,7 +1853,7 @@ struct OrientScratch {
     unsigned long long* masks = nullptr;  // [nf][scap] histogram-peak masks
     unsigned int* cws = nullptr;          // compaction scratch
     unsigned int* obegin = nullptr;       // [nf] list length after octave 0 (the early edge-test launch covers [0, obegin))
-    unsigned int* ranges = nullptr;       // [nf][VSLAM_MAX_OCTAVES + 1] first survivor of each octave (k_survivor_ranges)
+    unsigned int* ranges = nullptr;       // [nf][OR_RANGE_STRIDE] first survivor of each octave, of each (octave, level) (k_survivor_ranges)
     bool early_done = false;              // the early launch has been enqueued for this chunk
     bool early_forked = false;            // ... on another stream: ev_edge marks its end
     size_t fwords = 0;
@@ -1861,7 +1861,7 @@ struct OrientScratch {
 static size_t orient_scratch_bytes(const vslam_params& p, int nf) {
     const size_t fwords = ((size_t)p.dog_cap + 63) / 64, scap = p.oriented_cap;
     return ws_need((size_t)nf * fwords * 8) + ws_need((size_t)nf * scap * 4) + 2 * ws_need((size_t)nf * 4) + ws_need((size_t)nf * scap * 8) +
-           ws_need((size_t)nf * (VSLAM_MAX_OCTAVES + 1) * 4) +
+           ws_need((size_t)nf * OR_RANGE_STRIDE * 4) +
            ws_need(4 * compaction_ws_elems(std::max(fwords, scap), nf));
 }
 static int orient_scratch_take(vslam_ctx* c, const vslam_params& p, int nf, OrientScratch& s) {
@@ -1871,7 +1871,7 @@ static int orient_scratch_take(vslam_ctx* c, const vslam_params& p, int nf, Orie
     s.surv = ws_take<unsigned int>(c, (size_t)nf * scap);
     s.scounts = ws_take<unsigned int>(c, nf);
     s.obegin = ws_take<unsigned int>(c, nf);
-    s.ranges = ws_take<unsigned int>(c, (size_t)nf * (VSLAM_MAX_OCTAVES + 1));
+    s.ranges = ws_take<unsigned int>(c, (size_t)nf * OR_RANGE_STRIDE);
     s.early_done = false;
     s.masks = ws_take<unsigned long long>(c, (size_t)nf * scap);
     s.cws = ws_take<unsigned int>(c, compaction_ws_elems(std::max(s.fwords, scap), nf));
@@ -1946,14 +1946,18 @@ static int enqueue_orient_batch(vslam_ctx* c, const vslam_params& p, const vslam
            (const unsigned int*)(s.early_done ? s.obegin : nullptr), counts, p.dog_cap, pyr, pframe, g, s.flags, fw);
     SurvivorEntries se{s.flags, fw, s.surv};
     TRY(enqueue_compaction(c, se, fw, nf, s.cws, (unsigned int)scap, s.scounts, 0));
-    LAUNCH(c, "k_survivor_ranges", k_survivor_ranges, dim3(nf), dim3(64), points, p.dog_cap, s.surv, s.scounts, (unsigned int)scap, L.n_octaves, s.ranges);
+    LAUNCH(c, "k_survivor_ranges", k_survivor_ranges, dim3(nf), dim3(128), points, p.dog_cap, s.surv, s.scounts, (unsigned int)scap, L.n_octaves, s.ranges);
     TRY(raise_dyn_lds(c, reinterpret_cast<const void*>(&k_orient_survivors)));
     const int gwg = (int)std::min<long>(1024, std::max<long>(16, 8192 / nf));
     for (int o = 0; o < L.n_octaves; ++o) {  // one launch per octave: its own survivors, its own LDS footprint
         TimedScope ts(c, "k_orient_survivors");
-        if (pl.smax[o] <= OR_PK_MAX_SPAN && !c->orient_scalar_form) {  // the fine octaves: packed-f32 form, two waves per survivor
-            hipLaunchKernelGGL(k_orient_survivors_pk, dim3(2 * gwg, nf), dim3(128), (size_t)orient_pk_lds_floats(pl.smax[o]) * 4, c->stream, points,
-                               p.dog_cap, s.surv, s.ranges, (unsigned int)scap, pyr, pframe, g, pl.smax[o], o, s.masks);
+        if (pl.smax[o] <= OR_PK_MAX_SPAN && !c->orient_scalar_form) {  // the fine octaves: packed-f32 form, two waves per survivor, one launch per level
+            // 8 gwg workgroups per frame (256 at 256 frames): ~20 survivors each on a dense frame.  With 2 gwg (80 each) the
+            // launch ended on a long tail of half-empty CUs: 9.0 ms of these launches per 256-frame step against 8.4
+            constexpr int pk_mult = 8;
+            for (int l = 1; l <= 3; ++l)
+                hipLaunchKernelGGL(k_orient_survivors_pk, dim3(pk_mult * gwg, nf), dim3(128), (size_t)orient_pk_lds_floats(OR_WIN + 2 * (g.kn[o][l] / 2)) * 4,
+                                   c->stream, points, p.dog_cap, s.surv, s.ranges, (unsigned int)scap, pyr, pframe, g, o, l, s.masks);
             continue;
         }
         hipLaunchKernelGGL(k_orient_survivors, dim3(gwg, nf), dim3(256), (size_t)pl.need[o] * 4, c->stream, points, p.dog_cap, s.surv, s.ranges,
