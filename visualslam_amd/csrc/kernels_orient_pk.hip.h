@@ -100,6 +100,7 @@ __global__ __launch_bounds__(128) void k_orient_survivors_pk(const vslam_point* 
     const int o = oct;
     const int kn = g.kn[o][level], R = kn >> 1, span = OR_WIN + 2 * R, hs = span >> 1, pdw = (span + 2 + 6) >> 2;
     const int MP = orient_pk_mp(span), PP = orient_pk_pp(span);
+    const int GQ = ((span + 3) >> 2) + 1, gq_inv = 65536 / GQ + 1;
     vslam_f2* const M2 = reinterpret_cast<vslam_f2*>(orient_smem);                 // [span / 2][MP] {row 2p, row 2p + 1}
     float* const mw = orient_smem;                                                 // [16][16] blurred magnitudes of the window: written when the region has been read
     float* const ov = orient_smem + orient_pk_m2_floats(span);                     // patch, then the row-filtered strip
@@ -192,8 +193,10 @@ __global__ __launch_bounds__(128) void k_orient_survivors_pk(const vslam_point* 
         __syncthreads();
         // ---- [B] magnitudes of the region, and the histogram bin of every window pixel
         if (interior) {
-            for (int it = tid; it < hs * 16; it += 128) {
-                const int gq = it & 15, rp = it >> 4;
+            // GQ four-column groups reach byte span + 3 of a patch row (sh <= 3); it = rp * GQ + gq, the division by the launch's
+            // constant as a multiplication (it < 2^10, GQ <= 16: exact)
+            for (int it = tid; it < hs * GQ; it += 128) {
+                const int rp = (it * gq_inv) >> 16, gq = it - rp * GQ;
                 if (4 * gq > sh + span) continue;  // columns past the region
                 const uint32_t* P = Pw + (2 * rp) * PP + gq;  // dword gq - 1 of patch row 2 rp (one pad dword in front)
                 const uint32_t A = P[1], Bl = P[PP], Bm = P[PP + 1], Br = P[PP + 2], Cl = P[2 * PP], Cm = P[2 * PP + 1], Cr = P[2 * PP + 2], D = P[3 * PP + 1];
