@@ -836,3 +836,35 @@ def test_config4_full_batch_256_frames_1080p(env):
     assert hc[2] == 0 and dc[2] == 0 and not bool(o["response"][2].any()) and not bool(o["nms_mask"][2].any())
     bits = o["extrema_bits"][2].cpu().numpy().view(np.uint64)
     assert int(np.unpackbits(bits.view(np.uint8)).sum()) == 3_672_000
+
+
+def test_orientation_packed_and_scalar_kernels_agree(env, tmp_path):
+    # The fine octaves' orientation histograms run in k_orient_survivors_pk (packed f32, one launch per level); the round-3
+    # kernel k_orient_survivors still serves the coarse octaves and, under VSLAM_ORIENT_SCALAR=1, all of them.  Same frames
+    # through both (the second in a child process: the switch is read when a context is created): interior survivors
+    # (patch path), border survivors (pixel-by-pixel path) and all three levels' spans, byte for byte.
+    import os
+    import subprocess
+    import sys
+
+    ctx, torch = env
+    frames = np.stack([synth.frame_np(360, 520, 0, 3, "noise"), synth.frame_np(360, 520, 1, 4, "checker"), synth.frame_np(360, 520, 2, 5, "noise")])
+    np.save(tmp_path / "frames.npy", frames)
+    p, L, a = run_batch(ctx, torch, frames, n_octaves=3, localize=1, orient=1)
+    assert int(a["oriented_counts"].sum()) > 5000
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, numpy as np, torch; sys.path.insert(0, %r)\n"
+            "from tests.test_gpu_batch import run_batch\n"
+            "from visualslam_amd import capi\n"
+            "capi.build(); ctx = capi.Context(0)\n"
+            "p, L, b = run_batch(ctx, torch, np.load(%r), n_octaves=3, localize=1, orient=1)\n"
+            "np.savez(%r, pts=b['oriented_points'], cnt=b['oriented_counts'])\n") % (root, str(tmp_path / "frames.npy"), str(tmp_path / "scalar.npz"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, VSLAM_ORIENT_SCALAR="1"), cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    b = np.load(tmp_path / "scalar.npz")
+    assert np.array_equal(a["oriented_counts"], b["cnt"])
+    for f in range(len(frames)):
+        n = int(min(a["oriented_counts"][f], p.oriented_cap))
+        assert np.array_equal(a["oriented_points"][f][:n], b["pts"][f][:n]), f
+    for f in range(len(frames)):
+        check_frame(p, L, a, f, frames[f], 3)
