@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--rows", type=int, default=1080)
     ap.add_argument("--cols", type=int, default=1920)
     ap.add_argument("--kernel", default="k_orient_survivors")
+    ap.add_argument("--describe", type=int, default=0, help="1: the SIFT descriptors of every oriented point as well (params.describe)")
     a = ap.parse_args()
     capi.build()
     dev = torch.device("cuda", 0)
@@ -34,6 +35,9 @@ def main():
         out = dict(pyramid=torch.empty((n, L.pyramid_frame_bytes), dtype=torch.uint8, device=dev),
                    extrema_bits=torch.empty((n, L.bits_frame_words), dtype=torch.int64, device=dev),
                    dog_points=torch.empty((n, p.dog_cap, 6), dtype=torch.int32, device=dev), dog_counts=torch.zeros(n, dtype=torch.int32, device=dev))
+        if orient and a.describe:
+            out.update(descriptors=torch.empty((n, p.oriented_cap, 128), dtype=torch.float32, device=dev),
+                       descriptor_defined=torch.zeros((n, p.oriented_cap), dtype=torch.uint8, device=dev))
         if orient:
             out.update(oriented_points=torch.empty((n, p.oriented_cap, 6), dtype=torch.int32, device=dev),
                        oriented_counts=torch.zeros(n, dtype=torch.int32, device=dev), oriented_survivors=torch.zeros(n, dtype=torch.int32, device=dev))

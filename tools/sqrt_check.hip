@@ -18,7 +18,8 @@ __global__ void k_check(int n, unsigned int* bad, float* first) {
     // the packed form (k_orient_survivors_pk), the argument in either half beside another one
     const vslam::vslam_f2 p = vslam::sqrt_rn_small_pk(vslam::vslam_f2{x, (float)(n - i)});
     const float c = (float)sqrt((double)(n - i));
-    if (__float_as_uint(a) != __float_as_uint(b) || __float_as_uint(p.x) != __float_as_uint(b) || __float_as_uint(p.y) != __float_as_uint(c)) {
+    const float d = vslam::sqrt_rn_small_nr(x);
+    if (__float_as_uint(d) != __float_as_uint(b) || __float_as_uint(a) != __float_as_uint(b) || __float_as_uint(p.x) != __float_as_uint(b) || __float_as_uint(p.y) != __float_as_uint(c)) {
         if (atomicAdd(bad, 1u) == 0) *first = x;
     }
 }

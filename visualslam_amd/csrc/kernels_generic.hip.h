@@ -53,6 +53,14 @@ __device__ __forceinline__ vslam_f2 sqrt_rn_small_pk(vslam_f2 x) {
     return __builtin_elementwise_fma(e, h, s);
 }
 
+// One argument, the same six operations (tools/sqrt_check.hip covers it as well).
+__device__ __forceinline__ float sqrt_rn_small_nr(float x) {
+    const float r = __builtin_amdgcn_rsqf(fmaxf(x, 1e-30f));
+    const float s = x * r, h = r * 0.5f;
+    const float e = __builtin_fmaf(-s, s, x);
+    return __builtin_fmaf(e, h, s);
+}
+
 // cv::convertScaleAbs element as the reference's x86-64 OpenCV evaluates it: cvRound (cvtss2si /
 // cvtps2dq, round half even) returns INT_MIN for NaN and for |x| >= 2^31, which
 // saturate_cast<uchar> maps to 0; [255.5, 2^31) saturates to 255.

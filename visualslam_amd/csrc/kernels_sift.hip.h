@@ -64,7 +64,7 @@ __device__ __forceinline__ void sift_one_keypoint(SiftShared& sh, const vslam_po
     __syncthreads();
     const int i = t >> 4, j = t & 15;
     const int pr = rows + 2 * SIFT_PAD, pc = cols + 2 * SIFT_PAD;
-    float o = 0.0f;
+    float o = 0.0f, mval = 0.0f;
     {
         const int cx = kp.col + SIFT_PAD, cy = kp.row + SIFT_PAD;  // :591
         const int e = t;                                            // rotatedPoints[i * imgROI.rows + j], :545
@@ -82,7 +82,8 @@ __device__ __forceinline__ void sift_one_keypoint(SiftShared& sh, const vslam_po
             const float gx = (float)((int)G[(size_t)r * gpitch + reflect101(c + 1, cols)] - (int)G[(size_t)r * gpitch + reflect101(c - 1, cols)]);
             const float gy = (float)((int)G[(size_t)reflect101(r + 1, rows) * gpitch + c] - (int)G[(size_t)reflect101(r - 1, rows) * gpitch + c]);
             const float xx = gx * gx, yy = gy * gy;
-            sh.mag[t] = sqrt_rn_small(xx + yy);          // cv::magnitude, correctly rounded (kernels_generic.hip.h)
+            mval = sqrt_rn_small_nr(xx + yy);            // cv::magnitude, correctly rounded (kernels_generic.hip.h)
+            sh.mag[t] = mval;
             o = fast_atan2_deg(gy, gx);                  // cv::phase(..., true)
         }
     }
@@ -106,19 +107,30 @@ __device__ __forceinline__ void sift_one_keypoint(SiftShared& sh, const vslam_po
         // loops' instructions).  Same products, same order.
         constexpr int PER = 2 * (SIFT_WIN - 1);
         const int span = SIFT_WIN + 2 * R;
-        for (int m = t; m < kn; m += 256) sh.kt[m] = k[m];
-        for (int e = t; e < SIFT_WIN * span; e += 256) {
-            const int r = e / span, p = e - r * span;
-            int q = (p - R) % PER;
-            q = q < 0 ? q + PER : q;
-            sh.ext[e] = sh.mag[r * SIFT_WIN + (q < SIFT_WIN ? q : PER - q)];
+        {   // pixel (i, j)'s magnitude stands at every extended position of row i that reflects onto column j: R + j + 30 z and
+            // R - j + 30 z (round 3 walked the extended rows element by element: a division and a modulo each)
+            float* E = sh.ext + i * span;
+            int p = R + j;  // < 47 + 16
+            while (p >= PER) p -= PER;
+            for (; p < span; p += PER) E[p] = mval;
+            if (j != 0 && j != SIFT_WIN - 1) {
+                int p0 = R - j;
+                while (p0 < 0) p0 += PER;
+                while (p0 >= PER) p0 -= PER;
+                for (; p0 < span; p0 += PER) E[p0] = mval;
+            }
         }
         __syncthreads();
+        // The taps come through SCALAR loads (the same address in every lane: s_load, the tap a scalar operand of the
+        // multiply): with both operands read from the LDS the two filter loops were bound by LDS issue (two reads per
+        // product for four waves), not by arithmetic.
+        typedef const float __attribute__((address_space(4)))* ktaps_p;
+        const ktaps_p ks = (ktaps_p)k;
         {   // row filter of ROI row i: s = k[0]*S[0]; s += k[m]*S[m]
             const float* S = sh.ext + i * span + j;
-            float s0 = sh.kt[0] * S[0];
+            float s0 = ks[0] * S[0];
 #pragma unroll 4
-            for (int m = 1; m < kn; ++m) s0 += sh.kt[m] * S[m];
+            for (int m = 1; m < kn; ++m) s0 += ks[m] * S[m];
             // its value stands at every extended row position that reflects onto row i: R + i + 30 z and R - i + 30 z
             for (int p = (R + i) % PER; p < span; p += PER) sh.extc[p * SIFT_WIN + j] = s0;
             if (i != 0 && i != SIFT_WIN - 1) {
@@ -130,9 +142,9 @@ __device__ __forceinline__ void sift_one_keypoint(SiftShared& sh, const vslam_po
         __syncthreads();
         {   // symmetric column filter: s = k[R]*S(0); s += k[R+m]*(S(+m) + S(-m))
             const float* C = sh.extc + (R + i) * SIFT_WIN + j;
-            float s0 = sh.kt[R] * C[0];
+            float s0 = ks[R] * C[0];
 #pragma unroll 4
-            for (int m = 1; m <= R; ++m) s0 += sh.kt[R + m] * (C[m * SIFT_WIN] + C[-m * SIFT_WIN]);
+            for (int m = 1; m <= R; ++m) s0 += ks[R + m] * (C[m * SIFT_WIN] + C[-m * SIFT_WIN]);
             sh.mw[t] = s0;
         }
     } else if (kn <= SIFT_KMAX) {
@@ -227,7 +239,8 @@ __global__ __launch_bounds__(256) void k_sift_descriptors(const vslam_point* __r
     __shared__ SiftShared sh;
     const int q = blockIdx.x;
     const vslam_point kp = kps[q];
-    sift_one_keypoint(sh, kp, cs[q], lv.gauss[kp.level], gpitch, rows, cols, lv.kern[kp.level], lv.kn[kp.level],
+    const int level = __builtin_amdgcn_readfirstlane(kp.level);
+    sift_one_keypoint(sh, kp, cs[q], lv.gauss[level], gpitch, rows, cols, lv.kern[level], lv.kn[level],
                       desc + (size_t)q * SIFT_DESC, defined ? defined + q : nullptr);
 }
 
@@ -255,10 +268,10 @@ __global__ __launch_bounds__(256) void k_sift_descriptors_batch(const vslam_poin
     for (unsigned int q = blockIdx.x; q < n; q += gridDim.x) {
         const vslam_point kp = kp_next;
         if (q + gridDim.x < n) kp_next = oriented[(size_t)f * cap + q + gridDim.x];
-        const int o = kp.octave;
-        const uint8_t* G = pyr + f * pframe + g.oct_off[o] + (size_t)kp.level * g.rows[o] * g.pitch[o];
-        const unsigned int b = (unsigned int)kp.value / 10u;
-        sift_one_keypoint(sh, kp, g.cs36[b < 36u ? b : 0u], G, g.pitch[o], g.rows[o], g.cols[o], g.kern[o][kp.level], g.kn[o][kp.level],
+        const int o = __builtin_amdgcn_readfirstlane(kp.octave), level = __builtin_amdgcn_readfirstlane(kp.level);  // one record per workgroup: scalar
+        const uint8_t* G = pyr + f * pframe + g.oct_off[o] + (size_t)level * g.rows[o] * g.pitch[o];
+        const unsigned int b = (unsigned int)__builtin_amdgcn_readfirstlane(kp.value) / 10u;
+        sift_one_keypoint(sh, kp, g.cs36[b < 36u ? b : 0u], G, g.pitch[o], g.rows[o], g.cols[o], g.kern[o][level], g.kn[o][level],
                           desc + ((size_t)f * cap + q) * SIFT_DESC, defined ? defined + (size_t)f * cap + q : nullptr);
     }
 }
