@@ -73,11 +73,15 @@ __device__ __forceinline__ void sift_one_keypoint(SiftShared& sh, const vslam_po
         const float xr = (float)rx * a.x - (float)ry * a.y;        // rotation.cpp:22 (no FMA: -ffp-contract=off)
         const float yr = (float)rx * a.y + (float)ry * a.x;        // :23
         const int px = (int)xr + cx, py = (int)yr + cy;            // truncation; |xr|, |yr| < 16
-        const long long lin = (long long)px * pc + py;             // at<>(x, y): x is the row (:549-554)
-        if (lin < 0 || lin >= (long long)pr * pc) {
+        // at<>(x, y): x is the row (:549-554), i.e. linear element lin = px * pc + py of the padded Mat; defined iff
+        // 0 <= lin < pr * pc.  px, py > 0 here (centre >= 20, |offset| < 16), so lin >= 0 and floor(lin / pc) = px + py / pc:
+        // py < pc unless the image is taller than wide - a subtraction loop of rows / cols trips instead of the 64-bit
+        // division this was (a tenth of the kernel's instructions)
+        int prow = px, pcol = py;
+        while (pcol >= pc) pcol -= pc, ++prow;
+        if (prow >= pr) {
             atomicOr(&sh.bad, 1);
         } else {
-            const int prow = (int)(lin / pc), pcol = (int)(lin - (long long)prow * pc);
             const int r = clampi(prow - SIFT_PAD, 0, rows - 1), c = clampi(pcol - SIFT_PAD, 0, cols - 1);  // padOctave(20): replicate
             const float gx = (float)((int)G[(size_t)r * gpitch + reflect101(c + 1, cols)] - (int)G[(size_t)r * gpitch + reflect101(c - 1, cols)]);
             const float gy = (float)((int)G[(size_t)reflect101(r + 1, rows) * gpitch + c] - (int)G[(size_t)reflect101(r - 1, rows) * gpitch + c]);
