@@ -77,6 +77,7 @@ struct vslam_ctx {
     hipEvent_t ev_up2 = nullptr;  // the second half of a batch has been upsampled (enqueue_dog)
     hipEvent_t ev_chunk = nullptr;  // the main-stream kernels of a chunk (the readers of the octave bases) are enqueued up to here
     hipEvent_t ev_list0 = nullptr, ev_edge = nullptr;  // octave 0's part of the DoG list is written / its edge test is done
+    hipEvent_t ev_or_fork = nullptr, ev_or_join[2] = {nullptr, nullptr};  // the orientation launches spread over the idle side streams (enqueue_orient_batch)
     // recycled pyramid blocks: a GaussPyramid per image would otherwise pay hipMalloc + hipFree of
     // >100 MB each time (milliseconds, more than the kernels)
     std::vector<std::pair<size_t, void*>> block_cache;
@@ -302,6 +303,8 @@ static int ensure_aux(vslam_ctx* c) {
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_chunk, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_list0, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_edge, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_or_fork, hipEventDisableTiming));
+    for (auto& e : c->ev_or_join) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     return VSLAM_OK;
 }
@@ -1161,7 +1164,7 @@ int vslam_ctx_destroy(vslam_ctx* c) {
         if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
     }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    for (hipEvent_t e : {c->ev_phase, c->ev_up2, c->ev_chunk, c->ev_list0, c->ev_edge})
+    for (hipEvent_t e : {c->ev_phase, c->ev_up2, c->ev_chunk, c->ev_list0, c->ev_edge, c->ev_or_fork, c->ev_or_join[0], c->ev_or_join[1]})
         if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ev_oct)
         if (e) (void)hipEventDestroy(e);
@@ -1937,7 +1940,7 @@ static int enqueue_edge_flags_early(vslam_ctx* c, const vslam_params& p, const O
 // context's current stream; the lists must be complete on that stream.
 static int enqueue_orient_batch(vslam_ctx* c, const vslam_params& p, const vslam_batch_layout& L, const OrientPlan& pl, int nf, const uint8_t* pyr,
                                 size_t pframe, const vslam_point* points, const unsigned int* counts, OrientScratch& s,
-                                vslam_point* oriented, unsigned int* oriented_counts) {
+                                vslam_point* oriented, unsigned int* oriented_counts, hipStream_t side_a = nullptr, hipStream_t side_b = nullptr) {
     const OrientBatchGeom& g = pl.g;
     const size_t scap = p.oriented_cap;
     const size_t fw = s.fwords;
@@ -1949,21 +1952,40 @@ static int enqueue_orient_batch(vslam_ctx* c, const vslam_params& p, const vslam
     LAUNCH(c, "k_survivor_ranges", k_survivor_ranges, dim3(nf), dim3(128), points, p.dog_cap, s.surv, s.scounts, (unsigned int)scap, L.n_octaves, s.ranges);
     TRY(raise_dyn_lds(c, reinterpret_cast<const void*>(&k_orient_survivors)));
     const int gwg = (int)std::min<long>(1024, std::max<long>(16, 8192 / nf));
-    for (int o = 0; o < L.n_octaves; ++o) {  // one launch per octave: its own survivors, its own LDS footprint
-        TimedScope ts(c, "k_orient_survivors");
-        if (pl.smax[o] <= OR_PK_MAX_SPAN && !c->orient_scalar_form) {  // the fine octaves: packed-f32 form, two waves per survivor, one launch per level
-            // 8 gwg workgroups per frame (256 at 256 frames): ~20 survivors each on a dense frame.  With 2 gwg (80 each) the
-            // launch ended on a long tail of half-empty CUs: 9.0 ms of these launches per 256-frame step against 8.4
-            constexpr int pk_mult = 8;
-            for (int l = 1; l <= 3; ++l)
-                hipLaunchKernelGGL(k_orient_survivors_pk, dim3(pk_mult * gwg, nf), dim3(128), (size_t)orient_pk_lds_floats(OR_WIN + 2 * (g.kn[o][l] / 2)) * 4,
-                                   c->stream, points, p.dog_cap, s.surv, s.ranges, (unsigned int)scap, pyr, pframe, g, o, l, s.masks);
-            continue;
+    // The launches below are independent (each takes its own survivors, each writes its own mask words) and every one ends
+    // on a tail of half-empty CUs: with two idle side streams at hand (the Harris chain's and the upsample's: both are
+    // done long before the list is) they go out round-robin over three streams and share the chip.
+    const bool spread = side_a && side_b && side_a != c->stream && side_b != c->stream && side_a != side_b;
+    hipStream_t lanes[3] = {c->stream, spread ? side_a : c->stream, spread ? side_b : c->stream};
+    if (spread) {
+        HIPCHK(c, hipEventRecord(c->ev_or_fork, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(side_a, c->ev_or_fork, 0));
+        HIPCHK(c, hipStreamWaitEvent(side_b, c->ev_or_fork, 0));
+    }
+    int next = 0;
+    {
+        TimedScope ts(c, "k_orient_survivors");  // with the launches spread, this brackets the main stream's share only
+        for (int o = 0; o < L.n_octaves; ++o) {  // one launch per octave: its own survivors, its own LDS footprint
+            if (pl.smax[o] <= OR_PK_MAX_SPAN && !c->orient_scalar_form) {  // the fine octaves: packed-f32 form, two waves per survivor, one launch per level
+                // 8 gwg workgroups per frame (256 at 256 frames): ~20 survivors each on a dense frame.  With 2 gwg (80 each) the
+                // launch ended on a long tail of half-empty CUs: 9.0 ms of these launches per 256-frame step against 8.4
+                constexpr int pk_mult = 8;
+                for (int l = 1; l <= 3; ++l)
+                    hipLaunchKernelGGL(k_orient_survivors_pk, dim3(pk_mult * gwg, nf), dim3(128), (size_t)orient_pk_lds_floats(OR_WIN + 2 * (g.kn[o][l] / 2)) * 4,
+                                       lanes[next++ % 3], points, p.dog_cap, s.surv, s.ranges, (unsigned int)scap, pyr, pframe, g, o, l, s.masks);
+                continue;
+            }
+            hipLaunchKernelGGL(k_orient_survivors, dim3(gwg, nf), dim3(256), (size_t)pl.need[o] * 4, lanes[next++ % 3], points, p.dog_cap, s.surv, s.ranges,
+                               (unsigned int)scap, pyr, pframe, g, pl.need[o], o, s.masks);
         }
-        hipLaunchKernelGGL(k_orient_survivors, dim3(gwg, nf), dim3(256), (size_t)pl.need[o] * 4, c->stream, points, p.dog_cap, s.surv, s.ranges,
-                           (unsigned int)scap, pyr, pframe, g, pl.need[o], o, s.masks);
     }
     HIPCHK(c, hipGetLastError());
+    if (spread) {
+        HIPCHK(c, hipEventRecord(c->ev_or_join[0], side_a));
+        HIPCHK(c, hipEventRecord(c->ev_or_join[1], side_b));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_or_join[0], 0));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_or_join[1], 0));
+    }
     OrientBatchEntries oe{s.masks, s.surv, s.scounts, (unsigned int)scap, points, p.dog_cap, oriented};
     TRY(enqueue_compaction(c, oe, scap, nf, s.cws, (unsigned int)scap, oriented_counts, 0));
     return VSLAM_OK;
@@ -2065,6 +2087,10 @@ int vslam_detect_batch_dev(vslam_ctx* c, const vslam_params* pp, const uint8_t* 
         const char* e = std::getenv("VSLAM_AUX_STREAMS");
         return !(e && e[0] == '0');
     }();
+    static const bool orient_spread = [] {
+        const char* e = std::getenv("VSLAM_ORIENT_SPREAD");
+        return !(e && e[0] == '0');
+    }();
     hipStream_t sh = c->stream, sx = nullptr;  // Harris stream, extrema stream (nullptr = main)
     // Any early return between the fork and the join must not leave the side streams running into
     // buffers the caller (or the next ws_reserve) is about to reuse: drain them on the error path.
@@ -2139,7 +2165,8 @@ int vslam_detect_batch_dev(vslam_ctx* c, const vslam_params* pp, const uint8_t* 
                 StreamSwap sw(c, sx ? sx : c->stream);
                 TRY(enqueue_orient_batch(c, p, L, opl, nf, out->pyramid + (size_t)f0 * L.pyramid_frame_bytes, L.pyramid_frame_bytes,
                                          out->dog_points + (size_t)f0 * p.dog_cap, out->dog_counts + f0, os,
-                                         out->oriented_points + (size_t)f0 * p.oriented_cap, out->oriented_counts + f0));
+                                         out->oriented_points + (size_t)f0 * p.oriented_cap, out->oriented_counts + f0,
+                                         (use_aux && orient_spread) ? sh : nullptr, (use_aux && orient_spread) ? c->aux[2] : nullptr));
                 if (out->oriented_survivors)
                     HIPCHK(c, hipMemcpyAsync(out->oriented_survivors + f0, os.scounts, sizeof(unsigned int) * (size_t)nf,
                                              hipMemcpyDeviceToDevice, c->stream));
