@@ -868,3 +868,16 @@ def test_orientation_packed_and_scalar_kernels_agree(env, tmp_path):
         assert np.array_equal(a["oriented_points"][f][:n], b["pts"][f][:n]), f
     for f in range(len(frames)):
         check_frame(p, L, a, f, frames[f], 3)
+
+
+@pytest.mark.parametrize("sigma0", [0.9, 1.3, 2.0])
+def test_batch_oriented_keypoints_other_base_sigmas(env, sigma0):
+    # The orientation blur's width follows sigma0 (1.5 * sigma(octave, level), 8 sigma + 1 taps): other base sigmas give the
+    # packed kernel other spans, column-group counts and LDS layouts per level (sigma0 = 0.9: spans 30-38; 1.3: 36-48) and,
+    # at 2.0 (spans 46, 54, 64: the widest is past the packed kernel's 60), hand octave 0 back to the round-3 kernel.
+    ctx, torch = env
+    frames = np.stack([synth.frame_np(300, 400, 0, 7, "noise"), synth.frame_np(300, 400, 1, 8, "checker")])
+    p, L, out = run_batch(ctx, torch, frames, n_octaves=2, localize=1, orient=1, sigma0=sigma0)
+    assert int(out["oriented_counts"].sum()) > 300
+    for f in range(2):
+        check_frame(p, L, out, f, frames[f], 2)
