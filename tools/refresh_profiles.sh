@@ -38,3 +38,6 @@ RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 ./visualslam_amd/bin/Stream --mode hostfed --ba
 VSLAM_MX=1 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 ./visualslam_amd/bin/Stream --mode device --batches 30 --warmup 6 2>/dev/null | tail -1 > $OUT/stream_device_mx.json
 VSLAM_MX=1 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 ./visualslam_amd/bin/Stream --mode hostfed --batches 40 --warmup 6 2>/dev/null | tail -1 > $OUT/stream_hostfed_mx.json
 cut -c1-300 $OUT/bench_default.json
+# the orientation and descriptor stages on the bench's `modes` content (timing at 256 frames, one PMC pass at 64)
+bash tools/orient_pmc.sh $R/orient > $OUT/orient_stage.txt 2>&1 || true
+bash tools/sift_pmc.sh $R/sift > $OUT/sift_stage.txt 2>&1 || true
