@@ -9,12 +9,15 @@
 //     while wave 0 adds up the previous survivor's histogram;
 //   * magnitudes: one item = 2 rows x 4 columns from eight LDS dwords; every byte is converted once per item (20
 //     conversions for 8 values instead of 32), differences / squares / the Newton step of the square root in packed
-//     f32 (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32: two values per issue slot), the pair (row 2p, row 2p+1) of a
-//     column is what one packed register holds and what one 8-byte LDS word of the magnitude region holds;
+//     f32 (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32: two values per instruction - NOT twice the rate on this chip, 4.3
+//     cycles against 2.3 for the one-value forms, but half the instructions, LDS words and loop trips), the pair (row 2p,
+//     row 2p+1) of a column is what one packed register holds and what one 8-byte LDS word of the magnitude region holds;
 //   * row pass: one item = the same row pair x 4 output columns, a sliding window of 8-byte words, v_pk_mul_f32 by a
-//     tap held in a SCALAR register (op_sel splat: no LDS read, no vector register per tap) + v_pk_add_f32: one issue
-//     slot per product-and-sum of two rows, where the scalar form took 2.5;
-//   * column pass: two adjacent columns per thread, the same way.
+//     tap held in a SCALAR register (op_sel splat: no LDS read, no vector register per tap) + v_pk_add_f32: one
+//     instruction per product-and-sum of two rows, where the round-3 form took 2.5 and two LDS reads;
+//   * column pass: two adjacent columns per thread, the same way;
+//   * one launch per (octave, level): the span, the tap count and the LDS layout are the launch's constants and the
+//     footprint is the level's own (11 / 14 / 18 KB for octave 0's three levels: 14 / 11 / 9 workgroups per CU).
 // A zero tap adds +0 to a non-negative sum, which leaves every bit of it alone: the tap arrays are zero-padded (three in
 // front for the sliding window, to a multiple of four behind), steps that would read past a row are skipped.
 //
@@ -70,7 +73,7 @@ __device__ __forceinline__ void bin_masks_from_planes(int mybin, const unsigned 
     }
 }
 
-// Device layout of the padded taps of one (octave, level) (orient_taps_pk_floats / fill_orient_taps_pk on the host):
+// Device layout of the padded taps of one (octave, level) (written by get_orient_taps, vslam_hip.hip):
 //   [0, n)            the taps themselves (k_orient_survivors, SIFT)
 //   row  = A .. :     0 0 0 k[0] .. k[n-1] 0 0 ..    A = (n + 3) & ~3, length NR = ((n + 6) & ~3) + 8
 //   col  = A + NR .. : k[R+1] .. k[2R] 0 0 ..         length ((R + 3) & ~3) + 4   (k[R], the centre tap, is row[3 + R])
@@ -80,8 +83,8 @@ __host__ __device__ inline int orient_taps_pk_floats(int n) { return orient_taps
 
 constexpr int OR_PK_MAX_SPAN = 60;  // 16 four-column groups cover byte sh + span of a patch row (sh <= 3)
 // LDS floats of a launch for one level's span (even, <= OR_PK_MAX_SPAN): magnitude region as row pairs (the window's
-// weights take its place once the row pass has read it), patch / strip overlay, bin masks.  One launch per level: 11 / 14 /
-// 18 KB for the three levels of octave 0 = 14 / 11 / 9 workgroups per CU, where one launch per octave had 8.
+// weights take its first KB once the row pass has read it), patch / strip overlay, bin masks.  11 / 14 / 18 KB for the three
+// levels of octave 0 = 14 / 11 / 9 workgroups per CU, where one launch per octave (the widest level's footprint) had 8.
 __host__ __device__ inline int orient_pk_mp(int span) { return span + 7; }                     // 8-byte words per row pair: the row pass reads up to column span + 6; odd: bank spread
 __host__ __device__ inline int orient_pk_pp(int span) { return (((span + 8) >> 2) + 2) | 1; }  // dwords per patch row, one pad dword either side
 __host__ __device__ inline int orient_pk_m2_floats(int span) { return ((span >> 1) * orient_pk_mp(span) * 2 + 3) & ~3; }  // what follows stays 16-byte aligned
