@@ -94,14 +94,16 @@ __host__ __device__ inline int orient_pk_lds_floats(int span) {
 }
 
 // grid = (G, frames), 128 threads, dynamic LDS = orient_pk_lds_floats(span of the level) * 4 bytes; the survivors of
-// (octave `oct`, level `level`) (k_survivor_ranges).
+// (octave `oct`, level `level`) (k_survivor_ranges).  KN = the level's tap count as a compile-time constant (the three of
+// the default pyramid's octave 0 are instantiated: loop bounds, guards and LDS offsets fold), 0 = read it from g.
+template <int KN>
 __global__ __launch_bounds__(128) void k_orient_survivors_pk(const vslam_point* __restrict__ pts, unsigned int cap,
                                                               const unsigned int* __restrict__ surv, const unsigned int* __restrict__ ranges,
                                                               unsigned int scap, const uint8_t* __restrict__ pyr, size_t pframe,
                                                               OrientBatchGeom g, int oct, int level, unsigned long long* __restrict__ masks) {
     extern __shared__ __attribute__((aligned(16))) float orient_smem[];
     const int o = oct;
-    const int kn = g.kn[o][level], R = kn >> 1, span = OR_WIN + 2 * R, hs = span >> 1, pdw = (span + 2 + 6) >> 2;
+    const int kn = KN ? KN : g.kn[o][level], R = kn >> 1, span = OR_WIN + 2 * R, hs = span >> 1, pdw = (span + 2 + 6) >> 2;
     const int MP = orient_pk_mp(span), PP = orient_pk_pp(span);
     const int GQ = ((span + 3) >> 2) + 1, gq_inv = 65536 / GQ + 1;
     vslam_f2* const M2 = reinterpret_cast<vslam_f2*>(orient_smem);                 // [span / 2][MP] {row 2p, row 2p + 1}

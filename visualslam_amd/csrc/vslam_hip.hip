@@ -1970,9 +1970,17 @@ static int enqueue_orient_batch(vslam_ctx* c, const vslam_params& p, const vslam
                 // 8 gwg workgroups per frame (256 at 256 frames): ~20 survivors each on a dense frame.  With 2 gwg (80 each) the
                 // launch ended on a long tail of half-empty CUs: 9.0 ms of these launches per 256-frame step against 8.4
                 constexpr int pk_mult = 8;
-                for (int l = 1; l <= 3; ++l)
-                    hipLaunchKernelGGL(k_orient_survivors_pk, dim3(pk_mult * gwg, nf), dim3(128), (size_t)orient_pk_lds_floats(OR_WIN + 2 * (g.kn[o][l] / 2)) * 4,
+                for (int l = 1; l <= 3; ++l) {
+                    auto kfn = k_orient_survivors_pk<0>;
+                    switch (g.kn[o][l]) {  // the default pyramid's octave 0 (sigma0 = 1.6) with its tap counts compiled in: 6.85 -> 6.5 ms per step
+                        case 25: kfn = k_orient_survivors_pk<25>; break;
+                        case 31: kfn = k_orient_survivors_pk<31>; break;
+                        case 39: kfn = k_orient_survivors_pk<39>; break;
+                        default: break;
+                    }
+                    hipLaunchKernelGGL(kfn, dim3(pk_mult * gwg, nf), dim3(128), (size_t)orient_pk_lds_floats(OR_WIN + 2 * (g.kn[o][l] / 2)) * 4,
                                        lanes[next++ % 3], points, p.dog_cap, s.surv, s.ranges, (unsigned int)scap, pyr, pframe, g, o, l, s.masks);
+                }
                 continue;
             }
             hipLaunchKernelGGL(k_orient_survivors, dim3(gwg, nf), dim3(256), (size_t)pl.need[o] * 4, lanes[next++ % 3], points, p.dog_cap, s.surv, s.ranges,
