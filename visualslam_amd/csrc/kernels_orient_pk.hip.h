@@ -96,8 +96,10 @@ __host__ __device__ inline int orient_pk_lds_floats(int span) {
 // grid = (G, frames), 128 threads, dynamic LDS = orient_pk_lds_floats(span of the level) * 4 bytes; the survivors of
 // (octave `oct`, level `level`) (k_survivor_ranges).  KN = the level's tap count as a compile-time constant (the three of
 // the default pyramid's octave 0 are instantiated: loop bounds, guards and LDS offsets fold), 0 = read it from g.
+// At least six waves per SIMD (<= 85 vector registers): the unrolled instantiations otherwise take 90 - 124 and the registers, not
+// the LDS, would bound the workgroups per CU (28.7 -> 28.2 ms per dense step).
 template <int KN>
-__global__ __launch_bounds__(128) void k_orient_survivors_pk(const vslam_point* __restrict__ pts, unsigned int cap,
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_orient_survivors_pk(const vslam_point* __restrict__ pts, unsigned int cap,
                                                               const unsigned int* __restrict__ surv, const unsigned int* __restrict__ ranges,
                                                               unsigned int scap, const uint8_t* __restrict__ pyr, size_t pframe,
                                                               OrientBatchGeom g, int oct, int level, unsigned long long* __restrict__ masks) {
