@@ -415,7 +415,12 @@ int vslam_batch_out_required(const vslam_params* p, int n_frames, vslam_batch_ou
  * f*frame_stride, dense rows).  Asynchronous on the context stream.  This is the fused
  * path of BASELINE config 4: every frame is read from HBM once per path and every
  * output written once; frames are independent, so a multi-GPU job shards frames across
- * ranks with no data-path collective. */
+ * ranks with no data-path collective.
+ * Stream capture: a call may be recorded into a hipGraph (hipStreamBeginCapture on the context's stream ... EndCapture)
+ * once ONE call with the same parameters and batch size has run outside a capture - the workspace, the blur taps and the
+ * side streams are created by the first call, and a capture can allocate nothing.  The side-stream forks all start from
+ * and join back to the capturing stream; the stream tuner does not time captured calls
+ * (tests/test_gpu_batch.py::test_batch_call_captured_into_a_graph). */
 int vslam_detect_batch_dev(vslam_ctx* ctx, const vslam_params* p, const uint8_t* d_frames, size_t frame_stride,
                            int n_frames, const vslam_batch_out* out);
 

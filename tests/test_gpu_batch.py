@@ -881,3 +881,62 @@ def test_batch_oriented_keypoints_other_base_sigmas(env, sigma0):
     assert int(out["oriented_counts"].sum()) > 300
     for f in range(2):
         check_frame(p, L, out, f, frames[f], 2)
+
+
+@pytest.mark.parametrize("n,mode,mx", [(8, {}, False), (8, dict(localize=1, orient=1, describe=1), False), (64, dict(localize=1, orient=1), False), (64, {}, True)])
+def test_batch_call_captured_into_a_graph(env, n, mode, mx):
+    # vslam_detect_batch_dev inside a stream capture (hipGraph), after one warm-up call with the same parameters (workspace,
+    # taps and side streams exist then: a capture can allocate nothing): the side-stream forks are all capturable, the stream
+    # tuner stays out, and the two nested forks of the orientation stage fall back to their own stream (this runtime faults
+    # at the end of a capture in which a side stream forks to another one).  Replays on new frame contents = eager calls.
+    _, torch = env
+    dev = "cuda:0"
+    st = torch.cuda.Stream()
+    rows, cols = (240, 320) if n == 8 else (120, 160)
+    mode = dict(mode)
+    describe = mode.pop("describe", 0)
+    with torch.cuda.stream(st):
+        ctx = capi.Context(0, st.cuda_stream)
+        ctx.set_matrix_path(mx)
+        p = capi.default_params(rows, cols, n_octaves=3, **mode)
+        L = capi.batch_layout(p)
+        frames = torch.from_numpy(synth.frames_np(n, rows, cols, stream_id=3)).to(dev)
+
+        def outs():
+            o = dict(response=torch.zeros((n, rows, cols), dtype=torch.float32, device=dev), nms_mask=torch.zeros((n, rows, cols), dtype=torch.uint8, device=dev),
+                     harris_kps=torch.zeros((n, p.harris_cap, 3), dtype=torch.int32, device=dev), harris_counts=torch.zeros(n, dtype=torch.int32, device=dev),
+                     pyramid=torch.zeros((n, L.pyramid_frame_bytes), dtype=torch.uint8, device=dev),
+                     extrema_bits=torch.zeros((n, L.bits_frame_words), dtype=torch.int64, device=dev),
+                     dog_points=torch.zeros((n, p.dog_cap, 6), dtype=torch.int32, device=dev), dog_counts=torch.zeros(n, dtype=torch.int32, device=dev))
+            if mode:
+                o.update(oriented_points=torch.zeros((n, p.oriented_cap, 6), dtype=torch.int32, device=dev), oriented_counts=torch.zeros(n, dtype=torch.int32, device=dev))
+            if describe:
+                o.update(descriptors=torch.zeros((n, p.oriented_cap, 128), dtype=torch.float32, device=dev),
+                         descriptor_defined=torch.zeros((n, p.oriented_cap), dtype=torch.uint8, device=dev))
+            return o
+
+        a, b = outs(), outs()
+        ctx.detect_batch(p, frames, **a)  # warm-up
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            ctx.detect_batch(p, frames, **b)
+        lists = {"harris_kps": "harris_counts", "dog_points": "dog_counts", "oriented_points": "oriented_counts", "descriptors": "oriented_counts",
+                 "descriptor_defined": "oriented_counts"}
+        for rep in range(2):
+            kind = "noise" if rep else "checker"
+            frames.copy_(torch.from_numpy(np.stack([synth.frame_np(rows, cols, f, 20 + rep, kind) for f in range(n)])).to(dev))
+            ctx.detect_batch(p, frames, **a)
+            torch.cuda.synchronize()
+            g.replay()
+            torch.cuda.synchronize()
+            assert int(a["dog_counts"].sum()) > 0
+            for k in a:
+                if k in lists:  # records past a frame's count are whatever an earlier call left there
+                    for f in range(n):
+                        m = int(min(a[lists[k]][f], a[k].shape[1]))
+                        assert torch.equal(a[k][f][:m], b[k][f][:m]), (k, f)
+                else:
+                    assert torch.equal(a[k], b[k]), k
+        del g
+        ctx.close()

@@ -2099,6 +2099,16 @@ int vslam_detect_batch_dev(vslam_ctx* c, const vslam_params* pp, const uint8_t* 
         const char* e = std::getenv("VSLAM_ORIENT_SPREAD");
         return !(e && e[0] == '0');
     }();
+    // Under stream capture (hipGraph) a fork may only start from the capturing stream itself: this runtime ends the capture
+    // with a fault when a side stream forks to another side stream and takes the join back (tools/graph_try.py found it in
+    // the orientation stage).  The two nested forks of that stage - the early edge test and the spread launches - stay on
+    // their own stream while a capture is on; everything else forks from and joins to the main stream.
+    bool capturing = false;
+    {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(c->stream, &cap) != hipSuccess) (void)hipGetLastError();
+        capturing = cap != hipStreamCaptureStatusNone;
+    }
     hipStream_t sh = c->stream, sx = nullptr;  // Harris stream, extrema stream (nullptr = main)
     // Any early return between the fork and the join must not leave the side streams running into
     // buffers the caller (or the next ws_reserve) is about to reuse: drain them on the error path.
@@ -2153,7 +2163,7 @@ int vslam_detect_batch_dev(vslam_ctx* c, const vslam_params* pp, const uint8_t* 
             const std::function<int(int)> after_list = [&](int o) -> int {
                 if (orient && o == 0 && L.n_octaves > 1)
                     return enqueue_edge_flags_early(c, p, opl, nf, out->pyramid + (size_t)f0 * L.pyramid_frame_bytes, L.pyramid_frame_bytes,
-                                                    out->dog_points + (size_t)f0 * p.dog_cap, out->dog_counts + f0, os, use_aux ? sh : nullptr);
+                                                    out->dog_points + (size_t)f0 * p.dog_cap, out->dog_counts + f0, os, (use_aux && !capturing) ? sh : nullptr);
                 return VSLAM_OK;
             };
             const std::function<int(int)> after_octave = [&](int o) -> int {
@@ -2174,7 +2184,8 @@ int vslam_detect_batch_dev(vslam_ctx* c, const vslam_params* pp, const uint8_t* 
                 TRY(enqueue_orient_batch(c, p, L, opl, nf, out->pyramid + (size_t)f0 * L.pyramid_frame_bytes, L.pyramid_frame_bytes,
                                          out->dog_points + (size_t)f0 * p.dog_cap, out->dog_counts + f0, os,
                                          out->oriented_points + (size_t)f0 * p.oriented_cap, out->oriented_counts + f0,
-                                         (use_aux && orient_spread) ? sh : nullptr, (use_aux && orient_spread) ? c->aux[2] : nullptr));
+                                         (use_aux && orient_spread && !capturing) ? sh : nullptr,
+                                         (use_aux && orient_spread && !capturing) ? c->aux[2] : nullptr));
                 if (out->oriented_survivors)
                     HIPCHK(c, hipMemcpyAsync(out->oriented_survivors + f0, os.scounts, sizeof(unsigned int) * (size_t)nf,
                                              hipMemcpyDeviceToDevice, c->stream));
