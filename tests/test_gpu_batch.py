@@ -940,3 +940,42 @@ def test_batch_call_captured_into_a_graph(env, n, mode, mx):
                     assert torch.equal(a[k], b[k]), k
         del g
         ctx.close()
+
+
+def test_two_chunks_through_the_orientation_and_descriptor_stages(env):
+    # 512 frames = two chunks of 256 inside one call: the second chunk's orientation stage re-records the events of the first
+    # one's spread launches and early edge test, and queues behind them on the side streams.  The call's oriented points and
+    # descriptors = those of two calls of 256 frames each (single-chunk calls are what the oracle tests cover).
+    ctx, torch = env
+    rows, cols, n, n_oct = 136, 256, 512, 2
+    frames_np = np.stack([synth.frame_np(rows, cols, frame=f, stream_id=41 + (f >> 8), kind="noise" if f % 8 == 0 else "checker") for f in range(n)])
+    dev = "cuda:0"
+    frames = torch.from_numpy(frames_np).to(dev)
+    p = capi.default_params(rows, cols, n_octaves=n_oct, localize=1, orient=1, harris_cap=4096, dog_cap=16384)
+    L = capi.batch_layout(p)
+
+    def outs(m):
+        return dict(pyramid=torch.zeros((m, L.pyramid_frame_bytes), dtype=torch.uint8, device=dev),
+                    extrema_bits=torch.zeros((m, L.bits_frame_words), dtype=torch.int64, device=dev),
+                    dog_points=torch.zeros((m, p.dog_cap, 6), dtype=torch.int32, device=dev), dog_counts=torch.zeros(m, dtype=torch.int32, device=dev),
+                    oriented_points=torch.zeros((m, p.oriented_cap, 6), dtype=torch.int32, device=dev), oriented_counts=torch.zeros(m, dtype=torch.int32, device=dev),
+                    descriptors=torch.zeros((m, p.oriented_cap, 128), dtype=torch.float32, device=dev),
+                    descriptor_defined=torch.zeros((m, p.oriented_cap), dtype=torch.uint8, device=dev))
+
+    whole = outs(n)
+    ctx.detect_batch(p, frames, **whole)
+    torch.cuda.synchronize()
+    assert int(whole["oriented_counts"].sum()) > 10000
+    for half in range(2):
+        part = outs(256)
+        ctx.detect_batch(p, frames[256 * half:256 * (half + 1)], **part)
+        torch.cuda.synchronize()
+        sl = slice(256 * half, 256 * (half + 1))
+        assert torch.equal(whole["dog_counts"][sl], part["dog_counts"]) and torch.equal(whole["oriented_counts"][sl], part["oriented_counts"])
+        for f in range(0, 256, 8):  # the noise frames carry the points
+            m = int(min(part["oriented_counts"][f], p.oriented_cap))
+            assert torch.equal(whole["oriented_points"][256 * half + f][:m], part["oriented_points"][f][:m]), (half, f)
+            d = part["descriptor_defined"][f][:m].bool()
+            assert torch.equal(whole["descriptor_defined"][256 * half + f][:m], part["descriptor_defined"][f][:m])
+            assert torch.equal(whole["descriptors"][256 * half + f][:m][d], part["descriptors"][f][:m][d]), (half, f)
+        del part
