@@ -39,7 +39,8 @@ struct SiftLevels {  // per Gaussian level of the octave (null / 0 when no keypo
 // One keypoint by one 256-thread workgroup (all threads call this with the same arguments).
 // G = the keypoint's 8-bit Gaussian level, k / kn = the f32 taps of sigma = 1.5 * sigma(octave, level),
 // a = (cos, sin) of its angle.  Writes the 128 floats and the defined flag (0: the rotated window
-// leaves the padded level, descriptor zeroed).  Ends with the workgroup's shared arrays free again.
+// leaves the padded level, descriptor zeroed).  No barrier at the end: wave 0 may still be reading sh.d while the others start the
+// next keypoint, whose first write to it is five barriers away.
 constexpr int SIFT_KMAX = 640;  // blur taps staged in LDS (309 for octave 3 of the reference pyramid); longer kernels read them from memory
 constexpr int SIFT_EXT_R = 47;  // kernels up to 95 taps (octaves 0 and 1 of the reference pyramid: 25 ... 77) filter explicitly extended rows
 constexpr int SIFT_EXT_SPAN = SIFT_WIN + 2 * SIFT_EXT_R;
@@ -52,16 +53,13 @@ struct SiftShared {
     float mw[SIFT_WIN * SIFT_WIN];    // magWeighted
     float d[SIFT_DESC];
     uint8_t bin[SIFT_WIN * SIFT_WIN];
-    float wmax[2], first;  // max_element over the 128 histogram values: per-wave maxima, element 0
-    int bad;
+    int badw[4];  // per wave: one of its 64 sample points lies outside the padded Mat
 };
 
 __device__ __forceinline__ void sift_one_keypoint(SiftShared& sh, const vslam_point kp, const float2 a, const uint8_t* __restrict__ G,
                                                   int gpitch, int rows, int cols, const float* __restrict__ k, int kn,
                                                   float* __restrict__ desc, uint8_t* __restrict__ defined) {
     const int t = threadIdx.x;
-    if (t == 0) sh.bad = 0;
-    __syncthreads();
     const int i = t >> 4, j = t & 15;
     const int pr = rows + 2 * SIFT_PAD, pc = cols + 2 * SIFT_PAD;
     float o = 0.0f, mval = 0.0f;
@@ -79,9 +77,11 @@ __device__ __forceinline__ void sift_one_keypoint(SiftShared& sh, const vslam_po
         // division this was (a tenth of the kernel's instructions)
         int prow = px, pcol = py;
         while (pcol >= pc) pcol -= pc, ++prow;
-        if (prow >= pr) {
-            atomicOr(&sh.bad, 1);
-        } else {
+        const bool outside = prow >= pr;
+        // one flag word per wave instead of an atomic into a word that had to be cleared behind a barrier of its own
+        const bool wave_bad = __builtin_amdgcn_ballot_w64(outside) != 0ull;
+        if ((t & 63) == 0) sh.badw[t >> 6] = wave_bad;
+        if (!outside) {
             const int r = clampi(prow - SIFT_PAD, 0, rows - 1), c = clampi(pcol - SIFT_PAD, 0, cols - 1);  // padOctave(20): replicate
             const float gx = (float)((int)G[(size_t)r * gpitch + reflect101(c + 1, cols)] - (int)G[(size_t)r * gpitch + reflect101(c - 1, cols)]);
             const float gy = (float)((int)G[(size_t)reflect101(r + 1, rows) * gpitch + c] - (int)G[(size_t)reflect101(r - 1, rows) * gpitch + c]);
@@ -92,7 +92,7 @@ __device__ __forceinline__ void sift_one_keypoint(SiftShared& sh, const vslam_po
         }
     }
     __syncthreads();
-    if (sh.bad) {  // block-uniform
+    if (sh.badw[0] | sh.badw[1] | sh.badw[2] | sh.badw[3]) {  // block-uniform; the barrier below keeps a fast wave's next keypoint off these words
         if (t < SIFT_DESC) desc[t] = 0.0f;
         if (t == 0 && defined) *defined = 0;
         __syncthreads();
@@ -211,29 +211,28 @@ __device__ __forceinline__ void sift_one_keypoint(SiftShared& sh, const vslam_po
     // *max_element (operator< scan), c / max, min(c, 0.2f) as std::min, again c / max (:659-675).  The scan keeps a NaN
     // first element and skips every later NaN, i.e. its result is d[0] if that is NaN and otherwise the IEEE maxNum of all
     // elements (v_max_f32 ignores a NaN operand; the values are sums of non-negative products, so no -0 can decide a tie).
-    // Round 2 let each of the 128 threads scan all 128 values, twice (two fifths of the kernel's instructions); now the
-    // two waves that hold the values reduce them with lane exchanges and meet through two LDS words.
-    auto max_element128 = [&](float val) -> float {  // val: this thread's element (t < 128); every thread returns the maximum
-        float m = t < SIFT_DESC ? val : -INFINITY;
-        if (t < SIFT_DESC && val != val) m = -INFINITY;  // NaNs do not take part; d[0]'s NaN is handled below
+    // Round 2 let each of the 128 threads scan all 128 values, twice; round 3 reduced them in the two waves that held
+    // them, meeting through two LDS words and two barriers per maximum.  Now ONE wave holds two values per lane and both
+    // maxima are lane exchanges: no barrier behind the histogram at all - the other three waves are already at the next
+    // keypoint's samples (its first write to anything read here, sh.d, is five barriers away).
+    if (t < 64) {
+        const float d0 = sh.d[t], d1 = sh.d[t + 64];
+        auto max_element128 = [&](float x0, float x1) -> float {
+            const float first = __shfl(x0, 0);
+            float m = fmaxf(x0 != x0 ? -INFINITY : x0, x1 != x1 ? -INFINITY : x1);  // NaNs do not take part; d[0]'s NaN is handled below
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-        if ((t & 63) == 0 && t < SIFT_DESC) sh.wmax[t >> 6] = m;
-        if (t == 0) sh.first = val;
-        __syncthreads();
-        const float first = sh.first;
-        const float r = first != first ? first : fmaxf(sh.wmax[0], sh.wmax[1]);
-        __syncthreads();  // wmax / first are free again
-        return r;
-    };
-    const float d_t = t < SIFT_DESC ? sh.d[t] : 0.0f;
-    const float mx1 = max_element128(d_t);
-    float v = d_t / mx1;
-    v = 0.2f < v ? 0.2f : v;
-    const float mx2 = max_element128(v);
-    if (t < SIFT_DESC) desc[t] = v / mx2;
-    if (t == 0 && defined) *defined = 1;
-    __syncthreads();
+            for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+            return first != first ? first : m;
+        };
+        const float mx1 = max_element128(d0, d1);
+        float v0 = d0 / mx1, v1 = d1 / mx1;
+        v0 = 0.2f < v0 ? 0.2f : v0;
+        v1 = 0.2f < v1 ? 0.2f : v1;
+        const float mx2 = max_element128(v0, v1);
+        desc[t] = v0 / mx2;
+        desc[t + 64] = v1 / mx2;
+        if (t == 0 && defined) *defined = 1;
+    }
 }
 
 // Per-image entry point: grid = (keypoints), block = 256.  cs[q] = (cos, sin) of keypoint q's angle.
