@@ -89,6 +89,24 @@ __device__ __forceinline__ void sift_one_keypoint(SiftShared& sh, const vslam_po
             mval = sqrt_rn_small_nr(xx + yy);            // cv::magnitude, correctly rounded (kernels_generic.hip.h)
             sh.mag[t] = mval;
             o = fast_atan2_deg(gy, gx);                  // cv::phase(..., true)
+            if ((kn >> 1) <= SIFT_EXT_R) {
+                // Kernels up to 95 taps filter explicitly extended rows (below).  Pixel (i, j)'s magnitude stands at every extended
+                // position of row i that reflects onto column j: R + j + 30 z and R - j + 30 z (round 3 walked the extended rows
+                // element by element: a division and a modulo each).  Written here, by the pixel's own thread, the extension
+                // needs no barrier of its own.
+                constexpr int PER = 2 * (SIFT_WIN - 1);
+                const int R = kn >> 1, span = SIFT_WIN + 2 * R;
+                float* E = sh.ext + i * span;
+                int p = R + j;  // < 47 + 16
+                while (p >= PER) p -= PER;
+                for (; p < span; p += PER) E[p] = mval;
+                if (j != 0 && j != SIFT_WIN - 1) {
+                    int p0 = R - j;
+                    while (p0 < 0) p0 += PER;
+                    while (p0 >= PER) p0 -= PER;
+                    for (; p0 < span; p0 += PER) E[p0] = mval;
+                }
+            }
         }
     }
     __syncthreads();
@@ -111,20 +129,7 @@ __device__ __forceinline__ void sift_one_keypoint(SiftShared& sh, const vslam_po
         // loops' instructions).  Same products, same order.
         constexpr int PER = 2 * (SIFT_WIN - 1);
         const int span = SIFT_WIN + 2 * R;
-        {   // pixel (i, j)'s magnitude stands at every extended position of row i that reflects onto column j: R + j + 30 z and
-            // R - j + 30 z (round 3 walked the extended rows element by element: a division and a modulo each)
-            float* E = sh.ext + i * span;
-            int p = R + j;  // < 47 + 16
-            while (p >= PER) p -= PER;
-            for (; p < span; p += PER) E[p] = mval;
-            if (j != 0 && j != SIFT_WIN - 1) {
-                int p0 = R - j;
-                while (p0 < 0) p0 += PER;
-                while (p0 >= PER) p0 -= PER;
-                for (; p0 < span; p0 += PER) E[p0] = mval;
-            }
-        }
-        __syncthreads();
+        // (the extended rows were written with the samples, in front of the barrier that also covers the flags)
         // The taps come through SCALAR loads (the same address in every lane: s_load, the tap a scalar operand of the
         // multiply): with both operands read from the LDS the two filter loops were bound by LDS issue (two reads per
         // product for four waves), not by arithmetic.
