@@ -45,11 +45,17 @@ constexpr int SIFT_KMAX = 640;  // blur taps staged in LDS (309 for octave 3 of 
 constexpr int SIFT_EXT_R = 47;  // kernels up to 95 taps (octaves 0 and 1 of the reference pyramid: 25 ... 77) filter explicitly extended rows
 constexpr int SIFT_EXT_SPAN = SIFT_WIN + 2 * SIFT_EXT_R;
 struct SiftShared {
-    float ext[SIFT_WIN * SIFT_EXT_SPAN];   // rows of magROI extended by the repeated reflect-101, [row][R + 16 + R]
-    float extc[SIFT_EXT_SPAN * SIFT_WIN];  // the row-filtered ROI extended likewise along the rows, [R + 16 + R][col]
-    float kt[SIFT_KMAX];
+    union {  // a keypoint takes one of the two filter forms
+        struct {
+            float ext[SIFT_WIN * SIFT_EXT_SPAN];   // rows of magROI extended by the repeated reflect-101, [row][R + 16 + R]
+            float extc[SIFT_EXT_SPAN * SIFT_WIN];  // the row-filtered ROI extended likewise along the rows, [R + 16 + R][col]
+        };
+        struct {
+            float kt[SIFT_KMAX];
+            float rowf[SIFT_WIN * SIFT_WIN];  // row-filtered ROI
+        };
+    };
     float mag[SIFT_WIN * SIFT_WIN];   // magROI
-    float rowf[SIFT_WIN * SIFT_WIN];  // row-filtered ROI
     float mw[SIFT_WIN * SIFT_WIN];    // magWeighted
     float d[SIFT_DESC];
     uint8_t bin[SIFT_WIN * SIFT_WIN];
@@ -265,7 +271,9 @@ struct SiftBatchGeom {
     float2 cs36[36];
 };
 
-__global__ __launch_bounds__(256) void k_sift_descriptors_batch(const vslam_point* __restrict__ oriented, const unsigned int* __restrict__ counts,
+// Eight workgroups per CU (the wave limit): 16.8 KB of LDS each - the two filter forms share their arrays - and at most 64
+// vector registers (57 used, nothing spilled); with 20.3 KB and 73 registers it was seven, and 8.4 ms per dense step against 7.1.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_sift_descriptors_batch(const vslam_point* __restrict__ oriented, const unsigned int* __restrict__ counts,
                                                                  unsigned int cap, const uint8_t* __restrict__ pyr, size_t pframe,
                                                                  SiftBatchGeom g, float* __restrict__ desc, uint8_t* __restrict__ defined) {
     __shared__ SiftShared sh;
