@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256) void k_level_gradients(const uint8_t* __restri
     if (gy) gy[o] = y;
     if (mag) {
         const float xx = x * x, yy = y * y;
-        mag[o] = sqrt_rn_small(xx + yy);  // IEEE-correct f32 square root (the bare v_sqrt_f32 is not)
+        mag[o] = sqrt_rn_small_nr(xx + yy);  // IEEE-correct f32 square root (the bare v_sqrt_f32 is not)
     }
     if (orient) orient[o] = fast_atan2_deg(y, x);
 }

@@ -24,7 +24,8 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? l
 
 // Correctly rounded f32 square root (cv::magnitude on x86 is sqrtss / sqrtps) for the arguments this
 // library has: x*x + y*y of integer Sobel differences, i.e. integers in [0, 2 * 255^2] - normal numbers
-// or zero, so the denormal scaling of the general sequence is not needed.  v_sqrt_f32 is within one ulp;
+// or zero, so the denormal scaling of the general sequence is not needed.  (Round 3's form, kept as the reference of
+// tools/sqrt_check.hip; the kernels use the 6-operation sqrt_rn_small_nr / sqrt_rn_small_pk below.)  v_sqrt_f32 is within one ulp;
 // the two exact residuals (one FMA each) decide between the result and its neighbours.  9 instructions
 // instead of the f64 square root the round-2 kernels used (tools/sqrt_check.hip compares the two over
 // every possible argument).

@@ -77,7 +77,7 @@ __device__ __forceinline__ float magnitude_at(const uint8_t* __restrict__ G, int
     float x, y;
     gradient_at(G, gpitch, rows, cols, r, c, x, y);
     const float xx = x * x, yy = y * y;
-    return sqrt_rn_small(xx + yy);  // correctly rounded f32 square root
+    return sqrt_rn_small_nr(xx + yy);  // correctly rounded f32 square root (6 operations; tools/sqrt_check.hip)
 }
 
 // The survivor list of a frame is in list order, i.e. octave by octave and, inside an octave, level by level
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void k_orient_survivors(const vslam_point* __r
                 const uint8_t* c0 = Pb + off;
                 const float gx = (float)((int)c0[1] - (int)c0[-1]), gy = (float)((int)c0[pb] - (int)c0[-pb]);
                 const float xx = gx * gx, yy = gy * gy;
-                M[it] = sqrt_rn_small(xx + yy);
+                M[it] = sqrt_rn_small_nr(xx + yy);
                 cc += dr;
                 const bool wrap = cc >= span;
                 cc -= wrap ? span : 0;
