@@ -416,6 +416,21 @@ def main():
                                "oriented_cap": int(m["p"].oriented_cap)} if orr else {}),
                            **({"what": "the whole DoG executable: pyramid, initialKeypointDetection, filterKeypoints, SIFT descriptors of every oriented point"} if de else {}),
                            **({"what": "extension: dense 3x3x3 scale-space test on every pixel of levels 1..3 (params.extrema_dense) instead of the reference's lattice test"} if dn else {})}
+        # the same list modes with the OPT-IN matrix path on (reported inside `mx_path`, never beside `value`)
+        if mxp and "error" not in mxp:
+            try:
+                ctx.set_matrix_path(True)
+                mxp["modes"] = {}
+                for name, (lz, orr, de) in (("localize", (1, 0, 0)), ("orient", (1, 1, 0)), ("describe", (1, 1, 1))):
+                    ms = max(2, args.steps // 2)
+                    m = run_mode(lz, orr, ms, 1, None, de, 0, frames_t=mixed)
+                    mxp["modes"][name] = {"frames_per_sec": n * world * ms / m["dt"], "ms_per_step": m["dt"] / ms * 1e3,
+                                          "same_counts_as_default_path": bool(m["dog"] == modes[name]["dog_points_per_step"] and
+                                                                             (not orr or m["oriented"] == modes[name]["oriented_points_per_step"]))}
+            except Exception as e:
+                mxp["modes"] = {"error": str(e)[:200]}
+            finally:
+                ctx.set_matrix_path(False)
         del mixed
     leg("modes")
 
@@ -535,6 +550,8 @@ def main():
                 },
                 "pipeline_hbm_frac_of_peak": bytes_frame * (n * args.steps / mxp["dt"]) / 1e9 / HBM_PEAK_GBPS,
             }
+            if mxp.get("modes"):
+                mx_obj["modes"] = dict(mxp["modes"], content="as `modes`: every second frame uniform noise")
             if mxp["alone"] and mxp["alone"][0] and mxp["alone"][1] > 0:
                 a_ms_step = mxp["alone"][1] / 3
                 mx_obj["k_pyr_octave_mx"]["alone"] = {"kernel_ms_per_step": a_ms_step, "achieved": a_bytes * n / (a_ms_step * 1e-3) / 1e9,

@@ -80,6 +80,8 @@ def test_bench_one_rank_goes_through_rccl():
     # the opt-in matrix path beside the headline: same counts, its own kernel figures, never `value`
     assert d["config"]["matrix_path"] is False and d["mx_path"]["same_keypoint_counts_as_value"] is True and d["mx_path"]["frames_per_sec"] > 0
     assert d["mx_path"]["k_pyr_octave_mx"]["launches_per_step"] >= 2
+    for name in ("localize", "orient", "describe"):  # the list modes with the matrix path on: the default path's counts
+        assert d["mx_path"]["modes"][name]["same_counts_as_default_path"] is True and d["mx_path"]["modes"][name]["frames_per_sec"] > 0
     assert d["cxx_host"]["device"]["frames_per_sec"] > 0 and "RCCL" in d["cxx_host"]["device"]["host"]
     assert d["cxx_host"]["device"]["keypoints_per_batch"] == {"harris": d["keypoints_per_step"]["harris"], "dog": d["keypoints_per_step"]["dog"]}
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--frames", "8", "--rows", "240", "--cols", "320", "--steps", "2",
