@@ -17,7 +17,8 @@
 //     instruction per product-and-sum of two rows, where the round-3 form took 2.5 and two LDS reads;
 //   * column pass: two adjacent columns per thread, the same way;
 //   * one launch per (octave, level): the span, the tap count and the LDS layout are the launch's constants and the
-//     footprint is the level's own (11 / 14 / 18 KB for octave 0's three levels: 14 / 11 / 9 workgroups per CU).
+//     footprint is the level's own (11 / 14 / 18 KB for octave 0's three levels: room for 14 / 11 / 9 workgroups per CU; the register cap below
+//     makes it 12 / 11 / 9).
 // A zero tap adds +0 to a non-negative sum, which leaves every bit of it alone: the tap arrays are zero-padded (three in
 // front for the sliding window, to a multiple of four behind), steps that would read past a row are skipped.
 //
@@ -84,7 +85,7 @@ __host__ __device__ inline int orient_taps_pk_floats(int n) { return orient_taps
 constexpr int OR_PK_MAX_SPAN = 60;  // 16 four-column groups cover byte sh + span of a patch row (sh <= 3)
 // LDS floats of a launch for one level's span (even, <= OR_PK_MAX_SPAN): magnitude region as row pairs (the window's
 // weights take its first KB once the row pass has read it), patch / strip overlay, bin masks.  11 / 14 / 18 KB for the three
-// levels of octave 0 = 14 / 11 / 9 workgroups per CU, where one launch per octave (the widest level's footprint) had 8.
+// levels of octave 0 = room for 14 / 11 / 9 workgroups per CU, where one launch per octave (the widest level's footprint) had 8.
 __host__ __device__ inline int orient_pk_mp(int span) { return span + 7; }                     // 8-byte words per row pair: the row pass reads up to column span + 6; odd: bank spread
 __host__ __device__ inline int orient_pk_pp(int span) { return (((span + 8) >> 2) + 2) | 1; }  // dwords per patch row, one pad dword either side
 __host__ __device__ inline int orient_pk_m2_floats(int span) { return ((span >> 1) * orient_pk_mp(span) * 2 + 3) & ~3; }  // what follows stays 16-byte aligned
