@@ -417,8 +417,10 @@ int vslam_batch_out_required(const vslam_params* p, int n_frames, vslam_batch_ou
  * output written once; frames are independent, so a multi-GPU job shards frames across
  * ranks with no data-path collective.
  * Stream capture: a call may be recorded into a hipGraph (hipStreamBeginCapture on the context's stream ... EndCapture)
- * once ONE call with the same parameters and batch size has run outside a capture - the workspace, the blur taps and the
- * side streams are created by the first call, and a capture can allocate nothing.  The side-stream forks all start from
+ * once ONE call with the same parameters, the same batch size AND the same matrix-path setting
+ * (vslam_ctx_set_matrix_path) has run outside a capture - the workspace, the blur taps (each path has its own tables) and
+ * the side streams are created by the first call, and a capture can allocate nothing: a captured call that finds a table
+ * missing returns VSLAM_ERR_UNSUPPORTED and launches nothing more.  The side-stream forks all start from
  * and join back to the capturing stream; the stream tuner does not time captured calls
  * (tests/test_gpu_batch.py::test_batch_call_captured_into_a_graph). */
 int vslam_detect_batch_dev(vslam_ctx* ctx, const vslam_params* p, const uint8_t* d_frames, size_t frame_stride,

@@ -562,7 +562,11 @@ def test_stream_tuner_never_blocks_the_host():
             enq.append(time.perf_counter() - t)
         torch.cuda.synchronize()
         per_call = (time.perf_counter() - t0) / 8
-        assert max(enq) < 0.5 * per_call, (enq, per_call)  # a host-side wait for the previous call would cost a whole per_call
+        # a host-side wait for an earlier call would make the enqueue times add up to the GPU time.  The property is asserted
+        # on sums and on the calls that create nothing (calls 2-5 create the candidate streams and their events,
+        # runtime calls that can take milliseconds on a busy box - a per-call wall-clock bound on those flakes)
+        assert sum(enq) < 0.5 * 8 * per_call, (enq, per_call)
+        assert sorted(enq)[len(enq) // 2] < 0.25 * per_call and max(enq[5:]) < 0.5 * per_call, (enq, per_call)
         assert ctx.side_stream_report()[1] in (1, 2)
         ctx.detect_batch(p, frames, **o)  # everything has finished: this call decides
         torch.cuda.synchronize()
@@ -709,6 +713,70 @@ def test_matrix_path_switch_per_context(env):
             assert np.array_equal(a[k], b[k]), k
     for f in range(3):
         check_frame(p, L, b, f, frames[f], 4)
+
+
+def test_matrix_path_two_chunks_of_1080p_frames(env):
+    # on the matrix path the fused lattice scan leaves its site / seam maps in scratch that the octave
+    # kernels write on the MAIN stream and k_extrema_pack reads on a low-priority SIDE stream; a call with more than 256
+    # frames reuses that scratch for its second chunk, so the second chunk's octave kernels must wait for the first chunk's
+    # pack launches (ev_pack).  512 distinct 1080p frames (every eighth one noise), matrix path on: masks, counts and lists of
+    # ALL frames against the default path's (device-side compares; that path has no such scratch), and the frames on both
+    # sides of the chunk seam against the oracle.
+    ctx, torch = env
+    n, rows, cols = 512, 1080, 1920
+    dev = "cuda:0"
+    frames = synth.frames_torch(n, rows, cols, stream_id=77, device=dev, noise_every=8)
+    p = capi.default_params(rows, cols)
+    L = capi.batch_layout(p)
+    pyr = torch.empty((n, L.pyramid_frame_bytes), dtype=torch.uint8, device=dev)  # shared by both runs (62 GB)
+    was = ctx.matrix_path()
+    res = {}
+    try:
+        for mx in (True, False):
+            ctx.set_matrix_path(mx)
+            o = dict(pyramid=pyr, extrema_bits=torch.zeros((n, L.bits_frame_words), dtype=torch.int64, device=dev),
+                     dog_points=torch.zeros((n, p.dog_cap, 6), dtype=torch.int32, device=dev),
+                     dog_counts=torch.zeros(n, dtype=torch.int32, device=dev))
+            if mx:
+                ctx.kernel_timing_enable("k_pyr_octave_mx")
+            ctx.detect_batch(p, frames, **o)
+            torch.cuda.synchronize()
+            if mx:
+                launches, _ = ctx.kernel_timing_read()
+                ctx.kernel_timing_enable(None)
+                assert launches == 8  # four octaves, two chunks
+                seam = {f: pyr[f].cpu().numpy() for f in (255, 256)}
+            res[mx] = o
+    finally:
+        ctx.set_matrix_path(was)
+    a, b = res[True], res[False]
+    assert torch.equal(a["dog_counts"], b["dog_counts"])
+    assert torch.equal(a["extrema_bits"], b["extrema_bits"])
+    cnt = a["dog_counts"].cpu().numpy()
+    assert (cnt <= p.dog_cap).all() and cnt.min() > 0
+    for f in range(n):
+        assert torch.equal(a["dog_points"][f, : int(cnt[f])], b["dog_points"][f, : int(cnt[f])]), f
+    for f in (255, 256):
+        img = frames[f].cpu().numpy()
+        want = oracle.Pyramid(img, 4, p.sigma0)
+        pts = []
+        for oc in range(4):
+            r, c = want.sizes[oc]
+            pitch, off = L.pitch[oc], L.octave_offset[oc]
+            P = r * pitch
+            for l in range(5):
+                assert (seam[f][off + (6 + l) * P: off + (7 + l) * P].reshape(r, pitch)[:, :c] == want.dog(oc, l)).all(), (f, "dog", oc, l)
+            wm, wp = want.extrema(oc, 3, p.min_contrast)
+            lr, lc, wpr = L.lat_rows[oc], L.lat_cols[oc], L.lat_words[oc]
+            words = a["extrema_bits"][f].cpu().numpy()[L.bits_offset[oc]: L.bits_offset[oc] + 3 * lr * wpr].view(np.uint64)
+            gm = np.unpackbits(words.view(np.uint8).reshape(3, lr, wpr * 8), axis=-1, bitorder="little")[..., :lc]
+            assert (gm == wm).all(), (f, "mask", oc)
+            pts.append(wp)
+        want.close()
+        allp = np.concatenate(pts)
+        assert int(cnt[f]) == len(allp)
+        m = min(len(allp), p.dog_cap)
+        assert a["dog_points"][f][:m].cpu().numpy().view(capi.POINT_DTYPE).reshape(-1).tobytes() == allp[:m].tobytes(), f
 
 
 def test_batch_random_shapes(env):

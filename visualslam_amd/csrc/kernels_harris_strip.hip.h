@@ -337,7 +337,7 @@ __device__ __forceinline__ void harris_strip_rows(const HarrisStripArgs& a, cons
     const bool fast_ok = !EDGE && !ANYW && a.resp && a.mask && a.flags && !a.nms2 && a.dump;  // wave-uniform
     const int y_lo = max(y_begin, 2), y_hi = min(y_end, rows - 2);
     int t0 = t_begin;
-    const int t_hi = min(y_hi + 3, rows - 7);  // a steady trip starts at t0 <= t_hi: its last row y = t0 + 1 < y_hi, its last prefetch t0 + 7 < rows
+    const int t_hi = min(y_hi - 1, rows - 7);  // a steady trip starts at t0 < t_hi: its last row y = t0 + 1 < y_hi (the segment's own rows only: the next segment's wave stores its own), its last prefetch t0 + 7 < rows
     for (; t0 <= t_end && !(fast_ok && t0 - 4 >= y_lo && t0 < t_hi && t0 + 2 >= 0); t0 += 6) trip(std::false_type{}, t0);
     if constexpr (!EDGE && !ANYW) {
         // one steady trip peeled in front of the loop: the loop header's counter state is the join of the entry edge and the

@@ -76,6 +76,11 @@ struct vslam_ctx {
     bool phase_marked = false;
     hipEvent_t ev_up2 = nullptr;  // the second half of a batch has been upsampled (enqueue_dog)
     hipEvent_t ev_chunk = nullptr;  // the main-stream kernels of a chunk (the readers of the octave bases) are enqueued up to here
+    // matrix path, fused lattice scan: the side stream's k_extrema_pack launches of a chunk have read the site / seam maps
+    // (the one scratch of the DoG path written on the main stream and read on a side stream: the next chunk's octave
+    // kernels wait for this before they overwrite it)
+    hipEvent_t ev_pack = nullptr;
+    bool pack_pending = false;
     hipEvent_t ev_list0 = nullptr, ev_edge = nullptr;  // octave 0's part of the DoG list is written / its edge test is done
     hipEvent_t ev_or_fork = nullptr, ev_or_join[2] = {nullptr, nullptr};  // the orientation launches spread over the idle side streams (enqueue_orient_batch)
     // recycled pyramid blocks: a GaussPyramid per image would otherwise pay hipMalloc + hipFree of
@@ -301,6 +306,7 @@ static int ensure_aux(vslam_ctx* c) {
     for (auto& e : c->ev_oct) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_up2, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_chunk, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_pack, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_list0, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_edge, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_or_fork, hipEventDisableTiming));
@@ -381,6 +387,19 @@ static T* ws_take(vslam_ctx* c, size_t count) {
 }
 static inline size_t ws_need(size_t bytes) { return align_up(bytes, 256); }
 
+// One-time device tables (tap matrices) are allocated and copied with blocking calls: inside a stream capture that would
+// invalidate the capture, so a call that still needs one says so instead (include/vslam.h: the warm-up call must run with
+// the same parameters AND the same matrix-path setting as the captured one).
+static bool stream_is_capturing(vslam_ctx* c) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(c->stream, &cap) != hipSuccess) (void)hipGetLastError();
+    return cap != hipStreamCaptureStatusNone;
+}
+#define NO_TABLE_IN_CAPTURE(ctx, what)                                                                                         \
+    if (stream_is_capturing(ctx))                                                                                              \
+    return fail(ctx, VSLAM_ERR_UNSUPPORTED, what ": its tap tables are not on the device yet and cannot be put there during a stream capture - " \
+                                            "run one warm-up call with the same parameters and the same matrix-path setting first")
+
 // Device copy of the (zero-trimmed) quantised taps of one GaussianBlur; *n_eff = trimmed width.
 static int get_taps(vslam_ctx* c, int n, double sigma, const uint16_t** out, int* n_eff) {
     uint64_t sb;
@@ -391,6 +410,7 @@ static int get_taps(vslam_ctx* c, int n, double sigma, const uint16_t** out, int
     *n_eff = (int)h.size();
     auto it = c->taps.find(key);
     if (it == c->taps.end()) {
+        NO_TABLE_IN_CAPTURE(c, "Gaussian blur");
         uint16_t* d = nullptr;
         HIPCHK(c, hipMalloc((void**)&d, sizeof(uint16_t) * h.size()));
         HIPCHK(c, hipMemcpy(d, h.data(), sizeof(uint16_t) * h.size(), hipMemcpyHostToDevice));
@@ -489,6 +509,7 @@ static int get_strip_taps(vslam_ctx* c, double sigma0, int o, const OctPlan& pl,
     auto key = std::make_pair(sb, o);
     auto it = c->strip_taps.find(key);
     if (it == c->strip_taps.end()) {
+        NO_TABLE_IN_CAPTURE(c, "strip kernels");
         const uint16_t* tp[6];
         for (int l = 0; l < 6; ++l) tp[l] = pl.taps[l].data();
         std::vector<StripTaps> st(1);
@@ -742,6 +763,7 @@ static int enqueue_pyr_octave(vslam_ctx* c, double sigma0, int o, const OctPlan&
     auto key = std::make_pair(sb, o);
     auto it = c->tile_taps.find(key);
     if (it == c->tile_taps.end()) {
+        NO_TABLE_IN_CAPTURE(c, "octave kernel");
         const uint16_t* tp[6];
         for (int l = 0; l < 6; ++l) tp[l] = pl.taps[l].data();
         std::vector<PyrTaps<CFG>> host(1);
@@ -772,6 +794,7 @@ static int enqueue_pyr_octave_mx(vslam_ctx* c, int cfg, double sigma0, int o, co
     auto key = std::make_pair(sb, o);
     auto it = c->mx_taps.find(key);
     if (it == c->mx_taps.end()) {
+        NO_TABLE_IN_CAPTURE(c, "matrix-core octave kernel");
         const uint16_t* tp[6];
         for (int l = 0; l < 6; ++l) tp[l] = pl.taps[l].data();
         std::vector<char> host(mx_taps_bytes(cfg));
@@ -891,6 +914,12 @@ static int enqueue_dog(vslam_ctx* c, const vslam_params& p, const vslam_batch_la
         HIPCHK(c, hipEventRecord(c->ev_up2, c->stream));
     }
     bool fused[VSLAM_MAX_OCTAVES] = {};
+    // a later chunk reuses the site / seam maps: its octave kernels (main stream) must not overwrite them while the previous
+    // chunk's k_extrema_pack launches (side stream, low priority, possibly on a slow hardware queue) are still reading
+    if (later_chunk && c->pack_pending) {
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_pack, 0));
+        c->pack_pending = false;
+    }
     for (int o = 0; o < L.n_octaves; ++o) {
         const int rows = L.rows[o], cols = L.cols[o], pitch = L.pitch[o];
         const size_t P = (size_t)rows * pitch;
@@ -991,6 +1020,10 @@ static int enqueue_dog(vslam_ctx* c, const vslam_params& p, const vslam_batch_la
                 if (n_straddle > 0)
                     hipLaunchKernelGGL(k_extrema_w3<false>, dim3((L.lat_words[o] + 3) / 4, n_straddle, nf), dim3(256), 0, es, pyr, pframe, g, o, bits, s.lflags,
                                        L.bits_frame_words, 32, 32);
+                if (es != c->stream) {  // the maps' reader is on another stream than their writer: mark its end for the next chunk
+                    HIPCHK(c, hipEventRecord(c->ev_pack, es));
+                    c->pack_pending = true;
+                }
             } else if (p.extrema_window == 3) {
                 const dim3 eg((L.lat_words[o] + 3) / 4, L.lat_rows[o], nf);
                 if (p.localize)
@@ -1164,7 +1197,7 @@ int vslam_ctx_destroy(vslam_ctx* c) {
         if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
     }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    for (hipEvent_t e : {c->ev_phase, c->ev_up2, c->ev_chunk, c->ev_list0, c->ev_edge, c->ev_or_fork, c->ev_or_join[0], c->ev_or_join[1]})
+    for (hipEvent_t e : {c->ev_phase, c->ev_up2, c->ev_chunk, c->ev_pack, c->ev_list0, c->ev_edge, c->ev_or_fork, c->ev_or_join[0], c->ev_or_join[1]})
         if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ev_oct)
         if (e) (void)hipEventDestroy(e);
@@ -1833,6 +1866,7 @@ static int get_orient_taps(vslam_ctx* c, double sigma, const float** out, int* n
     auto key = std::make_pair(sb, n);
     auto it = c->orient_taps.find(key);
     if (it == c->orient_taps.end()) {
+        NO_TABLE_IN_CAPTURE(c, "filterKeypoints");
         std::vector<float> t;
         if (!gauss_kernel_f32(n, sigma, t)) return fail(c, VSLAM_ERR_INVALID, "filterKeypoints: bad blur kernel");
         // behind the taps: the zero-padded row / column forms k_orient_survivors_pk reads through scalar loads
@@ -2077,6 +2111,7 @@ int vslam_detect_batch_dev(vslam_ctx* c, const vslam_params* pp, const uint8_t* 
                 ws_need(4 * compaction_ws_elems(harris_flag_words(p.rows, p.cols), chunk));
     if (orient) need += orient_scratch_bytes(p, chunk);
     c->phase_marked = false;
+    c->pack_pending = false;  // the previous call joined its side streams back
     TRY(ws_reserve(c, need));
     DogScratch s;
     if (dog) TRY(dog_scratch_take(c, L, p.sigma0, chunk, s, want_sitemap));

@@ -120,14 +120,27 @@ static void tcp_rendezvous(const RankEnv& env, void* bytes, size_t n, std::vecto
                      (ignored ? " (" + std::to_string(ignored) + " foreign connection(s) ignored)" : ""));
             }
             const int fd = ::accept(ls, nullptr, nullptr);
-            if (fd < 0) continue;
+            if (fd < 0) {
+                // transient: the peer gave up between poll() and accept(), or a signal.  Anything else (EMFILE, ENFILE,
+                // ENOMEM ...) leaves the listening socket readable - retrying would spin to the deadline and then blame the ranks
+                if (errno == EINTR || errno == ECONNABORTED || errno == EAGAIN || errno == EWOULDBLOCK) continue;
+                const std::string msg = std::string("rendezvous: accept(): ") + std::strerror(errno);
+                ::close(ls);
+                fail(msg);
+            }
             Hello h{};
-            const bool ok = io_all(fd, &h, sizeof(h), false, 2000) && h.magic == kHelloMagic && h.token == job_token() && h.rank > 0 && h.rank < env.world &&
-                            !seen[h.rank] && io_all(fd, bytes, n, true);
-            if (!ok) {
+            const bool hello_ok = io_all(fd, &h, sizeof(h), false, 2000) && h.magic == kHelloMagic && h.token == job_token() && h.rank > 0 &&
+                                  h.rank < env.world && !seen[h.rank];
+            if (!hello_ok) {  // not one of this job's ranks
                 ::close(fd);
                 ++ignored;
                 continue;
+            }
+            if (!io_all(fd, bytes, n, true)) {  // a rank of this job whose payload could not be sent: it will not come back
+                const std::string msg = "rendezvous: sending to rank " + std::to_string(h.rank) + " failed: " + std::strerror(errno);
+                ::close(fd);
+                ::close(ls);
+                fail(msg);
             }
             if (keep) {
                 const int one_ = 1;
