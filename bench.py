@@ -69,16 +69,38 @@ def cpu_baseline(rows, cols, n_oct, sample_frames, gpu_keypoints=None):
     t0 = time.perf_counter()
     kp = oracle.baseline_frames(frames, n_oct, threads=1)
     dt = time.perf_counter() - t0
+    # ALL host cores.  The box may give this process fewer CPUs than it shows (affinity mask, cgroup
+    # quota): both are reported, the run uses one thread per CPU of the affinity mask, and the 64-thread figure the
+    # earlier rounds reported stays beside it.
     allcores = None
     try:
-        cores = min(len(os.sched_getaffinity(0)), 64)
-        if cores > 1:
-            many = synth.frames_np(2 * cores, rows, cols, stream_id=0)
-            t1 = time.perf_counter()
-            oracle.baseline_frames(many, n_oct, threads=cores)
-            d2 = time.perf_counter() - t1
-            allcores = {"value": len(many) / d2, "unit": "frames/s", "cores": cores,
-                        "sample": f"{len(many)} frames, OpenMP over frames in oracle/vslam_oracle.c ({cores} threads)"}
+        affinity = len(os.sched_getaffinity(0))
+        quota = None
+        try:
+            q = open("/sys/fs/cgroup/cpu.max").read().split()
+            if q and q[0] != "max":
+                quota = float(q[0]) / float(q[1])
+        except (OSError, ValueError, IndexError):
+            pass
+        if affinity > 1:
+            base_n = min(2 * 64, 2 * affinity)
+            many = synth.frames_np(base_n, rows, cols, stream_id=0)
+
+            def run(threads, nfr):
+                fr = many if nfr == len(many) else np.concatenate([many] * ((nfr + len(many) - 1) // len(many)))[:nfr]
+                t1 = time.perf_counter()
+                oracle.baseline_frames(fr, n_oct, threads=threads)
+                d2 = time.perf_counter() - t1
+                return {"value": nfr / d2, "unit": "frames/s", "cores": threads,
+                        "sample": f"{nfr} frames, OpenMP over frames in oracle/vslam_oracle.c ({threads} threads)"}
+
+            import numpy as np
+
+            allcores = run(affinity, 2 * affinity if affinity <= 64 else affinity)  # > 64 threads: one frame each (bounded run time)
+            allcores["affinity_cpus"] = affinity
+            allcores["cgroup_cpu_quota"] = quota
+            if affinity > 64:
+                allcores["threads_64"] = run(64, 128)
     except Exception as e:  # the single-thread figure is the reported baseline
         allcores = {"error": repr(e)}
     return {
@@ -90,6 +112,7 @@ def cpu_baseline(rows, cols, n_oct, sample_frames, gpu_keypoints=None):
         "sample": f"{sample_frames} synthetic {cols}x{rows} frames, Harris+NMS+DoG pyramid+extrema, oracle/vslam_oracle.c -O2, 1 thread",
         "keypoints_per_sec": kp / dt,
         "host_cpus": os.cpu_count(),
+        "threads_used": {"value": 1, "all_cores": (allcores or {}).get("cores")},
         "cpu_model": cpu_model(),
         # the same frames give the same keypoint counts on both paths (Harris list + DoG list
         # with value >= 8 of the sample's frames, which are the first frames of rank 0's batch)
@@ -368,6 +391,107 @@ def main():
         ctx.kernel_timing_enable(None)
         return launches, kms
 
+    def by_kernel(p, L, out, matrix_path, steps=2):
+        """every major kernel of the step priced against the HBM roof in the driver's own line.  One extra
+        pass of `steps` full steps PER KERNEL outside the timed region, the library's HIP-event hook (vslam_kernel_timing_*)
+        around that kernel's launches only ("name@o" = the launches of octave o), on the stream each launch goes to: the
+        durations are the in-step ones (the kernel beside whatever the schedule runs with it).  Algorithmic bytes per frame
+        as SURVEY 8d attributes them (kernel_algorithmic_bytes); a scan's are the mask words it is there to write."""
+        N = rows * cols
+        P = [L.rows[o] * L.cols[o] for o in range(L.n_octaves)]
+        mask_b = [3 * L.lat_rows[o] * L.lat_words[o] * 8 for o in range(L.n_octaves)]
+        items = [("k_harris_strip", None, 6 * N, "frame in, f32 response + u8 NMS mask out (6N)")]
+        if matrix_path:
+            for o in range(min(L.n_octaves, 4)):
+                items.append(("k_pyr_octave_mx", o, 11 * P[o] + (N if o == 0 else 0), "6 Gaussian + 5 DoG planes of the octave" + (" + the frame (fused x2 upsample, lattice scan inside)" if o == 0 else "")))
+            for o in range(min(L.n_octaves, 2)):
+                items.append(("k_extrema_pack", o, mask_b[o], "site bytes of the fused scan -> candidate mask words"))
+            for o in range(L.n_octaves):
+                items.append(("k_extrema_w3", o, mask_b[o] if o >= 2 else mask_b[o] // 32, "lattice scan: whole octave (o >= 2) or the straddling rows only"))
+        else:
+            items.append(("k_resize_linear2x_slide", None, N, "the DoG path's read of the frame (x2 bilinear upsample into the octave-0 base)"))
+            for o in range(min(L.n_octaves, 2)):
+                items.append(("k_pyr_octave", o, 11 * P[o], "6 Gaussian + 5 DoG planes of the octave"))
+            for o in range(2, L.n_octaves):
+                items.append(("k_gauss_v_strip", o, None, "vertical pass into the u16 scratch (intermediate: priced with the horizontal pass)"))
+                items.append(("k_gauss_h_strip", o, 11 * P[o], "horizontal pass + DoG: 6 Gaussian + 5 DoG planes of the octave (frac is for v + h together)"))
+            for o in range(L.n_octaves):
+                items.append(("k_extrema_w3", o, mask_b[o], "lattice scan: candidate mask words (re-reads the DoG planes: traffic, not algorithmic bytes)"))
+        items.append(("k_flag_scatter", None, None, "list records (Harris + DoG lists)"))
+        res, last_v = [], {}
+        for name, o, ab, what in items:
+            ctx.kernel_timing_enable(name if o is None else f"{name}@{o}")
+            for _ in range(steps):
+                ctx.detect_batch(p, frames, **out)
+            fence()
+            nl, ms = ctx.kernel_timing_read()
+            ctx.kernel_timing_enable(None)
+            if nl == 0:
+                continue
+            e = {"kernel": name, "octave": o, "launches_per_step": nl / steps, "avg_launch_ms": ms / nl, "ms_per_step": ms / steps,
+                 "algorithmic_bytes_per_frame": ab, "what": what}
+            if name == "k_gauss_v_strip":
+                last_v[o] = ms / steps
+            t = ms / steps + (last_v.get(o, 0.0) if name == "k_gauss_h_strip" else 0.0)
+            if ab and t > 0:
+                e["achieved_GBps"] = ab * n / (t * 1e-3) / 1e9
+                e["frac"] = e["achieved_GBps"] / HBM_PEAK_GBPS
+            res.append(e)
+        return res
+
+    def config_legs(steps=3):
+        """BASELINE configs 2 and 3 as batches of the same frames (the driver line's `value` is config 4, both fused):
+        Harris + NMS only, and DoG pyramid + extrema only."""
+        res = {}
+        N = rows * cols
+        try:
+            p2 = capi.default_params(rows, cols, n_octaves=0)
+            o2 = {k: shared[k] for k in ("response", "nms_mask", "harris_kps", "harris_counts")}
+            ctx.detect_batch(p2, frames, **o2)
+            fence()
+            ctx.kernel_timing_enable("k_harris_strip")
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                ctx.detect_batch(p2, frames, **o2)
+            fence()
+            d = time.perf_counter() - t0
+            nl, ms = ctx.kernel_timing_read()
+            ctx.kernel_timing_enable(None)
+            res["config2_harris_only"] = {
+                "what": "BASELINE config 2 as a batch: Harris response + NMS mask + keypoint list, no pyramid", "steps": steps,
+                "frames_per_sec": n * world * steps / d, "ms_per_step": d / steps * 1e3, "algorithmic_bytes_per_frame": 6 * N,
+                "pipeline_frac_of_peak": 6 * N * (n * steps / d) / 1e9 / HBM_PEAK_GBPS,
+                "k_harris_strip": {"avg_launch_ms": ms / max(nl, 1), "achieved_GBps": 6 * N * n * steps / (ms * 1e-3) / 1e9 if ms > 0 else None,
+                                   "frac": 6 * N * n * steps / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if ms > 0 else None, "bound": "hbm"}}
+        except Exception as e:
+            res["config2_harris_only"] = {"error": str(e)[:200]}
+        try:
+            p3 = capi.default_params(rows, cols, n_octaves=args.octaves)
+            L3 = capi.batch_layout(p3)
+            o3 = {k: shared[k] for k in ("pyramid", "extrema_bits", "dog_points", "dog_counts")}
+            ctx.detect_batch(p3, frames, **o3)
+            fence()
+            ctx.kernel_timing_enable("k_pyr_octave")
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                ctx.detect_batch(p3, frames, **o3)
+            fence()
+            d = time.perf_counter() - t0
+            nl, ms = ctx.kernel_timing_read()
+            ctx.kernel_timing_enable(None)
+            ab = L3.algorithmic_bytes_dog
+            a01 = 11 * sum(L3.rows[o] * L3.cols[o] for o in range(min(2, L3.n_octaves)))
+            res["config3_dog_only"] = {
+                "what": f"BASELINE config 3 as a batch: DoG pyramid {args.octaves} octaves x (6 Gaussian, 5 DoG) + extrema masks + candidate list, no Harris chain",
+                "steps": steps, "frames_per_sec": n * world * steps / d, "ms_per_step": d / steps * 1e3, "algorithmic_bytes_per_frame": ab,
+                "pipeline_frac_of_peak": ab * (n * steps / d) / 1e9 / HBM_PEAK_GBPS,
+                "k_pyr_octave": {"launches_per_step": nl / steps, "kernel_ms_per_step": ms / steps,
+                                 "achieved_GBps": a01 * n * steps / (ms * 1e-3) / 1e9 if ms > 0 else None,
+                                 "frac": a01 * n * steps / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if ms > 0 else None, "bound": "hbm (limited by VALU issue)"}}
+        except Exception as e:
+            res["config3_dog_only"] = {"error": str(e)[:200]}
+        return res
+
     kname = args.kernel or ("k_pyr_octave_mx" if args.matrix_path else "k_pyr_octave")
     leg("setup")
     main = run_mode(args.localize, args.orient, args.steps, args.warmup, kname)
@@ -380,6 +504,14 @@ def main():
         gpu_kp_sample = int(shared["harris_counts"][:cs].sum().item() + shared["dog_counts"][:cs].sum().item())
     alone = kernel_alone(kname, 3) if (args.modes and kname in ("k_pyr_octave", "k_pyr_octave_mx") and args.octaves >= 2) else None
     leg("alone")
+    per_kernel = cfg_legs = None
+    if args.modes and secondary and args.octaves >= 1 and not (args.localize or args.orient):
+        try:
+            per_kernel = by_kernel(p, L, {k: v for k, v in shared.items() if k != "dense_bits"}, bool(args.matrix_path))
+        except Exception as e:  # a secondary figure must never take the headline down
+            per_kernel = {"error": str(e)[:200]}
+        cfg_legs = config_legs()
+    leg("by_kernel")
     # OPT-IN matrix-core path: the same steps with vslam_ctx_set_matrix_path(1) - octaves 0..3 as
     # chained i8 MFMA band products instead of packed dots.  The north star rules MFMA out of this path, so this is
     # reported BESIDE the headline, never as `value` / `roofline`.
@@ -389,8 +521,12 @@ def main():
             ctx.set_matrix_path(True)
             mm = run_mode(0, 0, args.steps, 2, "k_pyr_octave_mx")
             ma = kernel_alone("k_pyr_octave_mx", 3) if args.octaves >= 2 else None
+            try:
+                mk = by_kernel(mm["p"], mm["L"], {k: v for k, v in shared.items() if k != "dense_bits"}, True) if args.modes else None
+            except Exception as e:
+                mk = {"error": str(e)[:200]}
             ctx.set_matrix_path(False)
-            mxp = {"dt": mm["dt"], "launches": mm["launches"], "kms": mm["kms"], "harris": mm["harris"], "dog": mm["dog"], "alone": ma}
+            mxp = {"dt": mm["dt"], "launches": mm["launches"], "kms": mm["kms"], "harris": mm["harris"], "dog": mm["dog"], "alone": ma, "by_kernel": mk}
         except Exception as e:
             ctx.set_matrix_path(False)
             mxp = {"error": str(e)[:200]}
@@ -550,6 +686,23 @@ def main():
                 },
                 "pipeline_hbm_frac_of_peak": bytes_frame * (n * args.steps / mxp["dt"]) / 1e9 / HBM_PEAK_GBPS,
             }
+            if mxp.get("by_kernel"):
+                mx_obj["roofline_by_kernel"] = mxp["by_kernel"]
+            # live roofline of the path's dominant kernel, like the default path's: achieved from the HIP events of the step,
+            # traffic from two rocprofv3 --pmc child passes of this script with the switch on
+            if mxp["kms"] > 0 and mxp["launches"]:
+                k = mx_obj["k_pyr_octave_mx"]
+                profiled = any("rocprof" in os.environ.get(kk, "") for kk in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD"))
+                lt = live_traffic("k_pyr_octave_mx", rows, cols, args.octaves, matrix_path=1) if (args.live_traffic and args.modes and world == 1 and not profiled) else None
+                mx_obj["roofline"] = {
+                    "kernel": "k_pyr_octave_mx", "bound": "hbm", "achieved": k["achieved"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": k["frac"],
+                    "launches": mxp["launches"], "avg_launch_ms": k["avg_launch_ms"],
+                    "algorithmic_bytes_per_launch": a_bytes * n * args.steps / mxp["launches"],
+                    "traffic": (lt["hbm_bytes_per_frame"] * n * args.steps / mxp["launches"]) if lt else None,
+                    "traffic_bytes_per_frame": lt["hbm_bytes_per_frame"] if lt else None,
+                    "traffic_source": "measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child passes with --matrix-path 1 (separate), 2*FETCH_SIZE + WRITE_SIZE KiB" if lt else None,
+                    "traffic_profiled": dict(lt, live=True) if lt else None}
+                leg("mx_live_traffic")
             if mxp.get("modes"):
                 mx_obj["modes"] = dict(mxp["modes"], content="as `modes`: every second frame uniform noise")
             if mxp["alone"] and mxp["alone"][0] and mxp["alone"][1] > 0:
@@ -593,6 +746,8 @@ def main():
             },
             "roofline": roof,
             "roofline_valu": valu,
+            "roofline_by_kernel": per_kernel,
+            **(cfg_legs or {}),
             "cpu_baseline": None,  # filled in below, after the C++ host's runs: 18 s of 64 busy OpenMP threads right in front of the
                                    # host-fed pipeline cost it 10 % (11.3 k against 13.0 k stand-alone on the same box)
         }

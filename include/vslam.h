@@ -470,8 +470,10 @@ int vslam_count_totals_dev(vslam_ctx* ctx, const uint32_t* harris_counts, const 
                            uint64_t* totals);
 
 /* Timing hook for bench.py: when enabled, the context brackets every launch of the
- * named kernel with HIP events on its stream; vslam_kernel_timing_read synchronises and
- * returns launches and total milliseconds since the last reset. */
+ * named kernel with HIP events on the stream the launch goes to (the context's stream or one of the
+ * batched path's side streams); vslam_kernel_timing_read synchronises and returns launches and total
+ * milliseconds since the last reset.  "name@N" restricts the hook to the launches of octave N
+ * ("k_pyr_octave@0", "k_gauss_h_strip@3", "k_extrema_w3@1"); NULL or "" switches it off. */
 int vslam_kernel_timing_enable(vslam_ctx* ctx, const char* kernel_name);
 int vslam_kernel_timing_read(vslam_ctx* ctx, int* launches, double* total_ms);
 /* Names of the kernels a batch launches, '\n'-separated (for profiles and the hook). */

@@ -155,6 +155,17 @@ def gauss_kernel_f32(n, sigma):
     return k
 
 
+def blur_f32_roi(parent, x0, y0, w, h, sigma):
+    """cv::GaussianBlur on the ROI Rect(x0, y0, w, h) of a CV_32F parent (the filter reads the parent around the window)."""
+    parent = _f32(parent)
+    out = np.zeros((h, w), np.float32)
+    L = lib()
+    L.vo_blur_f32_roi.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p]
+    if L.vo_blur_f32_roi(parent.ctypes.data, parent.shape[0], parent.shape[1], int(x0), int(y0), int(w), int(h), float(sigma), out.ctypes.data) != 0:
+        raise ValueError("blur_f32_roi: bad arguments")
+    return out
+
+
 def compute_edge_response(gx, gy, row, col, padding=1):
     gx, gy = _f32(gx), _f32(gy)
     return float(lib().vo_compute_edge_response(gx.ctypes.data, gy.ctypes.data, gx.shape[0], gx.shape[1], gx.shape[1], row, col, padding))

@@ -670,6 +670,19 @@ static int blur_f32_roi(const float* parent, int prows, int pcols, int x0, int y
     return 0;
 }
 
+/* The same blur with the kernel formed from sigma (getGaussianKernel(cvRound(8 sigma + 1) | 1, sigma, CV_32F)): the entry
+ * point tests/test_opencv_crosscheck.py compares with a real cv::GaussianBlur on a ROI (tools/opencv_pin/pin_harness.cpp). */
+int vo_blur_f32_roi(const float* parent, int prows, int pcols, int x0, int y0, int w, int h, double sigma, float* dst) {
+    if (!parent || !dst || prows <= 0 || pcols <= 0 || w <= 0 || h <= 0 || x0 < 0 || y0 < 0 || x0 + w > pcols || y0 + h > prows || !(sigma > 0)) return -1;
+    const int n = vo_gauss_ksize_f32(sigma);
+    float* k = (float*)malloc(sizeof(float) * (size_t)n);
+    if (!k) return -1;
+    int rc = vo_gauss_kernel_f32(n, sigma, k);
+    if (rc == 0) rc = blur_f32_roi(parent, prows, pcols, x0, y0, w, h, k, n, dst);
+    free(k);
+    return rc;
+}
+
 static float* pad_replicate_f32(const float* img, int rows, int cols, int pad) {
     const int pr = rows + 2 * pad, pc = cols + 2 * pad;
     float* o = (float*)malloc(sizeof(float) * (size_t)pr * pc);

@@ -155,6 +155,9 @@ size_t vo_dog_extrema_dense(const vo_pyramid* p, int octave, int min_contrast, u
 /* Automatic kernel width for CV_32F input (cvRound(sigma*4*2+1)|1) and getGaussianKernel(n, sigma, CV_32F). */
 int vo_gauss_ksize_f32(double sigma);
 int vo_gauss_kernel_f32(int n, double sigma, float* k);
+/* GaussianBlur(Mat(parent, Rect(x0, y0, w, h)), dst, Size(0,0), sigma, 0, BORDER_DEFAULT) on CV_32F (Diff_of_Gauss.cpp:341-348):
+ * no BORDER_ISOLATED, so the filter reads the parent around the window and reflects only at the parent's edges. */
+int vo_blur_f32_roi(const float* parent, int prows, int pcols, int x0, int y0, int w, int h, double sigma, float* dst);
 /* computeEdgeResponse, Diff_of_Gauss.cpp:79-109 (tr^2/det of the 2x2 gradient-product sums). */
 float vo_compute_edge_response(const float* gx, const float* gy, int rows, int cols, size_t step_elems, int row,
                                int col, int padding);

@@ -53,8 +53,35 @@ def make(name):
     return d
 
 
+def make_opencv(name):
+    """The same vectors with every plane that is the output of OpenCV calls alone MADE BY A REAL OpenCV (cv2), in the reference's
+    call order (Harris_corners.cpp:158-164, GaussPyramid.cpp:110,126,177,197), and an `opencv_version` stamp.  The fields the
+    reference's own loops produce (response, NMS maps, lattice extrema, keypoint lists) are the oracle's on those planes; the
+    call is refused when any OpenCV-made plane differs from the oracle's - then the recalled rule is wrong for this OpenCV and
+    tests/test_opencv_crosscheck.py says which (tools/pin_with_opencv.sh runs it first)."""
+    import cv2
+
+    d = make(name)
+    img = d["img"]
+    b = cv2.GaussianBlur(img, (3, 3), 0, borderType=cv2.BORDER_DEFAULT)
+    ix = cv2.Sobel(b, cv2.CV_32F, 1, 0, ksize=1, scale=1, delta=0, borderType=cv2.BORDER_DEFAULT)
+    iy = cv2.Sobel(b, cv2.CV_32F, 0, 1, ksize=1, scale=1, delta=0, borderType=cv2.BORDER_DEFAULT)
+    assert (oracle.harris_from_grad(ix, iy) == d["response"]).all(), "Harris planes differ from the oracle's"
+    base = cv2.resize(img, None, fx=2, fy=2, interpolation=cv2.INTER_LINEAR)
+    for o in range(int(d["n_octaves"])):
+        g = [cv2.GaussianBlur(base, (0, 0), oracle.sigma_at(1.6, o, l), sigmaY=0, borderType=cv2.BORDER_DEFAULT) for l in range(6)]
+        dg = [cv2.subtract(g[l + 1], g[l]) for l in range(5)]
+        for key, planes in ((f"base_{o}", base), (f"gauss_{o}", np.stack(g)), (f"dog_{o}", np.stack(dg))):
+            assert (planes == d[key]).all(), f"{key} from OpenCV {cv2.__version__} differs from the oracle's"
+            d[key] = planes
+        base = cv2.resize(g[3], None, fx=0.5, fy=0.5, interpolation=cv2.INTER_NEAREST)
+    d["opencv_version"] = np.array(cv2.__version__)
+    return d
+
+
 if __name__ == "__main__":
     here = os.path.dirname(os.path.abspath(__file__))
+    maker = make_opencv if "--opencv" in sys.argv[1:] else make
     for name in CASES:
-        np.savez_compressed(os.path.join(here, name + ".npz"), **make(name))
-        print("wrote", name)
+        np.savez_compressed(os.path.join(here, name + ".npz"), **maker(name))
+        print("wrote", name, "(planes from a real OpenCV)" if maker is make_opencv else "")

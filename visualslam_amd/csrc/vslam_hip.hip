@@ -93,6 +93,8 @@ struct vslam_ctx {
     std::map<std::pair<uint64_t, int>, float*> orient_taps;  // (sigma bits, kernel width) -> f32 Gaussian taps on the device
     // bench timing hook
     std::string timing_name;
+    int launch_tag = -1;  // octave of the launch being enqueued, for helpers that do not get it as an argument
+    int timing_tag = -1;  // "name@N": only launches tagged N (the octave)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timing_ev;
     size_t timing_used = 0;
 };
@@ -133,7 +135,7 @@ static const char* const kKernelNames =
     "k_resize_linear2x\nk_blur_h_generic\nk_blur_v_generic\n"
     "k_dog5\nk_resize_nearest_half\nk_extrema\nk_pyr_octave\nk_pyr_octave_mx\n"
     "k_gauss_v_strip\nk_gauss_h_strip\nk_gauss_band\nk_resize_linear2x_slide\nk_resize_nearest_half_v4\nk_extrema_w3\nk_extrema_dense\nk_localize_points\nk_orient_keypoints\nk_edge_response_windows\nk_level_gradients\nk_pack_rows\nk_edge_flags\nk_survivor_ranges\nk_orient_survivors\n"
-    "k_harris_strip\nk_flag_count\nk_chunk_scan\nk_flag_scatter\nk_level_gradients\nk_sift_descriptors\nk_pack_offsets\nk_pack_copy\nk_count_totals";
+    "k_extrema_pack\nk_harris_strip\nk_flag_count\nk_chunk_scan\nk_flag_scatter\nk_level_gradients\nk_sift_descriptors\nk_pack_offsets\nk_pack_copy\nk_count_totals";
 
 static std::pair<hipEvent_t, hipEvent_t>* timing_slot(vslam_ctx* c);
 
@@ -142,12 +144,16 @@ static std::pair<hipEvent_t, hipEvent_t>* timing_slot(vslam_ctx* c);
 struct TimedScope {
     vslam_ctx* c;
     std::pair<hipEvent_t, hipEvent_t>* ev;
-    TimedScope(vslam_ctx* ctx, const char* name)
-        : c(ctx), ev(!ctx->timing_name.empty() && ctx->timing_name == name ? timing_slot(ctx) : nullptr) {
-        if (ev) (void)hipEventRecord(ev->first, c->stream);
+    hipStream_t st;
+    // `tag`: the octave of the launch (-1: none) - "name@2" times only the launches tagged 2; `stream`: where the launch
+    // goes when that is not the context's current stream (the scans go straight to the side stream)
+    TimedScope(vslam_ctx* ctx, const char* name, int tag = -1, hipStream_t stream = nullptr)
+        : c(ctx), ev(!ctx->timing_name.empty() && ctx->timing_name == name && (ctx->timing_tag < 0 || ctx->timing_tag == tag) ? timing_slot(ctx) : nullptr),
+          st(stream ? stream : ctx->stream) {
+        if (ev) (void)hipEventRecord(ev->first, st);
     }
     ~TimedScope() {
-        if (ev) (void)hipEventRecord(ev->second, c->stream);
+        if (ev) (void)hipEventRecord(ev->second, st);
     }
 };
 
@@ -530,7 +536,7 @@ static int launch_h_strip(vslam_ctx* c, const uint16_t* h, size_t hframe, uint8_
     const size_t lds = (size_t)SH * pw * 4;
     TRY(raise_dyn_lds(c, reinterpret_cast<const void*>(&k_gauss_h_strip<SH, RI>)));
     {
-        TimedScope ts(c, "k_gauss_h_strip");
+        TimedScope ts(c, "k_gauss_h_strip", c->launch_tag);
         hipLaunchKernelGGL((k_gauss_h_strip<SH, RI>), dim3(1, (rows + SH - 1) / SH, nf), dim3(256), lds, c->stream, h, hframe, oct,
                            pframe, rows, cols, pitch, pw, taps, next_base, nframe, nrows, ncols, npitch);
     }
@@ -552,7 +558,7 @@ static int enqueue_strip_octave(vslam_ctx* c, double sigma0, int o, const OctPla
     const size_t P = (size_t)rows * pitch;
     TRY(raise_dyn_lds(c, reinterpret_cast<const void*>(&k_gauss_v_strip)));
     {
-        TimedScope ts(c, "k_gauss_v_strip");
+        TimedScope ts(c, "k_gauss_v_strip", o);
         // small batches: split the six levels over workgroups until the launch has >= 256 of them
         const int strips = (cols + STRIP_W - 1) / STRIP_W;
         const int want = (256 + strips * nf - 1) / (strips * nf);
@@ -562,6 +568,7 @@ static int enqueue_strip_octave(vslam_ctx* c, double sigma0, int o, const OctPla
     }
     HIPCHK(c, hipGetLastError());
     const int pw = strip_pw(cols, nmax);
+    c->launch_tag = o;
     // small batches: shorter row strips, more workgroups
     int sh = pl.sh;
     while (sh > 4 && (long)((rows + sh - 1) / sh) * nf < 256) sh >>= 1;
@@ -777,7 +784,7 @@ static int enqueue_pyr_octave(vslam_ctx* c, double sigma0, int o, const OctPlan&
     const PyrTaps<CFG>* taps = static_cast<const PyrTaps<CFG>*>(it->second);
     const dim3 grid((cols + CFG::TW - 1) / CFG::TW, (rows + CFG::TH - 1) / CFG::TH, nf);
     {
-        TimedScope ts(c, "k_pyr_octave");
+        TimedScope ts(c, "k_pyr_octave", o);
         hipLaunchKernelGGL(k_pyr_octave<CFG>, grid, dim3(CFG::NT), CFG::LDS_BYTES, c->stream, base, bframe, oct_out, pframe, rows,
                            cols, pitch, taps, next_base, nframe, nrows, ncols, npitch);
     }
@@ -807,7 +814,7 @@ static int enqueue_pyr_octave_mx(vslam_ctx* c, int cfg, double sigma0, int o, co
     }
     hipError_t e;
     {
-        TimedScope ts(c, "k_pyr_octave_mx");
+        TimedScope ts(c, "k_pyr_octave_mx", o);
         e = mx_launch(cfg, c->stream, it->second, base, bframe, oct_out, pframe, rows, cols, pitch, nf, next_base, nframe, nrows, ncols, npitch, scan, up2_step);
     }
     HIPCHK(c, e);
@@ -1012,11 +1019,15 @@ static int enqueue_dog(vslam_ctx* c, const vslam_params& p, const vslam_batch_la
             } else if (fused[o]) {
                 const MxScan sc{s.sitemap + s.site_off[o], s.site_frame, L.lat_rows[o], L.lat_cols[o], s.site_pitch[o], p.min_contrast,
                                 s.colmap + s.col_off[o], s.col_frame, mx_seams(L.cols[o])};
-                HIPCHK(c, mx_launch_pack(es, sc, L.rows[o], L.lat_words[o], nf, bits ? bits + L.bits_offset[o] : nullptr, s.lflags + L.bits_offset[o],
-                                         L.bits_frame_words));
+                {
+                    TimedScope ts(c, "k_extrema_pack", o, es);
+                    HIPCHK(c, mx_launch_pack(es, sc, L.rows[o], L.lat_words[o], nf, bits ? bits + L.bits_offset[o] : nullptr, s.lflags + L.bits_offset[o],
+                                             L.bits_frame_words));
+                }
                 // the lattice rows whose windows straddle a strip's first image row (every 32nd: a = 32, 64, ...) are not in
                 // the site map: the plain scan kernel runs on exactly those rows
                 const int n_straddle = (L.lat_rows[o] - 1) / 32;
+                TimedScope ts(c, "k_extrema_w3", o, es);
                 if (n_straddle > 0)
                     hipLaunchKernelGGL(k_extrema_w3<false>, dim3((L.lat_words[o] + 3) / 4, n_straddle, nf), dim3(256), 0, es, pyr, pframe, g, o, bits, s.lflags,
                                        L.bits_frame_words, 32, 32);
@@ -1026,6 +1037,7 @@ static int enqueue_dog(vslam_ctx* c, const vslam_params& p, const vslam_batch_la
                 }
             } else if (p.extrema_window == 3) {
                 const dim3 eg((L.lat_words[o] + 3) / 4, L.lat_rows[o], nf);
+                TimedScope ts(c, "k_extrema_w3", o, es);
                 if (p.localize)
                     hipLaunchKernelGGL(k_extrema_w3<true>, eg, dim3(256), 0, es, pyr, pframe, g, o, bits, s.lflags, L.bits_frame_words, 0, 1);
                 else
@@ -1218,13 +1230,18 @@ const char* vslam_kernel_names(void) { return kKernelNames; }
 int vslam_kernel_timing_enable(vslam_ctx* c, const char* name) {
     if (!c) return VSLAM_ERR_INVALID;
     c->timing_name = name ? name : "";
+    c->timing_tag = -1;
+    const size_t at = c->timing_name.find('@');  // "k_pyr_octave@1": the launches of octave 1 only
+    if (at != std::string::npos) {
+        c->timing_tag = std::atoi(c->timing_name.c_str() + at + 1);
+        c->timing_name.resize(at);
+    }
     c->timing_used = 0;
     return VSLAM_OK;
 }
-
 int vslam_kernel_timing_read(vslam_ctx* c, int* launches, double* total_ms) {
     TRY(bind_device(c));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // every batch call joins its side streams back: their events are complete too
     double tot = 0;
     for (size_t i = 0; i < c->timing_used; ++i) {
         float ms = 0;
