@@ -96,11 +96,16 @@ def cpu_baseline(rows, cols, n_oct, sample_frames, gpu_keypoints=None):
 
             import numpy as np
 
-            allcores = run(affinity, 2 * affinity if affinity <= 64 else affinity)  # > 64 threads: one frame each (bounded run time)
+            # the CPUs this process can really keep busy: its affinity mask, cut down to the cgroup's CPU quota where one is
+            # set (the GPU box shows 256 CPUs and grants 16 CPUs' worth of time: 256 threads then ran SLOWER than 64,
+            # 7.1 against 12.2 frames/s, and took 55 s)
+            usable = affinity if not quota else max(1, min(affinity, int(quota + 0.999)))
+            allcores = run(usable, 2 * usable if usable <= 64 else usable)  # > 64 threads: one frame each (bounded run time)
             allcores["affinity_cpus"] = affinity
             allcores["cgroup_cpu_quota"] = quota
-            if affinity > 64:
-                allcores["threads_64"] = run(64, 128)
+            allcores["what"] = "threads = CPUs usable by this process (affinity mask, limited to the cgroup CPU quota)"
+            if usable != 64 and affinity >= 64:
+                allcores["threads_64"] = run(64, 128)  # the figure rounds 2-4 reported
     except Exception as e:  # the single-thread figure is the reported baseline
         allcores = {"error": repr(e)}
     return {
@@ -732,6 +737,7 @@ def main():
             },
             "distributed": {"initialized": bool(use_dist), "world_size": dist.get_world_size() if use_dist else 1,
                             "backend": dist.get_backend() if use_dist else None, "ranks_gathered": int(world)},
+            "join_watch": dict(zip(("level", "done", "last_lag_fraction"), ctx.join_watch_report())),  # 0 = low-priority side streams kept
             "side_streams": dict(zip(("pair", "tuner_state"), ctx.side_stream_report())),  # which candidate pair the library's stream tuner kept (0 = the first), 2 = decided: DESIGN section 5.4
             "keypoints_per_sec": kp_per_step * args.steps / dt,
             "keypoints_per_step": {"harris": main["harris"], "dog": main["dog"], "list_overflow": main["list_overflow"],

@@ -91,6 +91,15 @@ int vslam_ctx_sync(vslam_ctx* ctx);
  * vslam_ctx_side_stream_report: the index of the pair in use (0 = the first created) and the state of the comparison
  * (0 off or not started, 1 measuring, 2 decided).  Diagnostic only. */
 int vslam_ctx_tune_side_streams(vslam_ctx* ctx, int on);
+/* Always on (VSLAM_JOIN_WATCH=0 disables; idle while a comparison of the tuner above runs and during stream captures):
+ * the first full-size batch calls of a context measure how long the context's stream waits at the end of the call for the
+ * side streams (three events on the stream, read by a later call once complete - no host wait).  Two calls with more than
+ * 10 % of the call spent waiting mean a side stream sits on a starved hardware queue: the context then moves its side
+ * work to streams of the main stream's priority (level 1) and, if that does not help either, onto the context's stream itself
+ * (level 2).  Three calls in a row under the limit end the watch (done).  A caller that embeds the library in a process
+ * with its own streams gets a sane schedule without setting GPU_MAX_HW_QUEUES or opting in to anything; results never
+ * depend on the level.  last_lag_fraction: the most recent measurement (-1: none yet). */
+int vslam_ctx_join_watch_report(const vslam_ctx* ctx, int* level, int* done, float* last_lag_fraction);
 int vslam_ctx_side_stream_report(const vslam_ctx* ctx, int* pair, int* state);
 /* Two batches in flight: a second context (own stream, own output buffers) whose batch starts when `leader`'s most
  * recent vslam_detect_batch_dev call is past its octave-0 kernels - the long, issue-bound part - instead of beside
@@ -461,6 +470,21 @@ int vslam_detect_batch_host(vslam_ctx* ctx, const vslam_params* p, const uint8_t
  * offsets[n_frames] * record_bytes > packed_bytes tells the caller).  record_bytes: a multiple of 4. */
 int vslam_pack_lists_dev(vslam_ctx* ctx, const void* lists, size_t record_bytes, uint32_t cap, const uint32_t* counts,
                          int n_frames, void* packed, size_t packed_bytes, uint64_t* offsets);
+
+/* The same for SLAM::point lists (dog_points, oriented_points) with every record squeezed from 24 to 16 bytes on the way:
+ * a host-fed caller downloads a third fewer bytes (the lists are what saturates PCIe on the batched path).  Lossless for
+ * what the detector writes: `padding` is 0 or 1, `octave` < VSLAM_MAX_OCTAVES, `level` < 6 - the three small fields share
+ * one word, tag = level | octave << 8 | padding << 16.  vslam_points16_expand (host, pure arithmetic) is the inverse:
+ * expand(pack(list)) is byte-identical to the list (tests/test_gpu_batch.py::test_pack_points16).  packed_bytes counts
+ * bytes of `packed`; records that do not fit are not written, offsets are as for vslam_pack_lists_dev. */
+typedef struct {
+    int32_t row, col, value;
+    uint32_t tag; /* level | octave << 8 | padding << 16 */
+} vslam_point16;
+int vslam_pack_points16_dev(vslam_ctx* ctx, const vslam_point* lists, uint32_t cap, const uint32_t* counts, int n_frames,
+                            vslam_point16* packed, size_t packed_bytes, uint64_t* offsets);
+/* Host: out[i] = the SLAM::point of in[i], i < n (no GPU involved). */
+void vslam_points16_expand(const vslam_point16* in, size_t n, vslam_point* out);
 
 /* The sending side of the one collective of the multi-GPU path: totals[0] = sum of
  * harris_counts[0..n_frames), totals[1] = the same for dog_counts (either list may be NULL -> 0), as two

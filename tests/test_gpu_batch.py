@@ -434,6 +434,44 @@ def test_pack_lists(env, n, cap):
             assert int(offsets[-1]) == total
 
 
+@pytest.mark.parametrize("n,cap", [(1, 64), (7, 4096), (300, 700)])
+def test_pack_points16(env, n, cap):
+    # vslam_pack_points16_dev: SLAM::point lists packed back to back as 16-byte records
+    # {row, col, value, level | octave << 8 | padding << 16}; vslam_points16_expand on the host gives the lists back byte
+    # for byte.  Random records in the ranges the detector writes (and negative values: `value` after localization can be),
+    # counts below, at and above the capacity, a packed buffer that is too small.
+    ctx, torch = env
+    rng = np.random.default_rng(n * 131 + cap)
+    dev = "cuda:0"
+    pts = np.zeros((n, cap, 6), np.int32)
+    pts[..., 0] = rng.integers(0, 1 << 20, (n, cap))
+    pts[..., 1] = rng.integers(0, 1 << 20, (n, cap))
+    pts[..., 2] = rng.integers(-(1 << 31), (1 << 31) - 1, (n, cap))
+    pts[..., 3] = rng.integers(0, 2, (n, cap))
+    pts[..., 4] = rng.integers(0, 10, (n, cap))
+    pts[..., 5] = rng.integers(0, 6, (n, cap))
+    counts = rng.integers(0, cap + 1, n).astype(np.int32)
+    counts[0] = cap
+    if n > 2:
+        counts[1], counts[2] = 0, cap + 17  # an empty frame; a frame that overflowed its capacity
+    clipped = np.minimum(counts, cap)
+    total = int(clipped.sum())
+    lists, cnt = torch.from_numpy(pts).to(dev), torch.from_numpy(counts).to(dev)
+    offsets = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    for room in (total + 5, max(total - 3, 0)):
+        packed = torch.full((max(room, 1), 4), -1, dtype=torch.int32, device=dev)
+        view = packed[:room] if room else packed[:0]
+        ctx.pack_points16(lists, cnt, view, offsets)
+        torch.cuda.synchronize()
+        off = offsets.cpu().numpy()
+        assert (off == np.concatenate([[0], np.cumsum(clipped)])).all()
+        got = capi.points16_expand(packed.cpu().numpy()[: min(total, room)])
+        want = np.concatenate([pts[f, : clipped[f]] for f in range(n)]).reshape(-1, 6)[: min(total, room)]
+        assert got.tobytes() == np.ascontiguousarray(want).tobytes()
+        if room > total:
+            assert (packed[total:] == -1).all()  # nothing written beyond the records
+
+
 @pytest.mark.parametrize("localize", [0, 1])
 def test_detect_batch_host_lists(env, localize):
     # vslam_detect_batch_host: numpy frames in, packed lists out (no torch in the call), against the oracle frame by
@@ -574,6 +612,72 @@ def test_stream_tuner_never_blocks_the_host():
         assert torch.equal(o["dog_counts"], ref[0]) and torch.equal(o["harris_counts"], ref[1]) and torch.equal(o["extrema_bits"], ref[2])
     finally:
         ctx.close()
+
+
+def test_join_watchdog_levels_give_the_same_results_and_the_watch_ends():
+    # the library itself notices when its low-priority side streams are held up (the main stream's wait at
+    # the end of a call exceeds 3 % of the call) and tries the next form - side streams at the main stream's priority (level 1),
+    # then none (level 2) - keeping a form only if it is measurably faster.  Here: (a) a context left alone measures its first full-size calls without blocking,
+    # reports a lag fraction and ends the watch (on a quiet box at level 0; whatever level it ends on, results are the
+    # same); (b) contexts forced to levels 1 and 2 (VSLAM_JOIN_WATCH_LEVEL) produce byte-identical outputs.
+    import os
+
+    import torch
+
+    capi.build()
+    rows, cols, n = 540, 960, 48
+    dev = "cuda:0"
+    frames = synth.frames_torch(n, rows, cols, stream_id=9, device=torch.device(dev), noise_every=4)
+    p = capi.default_params(rows, cols)
+    L = capi.batch_layout(p)
+
+    def outs():
+        return dict(response=torch.zeros((n, rows, cols), dtype=torch.float32, device=dev), nms_mask=torch.zeros((n, rows, cols), dtype=torch.uint8, device=dev),
+                    harris_kps=torch.zeros((n, p.harris_cap, 3), dtype=torch.int32, device=dev), harris_counts=torch.zeros(n, dtype=torch.int32, device=dev),
+                    pyramid=torch.zeros((n, L.pyramid_frame_bytes), dtype=torch.uint8, device=dev),
+                    extrema_bits=torch.zeros((n, L.bits_frame_words), dtype=torch.int64, device=dev),
+                    dog_points=torch.zeros((n, p.dog_cap, 6), dtype=torch.int32, device=dev), dog_counts=torch.zeros(n, dtype=torch.int32, device=dev))
+
+    res = {}
+    saved = os.environ.pop("VSLAM_JOIN_WATCH_LEVEL", None)
+    try:
+        for level in (None, 1, 2):
+            if level is None:
+                os.environ.pop("VSLAM_JOIN_WATCH_LEVEL", None)
+            else:
+                os.environ["VSLAM_JOIN_WATCH_LEVEL"] = str(level)
+            ctx = capi.Context(0, torch.cuda.current_stream().cuda_stream)
+            try:
+                o = outs()
+                if level is None:
+                    assert ctx.join_watch_report() == (0, False, -1.0)
+                    for _ in range(16):  # call 1 of a level is not measured; three more are, and read by a later call once finished
+                        ctx.detect_batch(p, frames, **o)
+                        torch.cuda.synchronize()
+                        if ctx.join_watch_report()[1]:
+                            break
+                    lv, done, lag = ctx.join_watch_report()
+                    assert done and lv in (0, 1, 2) and 0.0 <= lag < 1.0, (lv, done, lag)
+                else:
+                    assert ctx.join_watch_report()[:2] == (level, True)
+                    ctx.detect_batch(p, frames, **o)
+                    torch.cuda.synchronize()
+                res[level] = o
+            finally:
+                ctx.close()
+    finally:
+        os.environ.pop("VSLAM_JOIN_WATCH_LEVEL", None)
+        if saved is not None:
+            os.environ["VSLAM_JOIN_WATCH_LEVEL"] = saved
+    cnt = res[None]["dog_counts"].cpu().numpy()
+    hcn = res[None]["harris_counts"].cpu().numpy()
+    assert cnt.min() > 0
+    for level in (1, 2):
+        for k in ("response", "nms_mask", "harris_counts", "pyramid", "extrema_bits", "dog_counts"):
+            assert torch.equal(res[None][k], res[level][k]), (level, k)
+        for f in range(n):
+            assert torch.equal(res[None]["dog_points"][f, : int(cnt[f])], res[level]["dog_points"][f, : int(cnt[f])]), (level, f)
+            assert torch.equal(res[None]["harris_kps"][f, : int(hcn[f])], res[level]["harris_kps"][f, : int(hcn[f])]), (level, f)
 
 
 def test_fast_paths_are_the_ones_that_run(env):

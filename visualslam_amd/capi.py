@@ -131,8 +131,11 @@ SIGNATURES = {
     "vslam_ctx_get_matrix_path": (_I, [_P]),
     "vslam_ctx_side_stream_report": (_I, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "vslam_ctx_tune_side_streams": (_I, [_P, _I]),
+    "vslam_ctx_join_watch_report": (_I, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_float)]),
     "vslam_detect_batch_host": (_I, [_P, C.POINTER(Params), _P, _Z, _I, C.POINTER(HostLists)]),
     "vslam_pack_lists_dev": (_I, [_P, _P, _Z, C.c_uint32, _P, _I, _P, _Z, _P]),
+    "vslam_pack_points16_dev": (_I, [_P, _P, C.c_uint32, _P, _I, _P, _Z, _P]),
+    "vslam_points16_expand": (None, [_P, _Z, _P]),
     "vslam_count_totals_dev": (_I, [_P, _P, _P, _I, _P]),
     "vslam_kernel_timing_enable": (_I, [_P, C.c_char_p]),
     "vslam_kernel_timing_read": (_I, [_P, C.POINTER(_I), C.POINTER(_D)]),
@@ -238,6 +241,14 @@ def descriptor_file_write(path: str, desc) -> None:
     rc = lib().vslam_descriptor_file_write(os.fsencode(path), d.ctypes.data, d.shape[0])
     if rc:
         raise VslamError(rc, "vslam_descriptor_file_write", path)
+
+
+def points16_expand(packed) -> np.ndarray:
+    """vslam_points16_expand (host): [m, 4] int32 / uint32 packed records -> [m] POINT_DTYPE records."""
+    a = np.ascontiguousarray(packed).view(np.uint32).reshape(-1, 4)
+    out = np.zeros(len(a), POINT_DTYPE)
+    lib().vslam_points16_expand(a.ctypes.data, len(a), out.ctypes.data)
+    return out
 
 
 def default_params(rows: int, cols: int, **kw) -> Params:
@@ -485,6 +496,13 @@ class Context:
         self._chk(lib().vslam_ctx_side_stream_report(self._h, C.byref(a), C.byref(b)), "vslam_ctx_side_stream_report")
         return a.value, b.value
 
+    def join_watch_report(self):
+        """vslam_ctx_join_watch_report: (level: 0 low-priority side streams / 1 flat priority / 2 no side streams, done,
+        last measured fraction of a call the context's stream spent waiting for the side streams; -1: none yet)."""
+        a, b, f = C.c_int(0), C.c_int(0), C.c_float(-1.0)
+        self._chk(lib().vslam_ctx_join_watch_report(self._h, C.byref(a), C.byref(b), C.byref(f)), "vslam_ctx_join_watch_report")
+        return a.value, bool(b.value), float(f.value)
+
     def set_matrix_path(self, on: bool):
         """vslam_ctx_set_matrix_path: OPT-IN matrix-core (MFMA) form of the LDS-tiled octave kernels; off by default."""
         self._chk(lib().vslam_ctx_set_matrix_path(self._h, 1 if on else 0), "vslam_ctx_set_matrix_path")
@@ -537,6 +555,16 @@ class Context:
             raise ValueError("pack_lists: bad tensors")
         self._chk(lib().vslam_pack_lists_dev(self._h, lists.data_ptr(), rb, cap, counts.data_ptr(), n, packed.data_ptr(),
                                              packed.numel() * packed.element_size(), offsets.data_ptr()), "vslam_pack_lists_dev")
+
+    def pack_points16(self, lists, counts, packed, offsets):
+        """vslam_pack_points16_dev: SLAM::point lists [n, cap, 6] int32, counts [n] int32 -> packed 16-byte records (any flat
+        tensor; its byte size is the capacity), offsets [n + 1] int64.  CUDA tensors; asynchronous on the context stream."""
+        n, cap = lists.shape[0], lists.shape[1]
+        if not (lists.is_contiguous() and lists.shape[2] == 6 and lists.element_size() == 4 and packed.is_contiguous() and counts.numel() >= n and
+                offsets.numel() >= n + 1 and offsets.element_size() == 8):
+            raise ValueError("pack_points16: bad tensors")
+        self._chk(lib().vslam_pack_points16_dev(self._h, lists.data_ptr(), cap, counts.data_ptr(), n, packed.data_ptr(),
+                                                packed.numel() * packed.element_size(), offsets.data_ptr()), "vslam_pack_points16_dev")
 
     def count_totals(self, harris_counts, dog_counts, totals):
         """vslam_count_totals_dev: int32 [n] count tensors (either may be None) -> totals int64 [2], on the context stream."""

@@ -351,6 +351,24 @@ __global__ __launch_bounds__(256) void k_pack_copy(const unsigned int* __restric
         if (d0 + i < packed_dw) packed[d0 + i] = src[i];
 }
 
+// grid = (blocks per frame, 1, frames): frame f's first min(counts[f], cap) SLAM::point records (six ints) to 16-byte
+// records {row, col, value, level | octave << 8 | padding << 16} at packed + offsets[f]; a thread per record: three 8-byte
+// loads (records are 8-byte aligned), one 16-byte store.
+__global__ __launch_bounds__(256) void k_pack_points16(const int2* __restrict__ lists, unsigned int cap, const unsigned int* __restrict__ counts,
+                                                        const unsigned long long* __restrict__ offsets, uint4* __restrict__ packed,
+                                                        unsigned long long packed_recs) {
+    const int f = blockIdx.z;
+    const unsigned int nrec = min(counts[f], cap);
+    const int2* src = lists + (size_t)f * cap * 3;
+    const unsigned long long d0 = offsets[f];
+    for (unsigned int i = blockIdx.x * 256 + threadIdx.x; i < nrec; i += gridDim.x * 256) {
+        const int2 a = src[3 * (size_t)i], b = src[3 * (size_t)i + 1], c = src[3 * (size_t)i + 2];  // (row, col) (value, padding) (octave, level)
+        if (d0 + i < packed_recs)
+            packed[d0 + i] = make_uint4((unsigned int)a.x, (unsigned int)a.y, (unsigned int)b.x,
+                                        ((unsigned int)c.y & 0xffu) | (((unsigned int)c.x & 0xffu) << 8) | (((unsigned int)b.y & 0xffffu) << 16));
+    }
+}
+
 // one block: totals[0] = sum of a[0..n), totals[1] = sum of b[0..n) (either may be null -> 0), 64-bit
 __global__ __launch_bounds__(256) void k_count_totals(const unsigned int* __restrict__ a, const unsigned int* __restrict__ b, int n,
                                                        unsigned long long* __restrict__ totals) {

@@ -1,6 +1,7 @@
 // K-D2 / K-D3: separable Gaussian levels for the coarse octaves (wide kernels on small images).
 //
-// Octaves >= 2 of the reference pyramid have 39..245-tap kernels on 960x540 / 480x270 images
+// Octaves >= 2 of the reference pyramid have 39..245-tap kernels on 960x540 / 480x270 images (and 155..977 taps on
+// 240x135 / 120x68 when the octave count is the reference's automatic one)
 // (SURVEY.md Appendix C): a 2-D tile would be mostly halo.  Here each pass keeps the WHOLE
 // extent of its filtering axis in LDS, so there is no halo recomputation at all:
 //   k_gauss_v_strip: one workgroup = a 64-column strip x all rows of the octave base, staged
@@ -19,8 +20,13 @@
 namespace vslam {
 
 constexpr int STRIP_W = 64;        // columns per vertical-pass workgroup
-constexpr int STRIP_MAXM = 64;     // tap dword groups per level: ceil((245+3)/4) = 62
-constexpr int STRIP_MAXTP = 272;   // padded u16 tap-pair table: 8 + (245+1) + 16, multiple of 8
+constexpr int STRIP_MAXN = 2047;   // widest kernel (taps, after zero-tail trimming)
+// Kernels up to 2047 taps (round 5; 245 before): the reference's second constructor gives a 1080p frame six octaves, and
+// octaves 4 and 5 (240 x 135, 120 x 68) have kernels of up to 489 and 977 taps - several times wider than the image (4K: a seventh octave, 1955 taps on 120 x 68), which
+// the repeated BORDER_REFLECT_101 of the staging loops already handles.  On the one-thread-per-pixel generic kernels those two
+// octaves cost 8 x octave 3 (4.1 + 3.8 ms per 64-frame batch against 0.5).
+constexpr int STRIP_MAXM = 514;    // tap dword groups per level: M = (2047 + 6) >> 2 = 513
+constexpr int STRIP_MAXTP = 2072;  // padded u16 tap-pair table: 8 + (2047+1) + 16, multiple of 8 (the last block of a level reads 8 (nb-1) + 15 <= 2063)
 // The row sums the vertical pass hands to the horizontal pass carry +128 each: the taps of a level sum
 // to exactly 256 (strip_pack_taps checks it), so sum tx * (h + 128) = sum tx * h + 32768 - the rounding
 // constant of SURVEY A2-iv arrives with the data and the horizontal accumulators start from the first
@@ -449,7 +455,7 @@ __global__ __launch_bounds__(512) void k_gauss_band(const uint8_t* __restrict__ 
 static bool strip_pack_taps(const uint16_t* const t[6], const int n[6], StripTaps& out) {
     memset(&out, 0, sizeof(out));
     for (int l = 0; l < VSLAM_NUM_LEVELS; ++l) {
-        if (n[l] > 245 || (n[l] & 1) == 0) return false;
+        if (n[l] > STRIP_MAXN || (n[l] & 1) == 0) return false;
         out.n[l] = n[l];
         unsigned sum = 0;
         for (int k = 0; k < n[l]; ++k) {

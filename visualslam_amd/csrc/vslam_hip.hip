@@ -48,6 +48,34 @@ struct StreamTuner {
     int calls = 0, resets = 0;
 };
 
+// Join watchdog (round 5): the default answer to the same hardware-queue lottery, for every caller and without opt-in.
+// The first full-size batch calls of a context are bracketed by three events on the main stream - start, "my own kernels
+// are enqueued up to here" (just before the waits on the side streams' join events) and end.  t(end) - t(own) is how long
+// the main stream sat waiting for side work: 0.4 % of an 18 ms batch when the side streams run freely (their last
+// kernels follow the main stream's last), 5 % with HIP's default of four hardware queues, 20 % when a low-priority side
+// queue is being starved (the scan of octave 0 then takes 10 ms instead of 3.5 and the join waits for it).
+// A later call reads the events once they are complete (hipEventQuery: nothing ever waits on the host).  Three measured
+// calls with a median lag above 3 % start a TRIAL of the next form - side streams at the main stream's priority (level 1:
+// never starvable), and from there, if the lag is still above 10 %, no side streams at all (level 2) - and the trial is
+// kept only if its fastest call beats the previous form's fastest by 1 %; otherwise the context goes back.  Either way the
+// watch ends after at most ten full-size calls.  Off while a capture is on, while the opt-in tuner is comparing pairs, and
+// under VSLAM_JOIN_WATCH=0; VSLAM_JOIN_WATCH_LEVEL pins a level.  Results never depend on the level.
+struct JoinWatch {
+    static constexpr int RING = 4, NEED = 3;
+    hipEvent_t t0[RING] = {}, tm[RING] = {}, t1[RING] = {};
+    bool live[RING] = {};       // events of slot i are recorded and not yet read
+    int head = 0;               // next slot to record
+    int recording = -1;         // slot of the call being enqueued
+    int calls = 0;              // eligible calls at the current level (the first is not measured)
+    int n_meas = 0;             // measurements at the current level
+    float lag[NEED] = {}, best_total = 0.0f;
+    float level_best[3] = {0.0f, 0.0f, 0.0f};  // fastest measured call at each level tried
+    int level = 0;              // 0: low-priority side streams, 1: flat priority, 2: no side streams
+    bool done = false, disabled = false;
+    float last_lag_frac = -1.0f;
+    hipStream_t pair[2][2] = {};  // the side-stream pairs of levels 0 and 1 (both live until the context goes)
+};
+
 struct vslam_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -72,6 +100,7 @@ struct vslam_ctx {
     hipEvent_t ev_fork = nullptr, ev_join[kAux] = {nullptr, nullptr, nullptr}, ev_oct[VSLAM_MAX_OCTAVES] = {};
     int prio_lo = 0;      // priority of the two yielding side streams (0: the main stream's)
     StreamTuner tuner;    // which pair of side streams the batched path runs on (see StreamTuner)
+    JoinWatch watch;      // steps the side streams down when their join lags (see JoinWatch)
     hipEvent_t ev_phase = nullptr;  // recorded by every vslam_detect_batch_dev call once its octave-0 kernels are enqueued (vslam_ctx_follow)
     bool phase_marked = false;
     hipEvent_t ev_up2 = nullptr;  // the second half of a batch has been upsampled (enqueue_dog)
@@ -161,7 +190,7 @@ struct TimedScope {
 #define LAUNCH(ctx, name, kern, grid, block, ...)                                 \
     do {                                                                          \
         {                                                                         \
-            TimedScope ts_(ctx, name);                                            \
+            TimedScope ts_(ctx, name, (ctx)->launch_tag);                         \
             hipLaunchKernelGGL(kern, grid, block, 0, (ctx)->stream, __VA_ARGS__); \
         }                                                                         \
         HIPCHK(ctx, hipGetLastError());                                           \
@@ -225,7 +254,7 @@ static void tuner_finish(vslam_ctx* c, int chosen) {
 // Before the fork of a batch call (ensure_aux has run): picks the pair of side streams this call uses.  Never blocks.
 static int tuner_before_call(vslam_ctx* c, unsigned long long key, bool eligible) {
     StreamTuner& t = c->tuner;
-    if (t.done || !t.enabled) return VSLAM_OK;
+    if (t.done || !t.enabled || c->watch.level > 0) return VSLAM_OK;  // (the pairs it compares are low-priority ones)
     if (c->prio_lo == 0) {  // no priority levels: one pair is as good as another
         t.done = true;
         return VSLAM_OK;
@@ -289,6 +318,84 @@ static int tuner_after_call(vslam_ctx* c) {
     return VSLAM_OK;
 }
 
+// Before the fork of a batch call: reads finished measurements, moves between the levels, starts this call's measurement.
+static int watch_set_level(vslam_ctx* c, int level) {
+    JoinWatch& w = c->watch;
+    for (bool& l : w.live) l = false;  // measurements in flight belong to the form being left
+    w.calls = w.n_meas = 0;
+    w.best_total = 0.0f;
+    w.level = level;
+    if (level <= 1) {
+        for (int i = 0; i < 2; ++i) {
+            if (!w.pair[level][i]) HIPCHK(c, hipStreamCreateWithFlags(&w.pair[level][i], hipStreamNonBlocking));  // level 1: the main stream's priority
+            c->aux[i] = w.pair[level][i];  // the pair being left is idle: every call joins its side streams back
+        }
+    }
+    return VSLAM_OK;
+}
+
+static int watch_before_call(vslam_ctx* c, bool eligible, bool capturing) {
+    JoinWatch& w = c->watch;
+    w.recording = -1;
+    if (w.done || w.disabled || capturing || (c->tuner.enabled && !c->tuner.done)) return VSLAM_OK;
+    if (!w.pair[0][0]) w.pair[0][0] = c->aux[0], w.pair[0][1] = c->aux[1];
+    for (int i = 0; i < JoinWatch::RING; ++i) {
+        if (!w.live[i]) continue;
+        const hipError_t q = hipEventQuery(w.t1[i]);
+        if (q == hipErrorNotReady) {
+            (void)hipGetLastError();
+            continue;
+        }
+        w.live[i] = false;
+        float total = 0.0f, lag = 0.0f;
+        if (q != hipSuccess || hipEventElapsedTime(&total, w.t0[i], w.t1[i]) != hipSuccess || hipEventElapsedTime(&lag, w.tm[i], w.t1[i]) != hipSuccess || !(total > 0.0f)) {
+            (void)hipGetLastError();
+            continue;
+        }
+        w.last_lag_frac = lag / total;
+        if (w.n_meas < JoinWatch::NEED) {
+            w.lag[w.n_meas++] = lag / total;
+            w.best_total = (w.best_total == 0.0f || total < w.best_total) ? total : w.best_total;
+        }
+    }
+    if (w.n_meas >= JoinWatch::NEED) {
+        float a = w.lag[0], b = w.lag[1], m = w.lag[2];
+        const float med = std::max(std::min(a, b), std::min(std::max(a, b), m));
+        w.level_best[w.level] = w.best_total;
+        if (w.level == 0) {
+            if (med <= 0.03f || c->prio_lo == 0)  // the side streams run freely (or there are no priority levels to give up)
+                w.done = true;
+            else
+                TRY(watch_set_level(c, 1));
+        } else if (w.level == 1) {
+            if (!(w.best_total < 0.99f * w.level_best[0])) {  // the trial did not pay: back to the yielding side streams
+                TRY(watch_set_level(c, 0));
+                w.done = true;
+            } else if (med > 0.10f)
+                TRY(watch_set_level(c, 2));
+            else
+                w.done = true;
+        } else {
+            if (!(w.best_total < 0.99f * w.level_best[1])) TRY(watch_set_level(c, 1));
+            w.done = true;
+        }
+        if (w.done) return VSLAM_OK;
+    }
+    if (!eligible) return VSLAM_OK;
+    if (++w.calls == 1) return VSLAM_OK;  // the first call of a form pays one-time costs
+    const int slot = w.head;
+    if (w.live[slot]) return VSLAM_OK;  // the host is more than RING calls ahead: skip this one
+    if (!w.t0[slot]) {
+        HIPCHK(c, hipEventCreate(&w.t0[slot]));
+        HIPCHK(c, hipEventCreate(&w.tm[slot]));
+        HIPCHK(c, hipEventCreate(&w.t1[slot]));
+    }
+    HIPCHK(c, hipEventRecord(w.t0[slot], c->stream));
+    w.recording = slot;
+    w.head = (slot + 1) % JoinWatch::RING;
+    return VSLAM_OK;
+}
+
 static int ensure_aux(vslam_ctx* c) {
     if (c->ev_fork) return VSLAM_OK;
     int prio_lo = 0, prio_hi = 0;
@@ -297,7 +404,7 @@ static int ensure_aux(vslam_ctx* c) {
         prio_lo = 0;
     }
     static const bool flat = getenv("VSLAM_FLAT_PRIORITY") != nullptr;
-    c->prio_lo = flat ? 0 : prio_lo;
+    c->prio_lo = (flat || c->watch.level >= 1) ? 0 : prio_lo;
     for (int i = 0; i < vslam_ctx::kAux; ++i) {
         // aux[0], aux[1] (Harris chain, scans and lists) yield to the octave kernels; aux[2] carries only the
         // second-half upsample, which the main stream WAITS for: at low priority it was starved for the whole
@@ -477,7 +584,7 @@ static OctPlan plan_octave(double sigma0, int o, int rows, int cols) {
         pl.path = OctPath::Tile0;
     } else if (matches_cfg<PyrCfgOct1>(pl.ke)) {
         pl.path = OctPath::Tile1;
-    } else if (nmax <= 245) {
+    } else if (nmax <= STRIP_MAXN) {
         const int RM = (nmax / 2 + 3) & ~3;
         const size_t v_lds = (size_t)((((rows + 3) & ~3) + 2 * RM + 16) / 4) * STRIP_W * 4;
         pl.sh = cols <= 1024 ? 16 : cols <= 2048 ? 8 : cols <= 4096 ? 4 : 0;
@@ -927,7 +1034,12 @@ static int enqueue_dog(vslam_ctx* c, const vslam_params& p, const vslam_batch_la
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_pack, 0));
         c->pack_pending = false;
     }
+    struct TagReset {
+        vslam_ctx* c;
+        ~TagReset() { c->launch_tag = -1; }
+    } tag_reset{c};
     for (int o = 0; o < L.n_octaves; ++o) {
+        c->launch_tag = o;  // the timing hook's "name@o" (TimedScope) for every launch of this octave
         const int rows = L.rows[o], cols = L.cols[o], pitch = L.pitch[o];
         const size_t P = (size_t)rows * pitch;
         const uint8_t* base = s.bases + s.base_off[o];
@@ -1169,6 +1281,12 @@ int vslam_ctx_create(int device, void* stream, vslam_ctx** out) {
         c->mx = e && e[0] == '1';
         const char* es = std::getenv("VSLAM_ORIENT_SCALAR");
         c->orient_scalar_form = es && es[0] == '1';
+        const char* jw = std::getenv("VSLAM_JOIN_WATCH");
+        c->watch.disabled = jw && jw[0] == '0';
+        if (const char* lv = std::getenv("VSLAM_JOIN_WATCH_LEVEL")) {  // tests / A-B runs: start (and stay) at a level
+            c->watch.level = std::min(2, std::max(0, std::atoi(lv)));
+            c->watch.done = true;
+        }
         const char* t = std::getenv("VSLAM_STREAM_TUNER");
         c->tuner.enabled = t && t[0] == '1';
     }
@@ -1209,6 +1327,12 @@ int vslam_ctx_destroy(vslam_ctx* c) {
         if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
     }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    for (int i = 0; i < JoinWatch::RING; ++i)
+        for (hipEvent_t e : {c->watch.t0[i], c->watch.tm[i], c->watch.t1[i]})
+            if (e) (void)hipEventDestroy(e);
+    for (auto& pr : c->watch.pair)
+        for (hipStream_t st : pr)
+            if (st && st != c->aux[0] && st != c->aux[1]) (void)hipStreamSynchronize(st), (void)hipStreamDestroy(st);
     for (hipEvent_t e : {c->ev_phase, c->ev_up2, c->ev_chunk, c->ev_pack, c->ev_list0, c->ev_edge, c->ev_or_fork, c->ev_or_join[0], c->ev_or_join[1]})
         if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ev_oct)
@@ -2155,11 +2279,19 @@ int vslam_detect_batch_dev(vslam_ctx* c, const vslam_params* pp, const uint8_t* 
     // with a fault when a side stream forks to another side stream and takes the join back (tools/graph_try.py found it in
     // the orientation stage).  The two nested forks of that stage - the early edge test and the spread launches - stay on
     // their own stream while a capture is on; everything else forks from and joins to the main stream.
-    bool capturing = false;
+    bool capturing = false, cap_early = false, cap_spread = false;  // the nested forks stay out of a capture
     {
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(c->stream, &cap) != hipSuccess) (void)hipGetLastError();
         capturing = cap != hipStreamCaptureStatusNone;
+        // diagnostic switch for tools/graph_try.py (the reproducer of that fault): leave the nested forks in while capturing
+        // (1: both nested forks stay in, 2: only the early edge test's, 3: only the spread orientation launches')
+        static const int nested_in_capture = [] {
+            const char* e = std::getenv("VSLAM_CAPTURE_NESTED_FORKS");
+            return e ? std::atoi(e) : 0;
+        }();
+        cap_early = capturing && !(nested_in_capture == 1 || nested_in_capture == 2);
+        cap_spread = capturing && !(nested_in_capture == 1 || nested_in_capture == 3);
     }
     hipStream_t sh = c->stream, sx = nullptr;  // Harris stream, extrema stream (nullptr = main)
     // Any early return between the fork and the join must not leave the side streams running into
@@ -2174,8 +2306,14 @@ int vslam_detect_batch_dev(vslam_ctx* c, const vslam_params* pp, const uint8_t* 
             (void)hipStreamSynchronize(c->stream);
         }
     } guard{c};
+    bool side_streams = use_aux;
     if (use_aux) {
         TRY(ensure_aux(c));
+        // (calls of a few megapixels are dominated by launch latencies: their lag says nothing about starvation)
+        TRY(watch_before_call(c, dog && harris && n_frames >= 32 && (size_t)n_frames * N >= ((size_t)16 << 20), capturing));
+        if (c->watch.level == 2) side_streams = false;  // the watchdog's last step: everything on the caller's stream
+    }
+    if (side_streams) {
         // the side-stream pair of this call (StreamTuner): only full-size batches with both paths are compared
         const unsigned long long key = ((unsigned long long)(unsigned)n_frames << 40) ^ ((unsigned long long)(unsigned)p.rows << 20) ^ (unsigned)p.cols ^
                                        ((unsigned long long)(p.localize + 2 * p.orient + 4 * p.extrema_dense + 8 * (out->descriptors != nullptr)) << 60) ^
@@ -2206,7 +2344,7 @@ int vslam_detect_batch_dev(vslam_ctx* c, const vslam_params* pp, const uint8_t* 
         // right after that octave's event, so that nothing enqueued on its stream later can get in front of it.
         // (matrix path: starting the Harris chain at once, or behind octave 0 / 2 / 3 instead of 1, moved the step by less than
         // +-1.5 % - 14.54 .. 14.90 ms on one box - so the gate stays where the default path has it)
-        const int harris_gate = (dog && use_aux) ? dog_side_gate(p, L, nf) : -1;
+        const int harris_gate = (dog && side_streams) ? dog_side_gate(p, L, nf) : -1;
         if (harris && harris_gate < 0) TRY(do_harris());
         if (dog) {
             const bool ext = out->extrema_bits || (out->dog_points && out->dog_counts);
@@ -2215,7 +2353,7 @@ int vslam_detect_batch_dev(vslam_ctx* c, const vslam_params* pp, const uint8_t* 
             const std::function<int(int)> after_list = [&](int o) -> int {
                 if (orient && o == 0 && L.n_octaves > 1)
                     return enqueue_edge_flags_early(c, p, opl, nf, out->pyramid + (size_t)f0 * L.pyramid_frame_bytes, L.pyramid_frame_bytes,
-                                                    out->dog_points + (size_t)f0 * p.dog_cap, out->dog_counts + f0, os, (use_aux && !capturing) ? sh : nullptr);
+                                                    out->dog_points + (size_t)f0 * p.dog_cap, out->dog_counts + f0, os, (side_streams && !cap_early) ? sh : nullptr);
                 return VSLAM_OK;
             };
             const std::function<int(int)> after_octave = [&](int o) -> int {
@@ -2230,14 +2368,14 @@ int vslam_detect_batch_dev(vslam_ctx* c, const vslam_params* pp, const uint8_t* 
                             out->extrema_bits ? (unsigned long long*)out->extrema_bits + (size_t)f0 * L.bits_frame_words : nullptr,
                             ext, out->dog_points ? out->dog_points + (size_t)f0 * p.dog_cap : nullptr,
                             out->dog_counts ? out->dog_counts + f0 : nullptr, sx, after_list, after_octave,
-                            use_aux ? c->aux[2] : nullptr, f0 > 0, /*bases_are_scratch=*/true));
+                            side_streams ? c->aux[2] : nullptr, f0 > 0, /*bases_are_scratch=*/true));
             if (orient) {  // filterKeypoints behind the list, on the stream that produced it
                 StreamSwap sw(c, sx ? sx : c->stream);
                 TRY(enqueue_orient_batch(c, p, L, opl, nf, out->pyramid + (size_t)f0 * L.pyramid_frame_bytes, L.pyramid_frame_bytes,
                                          out->dog_points + (size_t)f0 * p.dog_cap, out->dog_counts + f0, os,
                                          out->oriented_points + (size_t)f0 * p.oriented_cap, out->oriented_counts + f0,
-                                         (use_aux && orient_spread && !capturing) ? sh : nullptr,
-                                         (use_aux && orient_spread && !capturing) ? c->aux[2] : nullptr));
+                                         (side_streams && orient_spread && !cap_spread) ? sh : nullptr,
+                                         (side_streams && orient_spread && !cap_spread) ? c->aux[2] : nullptr));
                 if (out->oriented_survivors)
                     HIPCHK(c, hipMemcpyAsync(out->oriented_survivors + f0, os.scounts, sizeof(unsigned int) * (size_t)nf,
                                              hipMemcpyDeviceToDevice, c->stream));
@@ -2249,13 +2387,19 @@ int vslam_detect_batch_dev(vslam_ctx* c, const vslam_params* pp, const uint8_t* 
             }
         }
     }
-    if (use_aux)  // join
+    if (c->watch.recording >= 0) HIPCHK(c, hipEventRecord(c->watch.tm[c->watch.recording], c->stream));  // the main stream's own work ends here
+    if (side_streams)  // join
         for (int i = 0; i < vslam_ctx::kAux; ++i) {
             HIPCHK(c, hipEventRecord(c->ev_join[i], c->aux[i]));
             HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[i], 0));
         }
+    if (c->watch.recording >= 0) {
+        HIPCHK(c, hipEventRecord(c->watch.t1[c->watch.recording], c->stream));
+        c->watch.live[c->watch.recording] = true;
+        c->watch.recording = -1;
+    }
     if (!c->phase_marked) TRY(mark_phase(c));  // no DoG path in this call: its end is the mark
-    if (use_aux) TRY(tuner_after_call(c));
+    if (side_streams) TRY(tuner_after_call(c));
     guard.armed = false;
     return VSLAM_OK;
 }
@@ -2264,6 +2408,14 @@ int vslam_ctx_side_stream_report(const vslam_ctx* c, int* pair, int* state) {
     if (!c) return VSLAM_ERR_INVALID;
     if (pair) *pair = c->tuner.chosen;
     if (state) *state = c->tuner.done ? 2 : ((c->tuner.enabled && c->tuner.calls > 1) ? 1 : 0);
+    return VSLAM_OK;
+}
+
+int vslam_ctx_join_watch_report(const vslam_ctx* c, int* level, int* done, float* last_lag_fraction) {
+    if (!c) return VSLAM_ERR_INVALID;
+    if (level) *level = c->watch.level;
+    if (done) *done = c->watch.done ? 1 : 0;
+    if (last_lag_fraction) *last_lag_fraction = c->watch.last_lag_frac;
     return VSLAM_OK;
 }
 
@@ -2375,6 +2527,20 @@ int vslam_pack_lists_dev(vslam_ctx* c, const void* lists, size_t record_bytes, u
     if (packed_bytes >= 4)
         LAUNCH(c, "k_pack_copy", k_pack_copy, dim3(gx, 1, n_frames), dim3(256), (const unsigned int*)lists, rec_dw, cap, counts,
                (const unsigned long long*)offsets, (unsigned int*)packed, (unsigned long long)(packed_bytes / 4));
+    return VSLAM_OK;
+}
+
+int vslam_pack_points16_dev(vslam_ctx* c, const vslam_point* lists, uint32_t cap, const uint32_t* counts, int n_frames, vslam_point16* packed,
+                            size_t packed_bytes, uint64_t* offsets) {
+    TRY(bind_device(c));
+    ARGCHK(c, lists && counts && offsets && n_frames > 0 && n_frames <= 65535 && cap > 0 && (packed || packed_bytes == 0),
+           "pack_points16: bad arguments (1 .. 65535 frames per call)");
+    static_assert(sizeof(vslam_point) == 24 && sizeof(vslam_point16) == 16, "record layouts");
+    LAUNCH(c, "k_pack_offsets", k_pack_offsets, dim3(1), dim3(256), counts, cap, n_frames, (unsigned long long*)offsets);
+    const unsigned int gx = (unsigned int)std::min<unsigned long long>(((unsigned long long)cap + 1023) / 1024, 96);
+    if (packed_bytes >= sizeof(vslam_point16))
+        LAUNCH(c, "k_pack_copy", k_pack_points16, dim3(gx, 1, n_frames), dim3(256), reinterpret_cast<const int2*>(lists), cap, counts,
+               (const unsigned long long*)offsets, reinterpret_cast<uint4*>(packed), (unsigned long long)(packed_bytes / sizeof(vslam_point16)));
     return VSLAM_OK;
 }
 

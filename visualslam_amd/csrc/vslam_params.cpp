@@ -269,4 +269,13 @@ int vslam_descriptor_file_write(const char* path, const float* desc, size_t n) {
     return ok ? VSLAM_OK : VSLAM_ERR_INVALID;
 }
 
+void vslam_points16_expand(const vslam_point16* in, size_t n, vslam_point* out) {
+    if (!in || !out) return;
+    for (size_t i = 0; i < n; ++i) {
+        const uint32_t t = in[i].tag;
+        out[i].row = in[i].row, out[i].col = in[i].col, out[i].value = in[i].value;
+        out[i].padding = (int32_t)(t >> 16), out[i].octave = (int32_t)((t >> 8) & 0xffu), out[i].level = (int32_t)(t & 0xffu);
+    }
+}
+
 }  // extern "C"

@@ -183,6 +183,26 @@ int main(int argc, char** argv) {
             vslam::BatchDetector::free_pinned(hB);
         }
 
+        // ---- 1c. Options::compact_points: the DoG list crosses PCIe as 16-byte records (vslam_pack_points16_dev) and
+        //          BatchResult::frame() rebuilds the SLAM::points - byte for byte the 24-byte records of the plain detector
+        {
+            vslam::BatchDetector::Options oc = opt;
+            oc.pipelines = 1, oc.compact_points = true;
+            vslam::BatchDetector cdet(oc);
+            cdet.submit(h_frames, n);
+            const vslam::BatchResult& rc = cdet.collect();
+            EXPECT(rc.dog == nullptr && rc.dog16 != nullptr && rc.dog_records == pt0.size() && rc.harris_records == kp0.size() && !rc.truncated);
+            EXPECT(std::memcmp(rc.harris, kp0.data(), kp0.size() * sizeof(vslam_kp)) == 0);
+            uint64_t seen = 0;
+            for (int f = 0; f < n; ++f) {
+                const vslam::FrameKeypoints fk = rc.frame(f);
+                EXPECT(fk.n_dog == doff[f + 1] - doff[f] && fk.dog == fk.dog_expanded.data());
+                EXPECT(fk.n_dog == 0 || std::memcmp(fk.dog, pt0.data() + doff[f], fk.n_dog * sizeof(vslam_point)) == 0);
+                seen += fk.n_dog;
+            }
+            EXPECT(seen == pt0.size() && seen > 0);
+        }
+
         // ---- 2. the per-image drop-in functions give the same lists (frames 0 and n-1)
         for (int f : {0, n - 1}) {
             const std::vector<vslam_kp> kps = HarrisKeypoints(imgs[f], 0.04f);

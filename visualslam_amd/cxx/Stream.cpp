@@ -44,7 +44,9 @@ namespace {
 struct Args {
     std::string mode = "device", source = "synth", dump, lists = "candidates";
     int frames = 256, batches = 8, warmup = 6, rows = 1080, cols = 1920, octaves = 4, pipelines = 1;
-    bool rdv_selftest = false, no_allgather = false, no_rccl = false, no_tuner = false;
+    bool rdv_selftest = false, no_allgather = false, no_rccl = false, no_tuner = true;
+    int hw_queues = 0;
+    int compact = 1;  // host-fed: SLAM::point lists cross PCIe as 16-byte records (BatchDetector::Options::compact_points)
 };
 
 Args parse(int argc, char** argv) {
@@ -66,9 +68,12 @@ Args parse(int argc, char** argv) {
         else if (k == "--source") a.source = val();
         else if (k == "--dump") a.dump = val();
         else if (k == "--lists") a.lists = val();  // candidates (default) | localize | orient | describe: how much of the DoG executable runs per frame
+        else if (k == "--compact") a.compact = std::stoi(val());  // 0: 24-byte SLAM::point records on the wire (the round-4 form)
         else if (k == "--rdv-selftest") a.rdv_selftest = true;
         else if (k == "--no-allgather") a.no_allgather = true;  // diagnosis only: the per-step collective left out
-        else if (k == "--no-tuner") a.no_tuner = true;          // diagnosis only: keep the first pair of side streams
+        else if (k == "--no-tuner") a.no_tuner = true;          // (the default since round 5)
+        else if (k == "--tuner") a.no_tuner = false;            // opt in to the library's comparison of three side-stream pairs (vslam_ctx_tune_side_streams)
+        else if (k == "--hw-queues") a.hw_queues = std::stoi(val());  // GPU_MAX_HW_QUEUES for this process (set in main before HIP starts)
         else if (k == "--no-rccl") a.no_rccl = true;            // diagnosis only: single rank without a communicator
         else throw std::runtime_error("unknown argument " + k);
     }
@@ -134,11 +139,22 @@ double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock:
 
 int main(int argc, char** argv) {
     try {
-        // The HIP runtime spreads a process's streams over 4 hardware queues by default; this process has the
-        // library's three side streams, the upload / download / pack streams of the host-fed pipeline and RCCL's own.
-        // Streams that share a queue serialise (measured: -2 % frames/s device-resident with 4; host-fed 13.1 k
-        // steady state with 8, 13.2-13.4 k with 10-16).  Must be set before HIP starts.
-        ::setenv("GPU_MAX_HW_QUEUES", "12", 0);
+        // The HIP runtime spreads a process's streams over GPU_MAX_HW_QUEUES (default 4) hardware queues per priority level,
+        // and which queue a stream lands on decides whether the library's low-priority side streams run or crawl (DESIGN
+        // section 5.4).  Rounds 3-4 set the variable to 12 here and opted in to the stream tuner; since round 5 the library's
+        // join watchdog (include/vslam.h: vslam_ctx_join_watch_report) handles an unlucky layout by itself, so this host
+        // changes nothing in the environment: --hw-queues N / --tuner are there for the comparison runs.
+        // The host-fed pipeline is this HOST's own: it adds an upload, a download and a packing stream, and a copy stream that
+        // shares a hardware queue with a compute stream serialises with it (host-fed 7.6-8.5 k frames/s with 1 or 3 queues
+        // against 12.9 k with 12) - that mode keeps asking for 12 queues, unless the caller has set the variable.
+        {
+            bool hostfed_mode = false, given = false;
+            for (int i = 1; i + 1 < argc; ++i) {
+                if (std::string(argv[i]) == "--mode" && std::string(argv[i + 1]) == "hostfed") hostfed_mode = true;
+                if (std::string(argv[i]) == "--hw-queues") ::setenv("GPU_MAX_HW_QUEUES", argv[i + 1], 1), given = true;  // before HIP starts
+            }
+            if (hostfed_mode && !given) ::setenv("GPU_MAX_HW_QUEUES", "12", 0);
+        }
         const Args a = parse(argc, argv);
         const vslam::RankEnv env = vslam::RankEnv::from_environment();
         if (a.rdv_selftest) {  // the TCP hand-off of the RCCL id alone (no GPU): rank 0's bytes must reach every rank
@@ -161,6 +177,7 @@ int main(int argc, char** argv) {
         opt.rows = a.rows, opt.cols = a.cols, opt.batch = a.frames;
         opt.host_fed = hostfed;
         opt.pipelines = a.pipelines;
+        opt.compact_points = hostfed && a.compact != 0;
         opt.tune_side_streams = !a.no_tuner;  // this host opts in: the library compares three pairs of side streams during the warm-up
         opt.localize = a.lists != "candidates", opt.orient = a.lists == "orient" || a.lists == "describe", opt.describe = a.lists == "describe";
         if (a.octaves != 4) {
@@ -328,6 +345,10 @@ int main(int argc, char** argv) {
         }
         int probe_replaced = 0, probe_flat = 0;
         (void)vslam_ctx_side_stream_report(det.context(), &probe_replaced, &probe_flat);
+        int jw_level = 0, jw_done = 0;
+        float jw_lag = -1.0f;
+        (void)vslam_ctx_join_watch_report(det.context(), &jw_level, &jw_done, &jw_lag);
+        const char* hwq = std::getenv("GPU_MAX_HW_QUEUES");
         const double dt_max = ex.max_over_ranks(dt, cs);
         if (!a.dump.empty() && last) dump_lists(a.dump, a.rows, a.cols, *last);
         uint64_t gh = 0, gd = 0;
@@ -342,11 +363,13 @@ int main(int argc, char** argv) {
             std::printf("{\"exe\": \"Stream\", \"host\": \"C++ (BatchDetector) + %s\", \"mode\": \"%s\", \"n_gpus\": %d, \"frames_per_batch\": %d, "
                         "\"batches\": %d, \"warmup\": %d, \"rows\": %d, \"cols\": %d, \"octaves\": %d, \"frames_per_sec\": %.2f, \"ms_per_batch\": %.4f, "
                         "\"keypoints_per_batch\": {\"harris\": %llu, \"dog\": %llu}, \"keypoints_per_sec\": %.1f, \"rank0_counts\": [%llu, %llu], "
-                        "\"steady_ms_per_batch\": %.4f, \"steady_frames_per_sec\": %.2f, \"counts_by_rank\": %s, \"lists\": \"%s\", \"oriented_points_rank0_last_batch\": %llu, \"pipelines\": %d, \"side_stream_pair\": %d, \"side_stream_tuner\": %d}\n",
+                        "\"steady_ms_per_batch\": %.4f, \"steady_frames_per_sec\": %.2f, \"counts_by_rank\": %s, \"lists\": \"%s\", \"oriented_points_rank0_last_batch\": %llu, \"pipelines\": %d, \"side_stream_pair\": %d, \"side_stream_tuner\": %d, "
+                        "\"join_watch\": {\"level\": %d, \"done\": %d, \"last_lag_fraction\": %.4f}, \"compact_points\": %d, \"gpu_max_hw_queues\": \"%s\"}\n",
                         a.no_rccl ? "no communicator (--no-rccl)" : tcp ? "TCP rehearsal exchange (VSLAM_COUNT_BACKEND=tcp)" : "RCCL ncclAllGather", a.mode.c_str(),
                         env.world, a.frames, a.batches, a.warmup, a.rows, a.cols, det.params().n_octaves, fps, dt_max / a.batches * 1e3,
                         (unsigned long long)gh, (unsigned long long)gd, (double)(gh + gd) * a.batches / dt_max, (unsigned long long)all[0],
-                        (unsigned long long)all[1], steady_ms, steady_ms > 0 ? a.frames * 1e3 / steady_ms * env.world : 0.0, by_rank.c_str(), a.lists.c_str(), oriented_rank, det.pipelines(), probe_replaced, probe_flat);
+                        (unsigned long long)all[1], steady_ms, steady_ms > 0 ? a.frames * 1e3 / steady_ms * env.world : 0.0, by_rank.c_str(), a.lists.c_str(), oriented_rank, det.pipelines(), probe_replaced, probe_flat,
+                        jw_level, jw_done, (double)jw_lag, (int)(hostfed && a.compact != 0), hwq ? hwq : "default");
         }
         vslam::BatchDetector::free_pinned(h_frames);
         return 0;

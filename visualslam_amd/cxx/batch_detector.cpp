@@ -26,14 +26,24 @@ FrameKeypoints BatchResult::frame(int f) const {
     const uint64_t d0 = std::min(dog_offsets[f], dog_records), d1 = std::min(dog_offsets[f + 1], dog_records);
     k.harris = harris + h0;
     k.n_harris = (size_t)(h1 - h0);
-    k.dog = dog + d0;
     k.n_dog = (size_t)(d1 - d0);
+    if (dog16) {  // the list came down as 16-byte records: this frame's SLAM::points are rebuilt here
+        k.dog_expanded.resize(k.n_dog);
+        vslam_points16_expand(dog16 + d0, k.n_dog, k.dog_expanded.data());
+        k.dog = k.dog_expanded.data();
+    } else
+        k.dog = dog + d0;
     k.harris_total = harris_counts[f];
     k.dog_total = dog_counts[f];
     if (oriented_offsets) {
         const uint64_t o0 = std::min(oriented_offsets[f], oriented_records), o1 = std::min(oriented_offsets[f + 1], oriented_records);
-        k.oriented = oriented + o0;
         k.n_oriented = (size_t)(o1 - o0);
+        if (oriented16) {
+            k.oriented_expanded.resize(k.n_oriented);
+            vslam_points16_expand(oriented16 + o0, k.n_oriented, k.oriented_expanded.data());
+            k.oriented = k.oriented_expanded.data();
+        } else
+            k.oriented = oriented + o0;
         k.oriented_total = oriented_counts[f];
         k.oriented_survivors = oriented_survivors[f];
         if (descriptors && o1 <= descriptor_records) k.descriptors = descriptors + o0 * 128;
@@ -288,11 +298,19 @@ void BatchDetector::submit(const uint8_t* host_frames, int n) {
         check(vslam_pack_lists_dev(ctx_pack_, s.out.harris_kps, sizeof(vslam_kp), p_.harris_cap, s.out.harris_counts, n, s.d_hpacked,
                                    packed_cap_h_ * sizeof(vslam_kp), s.d_off),
               ctx_pack_, "vslam_pack_lists_dev (harris)");
-    if (s.out.dog_points)
+    if (s.out.dog_points && opt_.compact_points)
+        check(vslam_pack_points16_dev(ctx_pack_, s.out.dog_points, p_.dog_cap, s.out.dog_counts, n, reinterpret_cast<vslam_point16*>(s.d_ppacked),
+                                      packed_cap_p_ * sizeof(vslam_point16), s.d_off + (nb + 1)),
+              ctx_pack_, "vslam_pack_points16_dev (dog)");
+    else if (s.out.dog_points)
         check(vslam_pack_lists_dev(ctx_pack_, s.out.dog_points, sizeof(vslam_point), p_.dog_cap, s.out.dog_counts, n, s.d_ppacked,
                                    packed_cap_p_ * sizeof(vslam_point), s.d_off + (nb + 1)),
               ctx_pack_, "vslam_pack_lists_dev (dog)");
-    if (s.out.oriented_points)
+    if (s.out.oriented_points && opt_.compact_points)
+        check(vslam_pack_points16_dev(ctx_pack_, s.out.oriented_points, p_.oriented_cap, s.out.oriented_counts, n, reinterpret_cast<vslam_point16*>(s.d_opacked),
+                                      packed_cap_o_ * sizeof(vslam_point16), s.d_off + 2 * (nb + 1)),
+              ctx_pack_, "vslam_pack_points16_dev (oriented)");
+    else if (s.out.oriented_points)
         check(vslam_pack_lists_dev(ctx_pack_, s.out.oriented_points, sizeof(vslam_point), p_.oriented_cap, s.out.oriented_counts, n, s.d_opacked,
                                    packed_cap_o_ * sizeof(vslam_point), s.d_off + 2 * (nb + 1)),
               ctx_pack_, "vslam_pack_lists_dev (oriented)");
@@ -331,7 +349,11 @@ const BatchResult& BatchDetector::collect() {
     r.harris_counts = h_cnt;
     r.dog_counts = h_cnt + nb;
     r.harris = s.h_hpacked;
-    r.dog = s.h_ppacked;
+    const size_t prec = opt_.compact_points ? sizeof(vslam_point16) : sizeof(vslam_point);  // bytes per SLAM::point on the wire
+    if (opt_.compact_points)
+        r.dog16 = reinterpret_cast<const vslam_point16*>(s.h_ppacked);
+    else
+        r.dog = s.h_ppacked;
     const uint64_t th = s.out.harris_kps ? r.harris_offsets[s.n] : 0, tp = s.out.dog_points ? r.dog_offsets[s.n] : 0;
     r.harris_records = std::min<uint64_t>(th, packed_cap_h_);
     r.dog_records = std::min<uint64_t>(tp, packed_cap_p_);
@@ -342,10 +364,13 @@ const BatchResult& BatchDetector::collect() {
     if (r.harris_records)
         HIPX(hipMemcpyAsync(s.h_hpacked, s.d_hpacked, r.harris_records * sizeof(vslam_kp), hipMemcpyDeviceToHost, ds));
     if (r.dog_records)
-        HIPX(hipMemcpyAsync(s.h_ppacked, s.d_ppacked, r.dog_records * sizeof(vslam_point), hipMemcpyDeviceToHost, ds));
+        HIPX(hipMemcpyAsync(s.h_ppacked, s.d_ppacked, r.dog_records * prec, hipMemcpyDeviceToHost, ds));
     if (s.out.oriented_points) {
         r.oriented_offsets = h_off + 2 * (nb + 1);
-        r.oriented = s.h_opacked;
+        if (opt_.compact_points)
+            r.oriented16 = reinterpret_cast<const vslam_point16*>(s.h_opacked);
+        else
+            r.oriented = s.h_opacked;
         r.oriented_counts = h_cnt + 2 * nb;
         r.oriented_survivors = h_cnt + 3 * nb;
         r.oriented_cap = p_.oriented_cap;
@@ -354,7 +379,7 @@ const BatchResult& BatchDetector::collect() {
         r.truncated = r.truncated || to > packed_cap_o_;
         for (int f = 0; f < s.n && !r.truncated; ++f) r.truncated = r.oriented_survivors[f] > p_.oriented_cap || r.oriented_counts[f] > p_.oriented_cap;
         if (r.oriented_records)
-            HIPX(hipMemcpyAsync(s.h_opacked, s.d_opacked, r.oriented_records * sizeof(vslam_point), hipMemcpyDeviceToHost, ds));
+            HIPX(hipMemcpyAsync(s.h_opacked, s.d_opacked, r.oriented_records * prec, hipMemcpyDeviceToHost, ds));
         if (s.out.descriptors) {
             r.descriptors = s.h_dpacked;
             r.descriptor_defined = s.h_defined;

@@ -41,6 +41,9 @@ struct FrameKeypoints {
     // whether its rotated window was defined (include/vslam.h: vslam_sift_descriptors); may be null
     const float* descriptors = nullptr;
     const uint8_t* descriptor_defined = nullptr;
+    // Options::compact_points: the batch's SLAM::point lists travelled as 16-byte records; `dog` / `oriented` then point
+    // into these re-expanded copies, which the FrameKeypoints owns (a moved vector keeps its buffer: the pointers stay valid)
+    std::vector<vslam_point> dog_expanded, oriented_expanded;
 };
 
 struct BatchResult {
@@ -48,7 +51,7 @@ struct BatchResult {
     const uint64_t* harris_offsets = nullptr;  // [n_frames + 1] record offsets into `harris`
     const uint64_t* dog_offsets = nullptr;     // [n_frames + 1]
     const vslam_kp* harris = nullptr;          // packed, pinned host memory
-    const vslam_point* dog = nullptr;
+    const vslam_point* dog = nullptr;          // nullptr with Options::compact_points: see dog16
     const uint32_t* harris_counts = nullptr;   // [n_frames] true totals
     const uint32_t* dog_counts = nullptr;
     uint64_t harris_records = 0, dog_records = 0;  // records present in the packed lists
@@ -62,6 +65,10 @@ struct BatchResult {
     uint64_t oriented_records = 0, descriptor_records = 0;
     uint32_t oriented_cap = 0;
     bool truncated = false;  // a frame exceeded its cap, or the batch the host budget (records beyond it are missing)
+    // Options::compact_points: the packed SLAM::point lists as 16-byte records (vslam_pack_points16_dev: a third fewer
+    // bytes over PCIe); frame() re-expands a frame's records to SLAM::point (vslam_points16_expand), byte-identical
+    const vslam_point16* dog16 = nullptr;
+    const vslam_point16* oriented16 = nullptr;
     FrameKeypoints frame(int f) const;
 };
 
@@ -83,6 +90,9 @@ public:
         // own, and -20 % when they do not: the outcome follows GPU_MAX_HW_QUEUES and the order in which streams are first
         // used (DESIGN section 5.4 has the table), so the default stays at one pipeline.
         int pipelines = 1;
+        // host-fed: the DoG and oriented lists cross PCIe as 16-byte records {row, col, value, level | octave << 8 | padding << 16}
+        // instead of SLAM::point's 24 bytes (8 of which are constants of the list); BatchResult::frame() re-expands them
+        bool compact_points = false;
         size_t host_records_per_frame = (size_t)1 << 17;  // pinned host budget per list, averaged over the batch
         bool host_fed = true;            // false: no frame / list staging buffers at all (device-resident use only)
         // The rest of the reference's DoG executable for every frame of the batch (Diff_of_Gauss.cpp:785-791):
