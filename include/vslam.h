@@ -91,14 +91,21 @@ int vslam_ctx_sync(vslam_ctx* ctx);
  * vslam_ctx_side_stream_report: the index of the pair in use (0 = the first created) and the state of the comparison
  * (0 off or not started, 1 measuring, 2 decided).  Diagnostic only. */
 int vslam_ctx_tune_side_streams(vslam_ctx* ctx, int on);
+/* Priority of the batched path's two side streams (Harris chain; scans and lists).  Default (low = 0): the context stream's
+ * own priority - within 3.5 % of the best schedule for every hardware-queue layout measured.  low = 1:
+ * the device's LOWEST priority, so that the side work yields to the octave kernels - 2-3 % faster when every stream has a
+ * hardware queue to itself, up to 18 % slower when one does not: for a host that controls GPU_MAX_HW_QUEUES and its own
+ * stream count (vslam::BatchDetector::Options::yielding_side_streams; Stream's host-fed mode).  Before the context's first
+ * batch call only (VSLAM_ERR_UNSUPPORTED afterwards); VSLAM_SIDE_PRIORITY=low|main sets the default of new contexts.
+ * Results never depend on it. */
+int vslam_ctx_set_side_stream_priority(vslam_ctx* ctx, int low);
 /* Always on (VSLAM_JOIN_WATCH=0 disables; idle while a comparison of the tuner above runs and during stream captures):
  * the first full-size batch calls of a context measure how long the context's stream waits at the end of the call for the
- * side streams (three events on the stream, read by a later call once complete - no host wait).  Two calls with more than
- * 10 % of the call spent waiting mean a side stream sits on a starved hardware queue: the context then moves its side
- * work to streams of the main stream's priority (level 1) and, if that does not help either, onto the context's stream itself
- * (level 2).  Three calls in a row under the limit end the watch (done).  A caller that embeds the library in a process
- * with its own streams gets a sane schedule without setting GPU_MAX_HW_QUEUES or opting in to anything; results never
- * depend on the level.  last_lag_fraction: the most recent measurement (-1: none yet). */
+ * side streams (three events on the stream, read by a later call once complete - no host wait).  Three calls whose median
+ * wait exceeds the level's limit (3 % of the call with yielding side streams = level 0, 10 % at the default level 1) start a
+ * trial of the next level - 1: side streams at the context stream's priority, 2: side work on the context's stream itself -
+ * which is kept only if its fastest call is 1 % faster than the previous level's; then the watch ends (done).  Results
+ * never depend on the level.  last_lag_fraction: the most recent measurement (-1: none yet). */
 int vslam_ctx_join_watch_report(const vslam_ctx* ctx, int* level, int* done, float* last_lag_fraction);
 int vslam_ctx_side_stream_report(const vslam_ctx* ctx, int* pair, int* state);
 /* Two batches in flight: a second context (own stream, own output buffers) whose batch starts when `leader`'s most

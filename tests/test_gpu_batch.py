@@ -20,6 +20,18 @@ def env():
     ctx.close()
 
 
+@pytest.fixture(params=["dot", "mx"])
+def path(request, env):
+    """Both kernel families for the same rows: the default packed-dot kernels and, switched on for the
+    shared context only while the test runs, the OPT-IN matrix-core kernels - every parametrised test shows up as a dot of
+    its own instead of inside one child-process run."""
+    ctx, _ = env
+    was = ctx.matrix_path()
+    ctx.set_matrix_path(request.param == "mx")
+    yield request.param
+    ctx.set_matrix_path(was)
+
+
 def run_batch(ctx, torch, frames_np, with_nms2=True, **pkw):
     n, rows, cols = frames_np.shape
     p = capi.default_params(rows, cols, **pkw)
@@ -110,7 +122,7 @@ def check_frame(p, L, out, f, img, n_oct):
     want.close()
 
 
-def test_batch_small_frames_all_outputs(env):
+def test_batch_small_frames_all_outputs(env, path):
     ctx, torch = env
     frames = synth.frames_np(11, 96, 160, stream_id=7)
     frames[3] = synth.frame_np(96, 160, kind="noise")
@@ -137,7 +149,7 @@ def test_batch_larger_than_one_chunk(env, mode):
 
 
 @pytest.mark.parametrize("lists", [False, True])
-def test_two_full_chunks_of_256_frames(env, lists):
+def test_two_full_chunks_of_256_frames(env, lists, path):
     # with two chunks of >= 64 frames the second chunk's half-batch upsample runs on a
     # side stream and overwrites the octave bases of frames [128, 256) of the FIRST chunk; in a pyramid-only
     # call nothing but the ev_chunk wait orders it behind the first chunk's octave-0 kernel.  Every frame
@@ -219,7 +231,7 @@ def test_batch_of_70_frames_goes_through_octave_0_in_two_halves(env, mode):
         check_frame(p, L, out, f, frames[f], 3)
 
 
-def test_batch_ragged_size_and_small_caps(env):
+def test_batch_ragged_size_and_small_caps(env, path):
     ctx, torch = env
     frames = synth.frames_np(2, 75, 131, stream_id=9)
     p, L, out = run_batch(ctx, torch, frames, n_octaves=2, harris_cap=5, dog_cap=7, min_contrast=0)
@@ -276,7 +288,7 @@ def test_config1_640x480_plumbing(env):
     check_frame(p, L, out, 0, frames[0], 4)
 
 
-def test_config2_and_3_full_1080p_frame(env):
+def test_config2_and_3_full_1080p_frame(env, path):
     # BASELINE configs 2+3: one 1920x1080 frame, Harris+NMS indices and the 4x(6,5) pyramid +
     # extrema, bit-exact against the oracle
     ctx, torch = env
@@ -532,6 +544,7 @@ def test_stream_tuner_compares_side_stream_pairs_without_touching_the_results():
         ctx.close()
     ctx = capi.Context(0, torch.cuda.current_stream().cuda_stream)
     try:
+        ctx.set_side_stream_priority(True)  # the tuner compares pairs of YIELDING side streams (the default since round 5 is the main stream's priority)
         ctx.tune_side_streams(True)
         first = None
         states = []
@@ -548,6 +561,7 @@ def test_stream_tuner_compares_side_stream_pairs_without_touching_the_results():
         ctx.close()
     ctx = capi.Context(0, torch.cuda.current_stream().cuda_stream)
     try:
+        ctx.set_side_stream_priority(True)  # the tuner compares pairs of YIELDING side streams (the default since round 5 is the main stream's priority)
         ctx.tune_side_streams(True)
         a, b = synth.frames_np(32, 120, 160, stream_id=6), synth.frames_np(40, 120, 160, stream_id=6)
         small = synth.frames_np(3, 120, 160, stream_id=6)
@@ -558,6 +572,7 @@ def test_stream_tuner_compares_side_stream_pairs_without_touching_the_results():
         ctx.close()
     ctx = capi.Context(0, torch.cuda.current_stream().cuda_stream)
     try:
+        ctx.set_side_stream_priority(True)  # the tuner compares pairs of YIELDING side streams (the default since round 5 is the main stream's priority)
         ctx.tune_side_streams(True)
         a, b = synth.frames_np(32, 120, 160, stream_id=6), synth.frames_np(40, 120, 160, stream_id=6)
         for fr in (a, a, b, a, b, a, b):  # a caller whose full-size shape keeps changing: given up on the first pair
@@ -578,6 +593,7 @@ def test_stream_tuner_never_blocks_the_host():
     capi.build()
     ctx = capi.Context(0, torch.cuda.current_stream().cuda_stream)
     try:
+        ctx.set_side_stream_priority(True)  # the tuner compares pairs of YIELDING side streams (the default since round 5 is the main stream's priority)
         ctx.tune_side_streams(True)
         rows, cols, n = 1080, 1920, 64
         p = capi.default_params(rows, cols)
@@ -641,7 +657,7 @@ def test_join_watchdog_levels_give_the_same_results_and_the_watch_ends():
     res = {}
     saved = os.environ.pop("VSLAM_JOIN_WATCH_LEVEL", None)
     try:
-        for level in (None, 1, 2):
+        for level in (None, 0, 1, 2):
             if level is None:
                 os.environ.pop("VSLAM_JOIN_WATCH_LEVEL", None)
             else:
@@ -650,7 +666,7 @@ def test_join_watchdog_levels_give_the_same_results_and_the_watch_ends():
             try:
                 o = outs()
                 if level is None:
-                    assert ctx.join_watch_report() == (0, False, -1.0)
+                    assert ctx.join_watch_report() == (1, False, -1.0)  # the default: side streams at the context stream's priority
                     for _ in range(16):  # call 1 of a level is not measured; three more are, and read by a later call once finished
                         ctx.detect_batch(p, frames, **o)
                         torch.cuda.synchronize()
@@ -672,7 +688,7 @@ def test_join_watchdog_levels_give_the_same_results_and_the_watch_ends():
     cnt = res[None]["dog_counts"].cpu().numpy()
     hcn = res[None]["harris_counts"].cpu().numpy()
     assert cnt.min() > 0
-    for level in (1, 2):
+    for level in (0, 1, 2):
         for k in ("response", "nms_mask", "harris_counts", "pyramid", "extrema_bits", "dog_counts"):
             assert torch.equal(res[None][k], res[level][k]), (level, k)
         for f in range(n):
@@ -702,7 +718,7 @@ def test_fast_paths_are_the_ones_that_run(env):
 
 
 @pytest.mark.parametrize("shape,n_oct", [((8, 8), 1), ((24, 40), 2), ((64, 48), 3), ((32, 128), 4)])
-def test_batch_tiny_frames(env, shape, n_oct):
+def test_batch_tiny_frames(env, shape, n_oct, path):
     # tiny frames through the specialised kernels: halos far larger than the image (repeated
     # reflection), single-tile grids, lattice rows shorter than one ballot word
     ctx, torch = env
@@ -770,8 +786,8 @@ def test_matrix_core_octave_kernel_matches_oracle():
         pytest.skip("already inside the matrix-path run")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, VSLAM_MX="1")
-    sel = ("random_shapes or ragged or tiny_frames or config2_and_3 or small_frames_all_outputs or matrix_kernel_is_dispatched "
-           "or two_full_chunks or batch_on_the_reference_images")
+    # (the batched shape sweep - random shapes, ragged, tiny, 1080p, two chunks - runs in-process since round 5: the `path` fixture)
+    sel = "matrix_kernel_is_dispatched or batch_on_the_reference_images"
     sel += " or pyramid or golden_fixtures or filter_keypoints or feature_point_localization or process_gradients"  # the per-image API too
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_batch.py"),
                         os.path.join(root, "tests", "test_gpu_ref_images.py"), os.path.join(root, "tests", "test_gpu_parity.py"),
@@ -883,7 +899,7 @@ def test_matrix_path_two_chunks_of_1080p_frames(env):
         assert a["dog_points"][f][:m].cpu().numpy().view(capi.POINT_DTYPE).reshape(-1).tobytes() == allp[:m].tobytes(), f
 
 
-def test_batch_random_shapes(env):
+def test_batch_random_shapes(env, path):
     # seeded sweep over frame sizes (multiples of 4/8/16 and ragged ones) through every dispatch
     # path of the batch: specialised and generic kernels must agree with the oracle everywhere
     ctx, torch = env

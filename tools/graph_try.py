@@ -87,24 +87,27 @@ def one(api, nested, n=8, rows=240, cols=320, spread=1, early=1):
             hip.hipGetErrorString.restype = C.c_char_p
             hip.hipGetErrorName.restype = C.c_char_p
 
-            def chk(name, rc):
-                print("GRAPH_TRY_STEP done: " + name, file=sys.stderr, flush=True)
+            def call(name, fn):
+                print("GRAPH_TRY_STEP calling " + name, file=sys.stderr, flush=True)  # the last "calling" line before a crash names the API
+                rc = fn()
+                print("GRAPH_TRY_STEP returned " + name, file=sys.stderr, flush=True)
                 rep["steps"].append({name: "hipSuccess" if rc == 0 else f"{rc} {hip.hipGetErrorName(rc).decode()}: {hip.hipGetErrorString(rc).decode()}"})
                 return rc == 0
 
             sh = C.c_void_p(st.cuda_stream)
             graph, gexec = C.c_void_p(), C.c_void_p()
-            ok = chk("hipStreamBeginCapture(ThreadLocal)", hip.hipStreamBeginCapture(sh, 1))
+            ok = call("hipStreamBeginCapture(ThreadLocal)", lambda: hip.hipStreamBeginCapture(sh, 1))
             ok = ok and step("vslam_detect_batch_dev under capture", lambda: ctx.detect_batch(p, frames, **b))
-            ok = chk("hipStreamEndCapture", hip.hipStreamEndCapture(sh, C.byref(graph))) and ok
+            print("GRAPH_TRY_STEP returned vslam_detect_batch_dev", file=sys.stderr, flush=True)
+            ok = call("hipStreamEndCapture", lambda: hip.hipStreamEndCapture(sh, C.byref(graph))) and ok
             if ok:
                 nn = C.c_size_t()
-                chk("hipGraphGetNodes", hip.hipGraphGetNodes(graph, None, C.byref(nn)))
+                call("hipGraphGetNodes", lambda: hip.hipGraphGetNodes(graph, None, C.byref(nn)))
                 rep["graph_nodes"] = nn.value
-                ok = chk("hipGraphInstantiate", hip.hipGraphInstantiate(C.byref(gexec), graph, None, None, 0))
+                ok = call("hipGraphInstantiate", lambda: hip.hipGraphInstantiate(C.byref(gexec), graph, None, None, 0))
             if ok:
-                ok = chk("hipGraphLaunch", hip.hipGraphLaunch(gexec, sh))
-                ok = chk("hipStreamSynchronize", hip.hipStreamSynchronize(sh)) and ok
+                ok = call("hipGraphLaunch", lambda: hip.hipGraphLaunch(gexec, sh))
+                ok = call("hipStreamSynchronize", lambda: hip.hipStreamSynchronize(sh)) and ok
         if ok:
             torch.cuda.synchronize()
             same = bool(torch.equal(a["oriented_counts"], b["oriented_counts"]) and torch.equal(a["dog_counts"], b["dog_counts"]))
@@ -121,14 +124,13 @@ def main():
     for api in ("raw", "torch"):
         for nested in ((0, 2, 3, 1) if api == "raw" else (0, 1)):  # 2: only the early edge test's fork, 3: only the spread launches', 1: both
             env = dict(os.environ, VSLAM_CAPTURE_NESTED_FORKS=str(nested))
-            if nested:
-                env["AMD_LOG_LEVEL"] = "3"  # the HIP runtime logs every API call: the last lines before a crash name the call
             bt = os.path.join(ROOT, "tools", "segv_bt.so")  # gcc -shared -fPIC -O1 -g tools/segv_bt.c -o tools/segv_bt.so
             if os.path.exists(bt):
                 env["LD_PRELOAD"] = (env.get("LD_PRELOAD", "") + " " + bt).strip()
             r = subprocess.run(["timeout", "-k", "10", "120", sys.executable, os.path.abspath(__file__), "--case", api, str(nested)], capture_output=True, text=True, env=env)
             lines = [l for l in r.stdout.splitlines() if l.startswith("GRAPH_TRY ")]
             print(json.dumps({"case": [api, nested], "exit_code": r.returncode, "report": json.loads(lines[-1][10:]) if lines else None,
+                              "steps_seen": [l for l in r.stderr.splitlines() if l.startswith("GRAPH_TRY_STEP")][-4:],
                               "stderr_tail": r.stderr[-6000:] if (r.returncode != 0 or not lines) else ""}), flush=True)
 
 

@@ -132,6 +132,7 @@ SIGNATURES = {
     "vslam_ctx_side_stream_report": (_I, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "vslam_ctx_tune_side_streams": (_I, [_P, _I]),
     "vslam_ctx_join_watch_report": (_I, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_float)]),
+    "vslam_ctx_set_side_stream_priority": (_I, [_P, _I]),
     "vslam_detect_batch_host": (_I, [_P, C.POINTER(Params), _P, _Z, _I, C.POINTER(HostLists)]),
     "vslam_pack_lists_dev": (_I, [_P, _P, _Z, C.c_uint32, _P, _I, _P, _Z, _P]),
     "vslam_pack_points16_dev": (_I, [_P, _P, C.c_uint32, _P, _I, _P, _Z, _P]),
@@ -495,6 +496,11 @@ class Context:
         a, b = C.c_int(0), C.c_int(0)
         self._chk(lib().vslam_ctx_side_stream_report(self._h, C.byref(a), C.byref(b)), "vslam_ctx_side_stream_report")
         return a.value, b.value
+
+    def set_side_stream_priority(self, low: bool):
+        """vslam_ctx_set_side_stream_priority: low = True puts the two side streams at the device's lowest priority (yielding);
+        the default is the context stream's priority.  Before the first batch call only."""
+        self._chk(lib().vslam_ctx_set_side_stream_priority(self._h, int(bool(low))), "vslam_ctx_set_side_stream_priority")
 
     def join_watch_report(self):
         """vslam_ctx_join_watch_report: (level: 0 low-priority side streams / 1 flat priority / 2 no side streams, done,

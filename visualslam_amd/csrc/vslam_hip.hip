@@ -48,18 +48,28 @@ struct StreamTuner {
     int calls = 0, resets = 0;
 };
 
-// Join watchdog (round 5): the default answer to the same hardware-queue lottery, for every caller and without opt-in.
-// The first full-size batch calls of a context are bracketed by three events on the main stream - start, "my own kernels
-// are enqueued up to here" (just before the waits on the side streams' join events) and end.  t(end) - t(own) is how long
-// the main stream sat waiting for side work: 0.4 % of an 18 ms batch when the side streams run freely (their last
-// kernels follow the main stream's last), 5 % with HIP's default of four hardware queues, 20 % when a low-priority side
-// queue is being starved (the scan of octave 0 then takes 10 ms instead of 3.5 and the join waits for it).
-// A later call reads the events once they are complete (hipEventQuery: nothing ever waits on the host).  Three measured
-// calls with a median lag above 3 % start a TRIAL of the next form - side streams at the main stream's priority (level 1:
-// never starvable), and from there, if the lag is still above 10 %, no side streams at all (level 2) - and the trial is
-// kept only if its fastest call beats the previous form's fastest by 1 %; otherwise the context goes back.  Either way the
-// watch ends after at most ten full-size calls.  Off while a capture is on, while the opt-in tuner is comparing pairs, and
-// under VSLAM_JOIN_WATCH=0; VSLAM_JOIN_WATCH_LEVEL pins a level.  Results never depend on the level.
+// Side-stream priority and the join watchdog (round 5).
+// The batched path's two side streams (Harris chain; scans and lists) may run at the LOWEST stream priority, so that they
+// yield to the octave kernels, or at the main stream's.  Which is faster is decided by the hardware queue each stream
+// happens to land on (HIP multiplexes streams onto GPU_MAX_HW_QUEUES queues per priority level, default 4; DESIGN section
+// 5.4).  Same box, C++ host, device-resident, frames/s with 2 / 3 / 4 / 6 / 12 queues: yielding 14.1 k / 11.5 k / 13.4 k /
+// 14.0 k / 14.0 k, same priority 13.7 k / 13.7 k / 14.0 k / 13.7 k / 14.2 k - yielding wins 2-3 % on a lucky layout and
+// loses 18 % on an unlucky one (a low-priority queue behind the main queue's barrier packet crawls), same priority never
+// moves more than 3.5 %.  The default is therefore the SAME priority (level 1): a caller that embeds the library in a
+// process with streams of its own gets a sane schedule with HIP's default queue count, without setting an environment
+// variable or opting in to anything.  A host that owns its queue layout asks for yielding streams (level 0) with
+// vslam_ctx_set_side_stream_priority / VSLAM_SIDE_PRIORITY=low (Stream's host-fed mode, which also asks for 12 queues).
+//
+// The watchdog keeps either choice honest.  The first full-size batch calls of a context are bracketed by three events on
+// the main stream - start, "my own kernels are enqueued up to here" (just before the waits on the side streams' join
+// events) and end.  t(end) - t(own) is how long the main stream sat waiting for side work: 0.4 % of an 18 ms batch when
+// the side streams run freely, 5 % with yielding streams on four queues, 20 % when one of them is being starved.  A later
+// call reads the events once they are complete (hipEventQuery: nothing ever waits on the host).  Three measured calls with
+// a median lag above the level's limit (3 % at level 0, 10 % at level 1) start a TRIAL of the next level - same priority,
+// then no side streams at all (level 2) - and the trial is kept only if its fastest call beats the previous level's fastest
+// by 1 %; otherwise the context goes back.  Either way the watch ends after at most ten measured calls.  Off while a capture
+// is on, while the opt-in tuner is comparing pairs, and under VSLAM_JOIN_WATCH=0; VSLAM_JOIN_WATCH_LEVEL pins a level.
+// Results never depend on the level.
 struct JoinWatch {
     static constexpr int RING = 4, NEED = 3;
     hipEvent_t t0[RING] = {}, tm[RING] = {}, t1[RING] = {};
@@ -70,8 +80,9 @@ struct JoinWatch {
     int n_meas = 0;             // measurements at the current level
     float lag[NEED] = {}, best_total = 0.0f;
     float level_best[3] = {0.0f, 0.0f, 0.0f};  // fastest measured call at each level tried
-    int level = 0;              // 0: low-priority side streams, 1: flat priority, 2: no side streams
-    bool done = false, disabled = false;
+    int level = 1;              // 0: low-priority (yielding) side streams, 1: the main stream's priority, 2: no side streams
+    int trial_from = -1;        // the level a running trial came from (-1: the current level is not a trial)
+    bool done = false, disabled = false, pinned = false;
     float last_lag_frac = -1.0f;
     hipStream_t pair[2][2] = {};  // the side-stream pairs of levels 0 and 1 (both live until the context goes)
 };
@@ -98,7 +109,8 @@ struct vslam_ctx {
     static constexpr int kAux = 3;
     hipStream_t aux[kAux] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[kAux] = {nullptr, nullptr, nullptr}, ev_oct[VSLAM_MAX_OCTAVES] = {};
-    int prio_lo = 0;      // priority of the two yielding side streams (0: the main stream's)
+    int prio_lo = 0;      // priority of the two side streams in use (0: the main stream's)
+    int prio_dev_lo = 0;  // the device's lowest stream priority (0: it has no priority levels)
     StreamTuner tuner;    // which pair of side streams the batched path runs on (see StreamTuner)
     JoinWatch watch;      // steps the side streams down when their join lags (see JoinWatch)
     hipEvent_t ev_phase = nullptr;  // recorded by every vslam_detect_batch_dev call once its octave-0 kernels are enqueued (vslam_ctx_follow)
@@ -327,9 +339,10 @@ static int watch_set_level(vslam_ctx* c, int level) {
     w.level = level;
     if (level <= 1) {
         for (int i = 0; i < 2; ++i) {
-            if (!w.pair[level][i]) HIPCHK(c, hipStreamCreateWithFlags(&w.pair[level][i], hipStreamNonBlocking));  // level 1: the main stream's priority
+            if (!w.pair[level][i]) TRY(create_side_stream(c, level == 0 ? c->prio_dev_lo : 0, &w.pair[level][i]));
             c->aux[i] = w.pair[level][i];  // the pair being left is idle: every call joins its side streams back
         }
+        c->prio_lo = level == 0 ? c->prio_dev_lo : 0;
     }
     return VSLAM_OK;
 }
@@ -338,7 +351,7 @@ static int watch_before_call(vslam_ctx* c, bool eligible, bool capturing) {
     JoinWatch& w = c->watch;
     w.recording = -1;
     if (w.done || w.disabled || capturing || (c->tuner.enabled && !c->tuner.done)) return VSLAM_OK;
-    if (!w.pair[0][0]) w.pair[0][0] = c->aux[0], w.pair[0][1] = c->aux[1];
+    if (w.level <= 1 && !w.pair[w.level][0]) w.pair[w.level][0] = c->aux[0], w.pair[w.level][1] = c->aux[1];
     for (int i = 0; i < JoinWatch::RING; ++i) {
         if (!w.live[i]) continue;
         const hipError_t q = hipEventQuery(w.t1[i]);
@@ -359,25 +372,25 @@ static int watch_before_call(vslam_ctx* c, bool eligible, bool capturing) {
         }
     }
     if (w.n_meas >= JoinWatch::NEED) {
-        float a = w.lag[0], b = w.lag[1], m = w.lag[2];
+        const float a = w.lag[0], b = w.lag[1], m = w.lag[2];
         const float med = std::max(std::min(a, b), std::min(std::max(a, b), m));
         w.level_best[w.level] = w.best_total;
-        if (w.level == 0) {
-            if (med <= 0.03f || c->prio_lo == 0)  // the side streams run freely (or there are no priority levels to give up)
-                w.done = true;
-            else
-                TRY(watch_set_level(c, 1));
-        } else if (w.level == 1) {
-            if (!(w.best_total < 0.99f * w.level_best[0])) {  // the trial did not pay: back to the yielding side streams
-                TRY(watch_set_level(c, 0));
-                w.done = true;
-            } else if (med > 0.10f)
-                TRY(watch_set_level(c, 2));
-            else
-                w.done = true;
-        } else {
-            if (!(w.best_total < 0.99f * w.level_best[1])) TRY(watch_set_level(c, 1));
+        bool keep = true;
+        if (w.trial_from >= 0 && !(w.best_total < 0.99f * w.level_best[w.trial_from])) {  // the trial did not pay: go back, stop
+            TRY(watch_set_level(c, w.trial_from));
+            w.trial_from = -1;
             w.done = true;
+            keep = false;
+        }
+        if (keep) {
+            w.trial_from = -1;
+            const float limit = w.level == 0 ? 0.03f : 0.10f;
+            if (w.level < 2 && med > limit && (w.level == 1 || c->prio_dev_lo != 0)) {  // (level 0 without priority levels IS level 1)
+                const int from = w.level;
+                TRY(watch_set_level(c, from + 1));
+                w.trial_from = from;
+            } else
+                w.done = true;
         }
         if (w.done) return VSLAM_OK;
     }
@@ -403,8 +416,9 @@ static int ensure_aux(vslam_ctx* c) {
         (void)hipGetLastError();  // priorities are a speed matter only: do not leave the error for the next launch check
         prio_lo = 0;
     }
-    static const bool flat = getenv("VSLAM_FLAT_PRIORITY") != nullptr;
-    c->prio_lo = (flat || c->watch.level >= 1) ? 0 : prio_lo;
+    c->prio_dev_lo = prio_lo;
+    if (prio_lo == 0 && c->watch.level == 0) c->watch.level = 1;  // no priority levels on this device
+    c->prio_lo = c->watch.level >= 1 ? 0 : prio_lo;
     for (int i = 0; i < vslam_ctx::kAux; ++i) {
         // aux[0], aux[1] (Harris chain, scans and lists) yield to the octave kernels; aux[2] carries only the
         // second-half upsample, which the main stream WAITS for: at low priority it was starved for the whole
@@ -1283,9 +1297,11 @@ int vslam_ctx_create(int device, void* stream, vslam_ctx** out) {
         c->orient_scalar_form = es && es[0] == '1';
         const char* jw = std::getenv("VSLAM_JOIN_WATCH");
         c->watch.disabled = jw && jw[0] == '0';
+        if (const char* sp = std::getenv("VSLAM_SIDE_PRIORITY")) c->watch.level = (sp[0] == 'l' || sp[0] == 'L') ? 0 : 1;  // low | main
+        if (std::getenv("VSLAM_FLAT_PRIORITY")) c->watch.level = 1;  // (rounds 3-4: the switch away from the then default)
         if (const char* lv = std::getenv("VSLAM_JOIN_WATCH_LEVEL")) {  // tests / A-B runs: start (and stay) at a level
             c->watch.level = std::min(2, std::max(0, std::atoi(lv)));
-            c->watch.done = true;
+            c->watch.done = c->watch.pinned = true;
         }
         const char* t = std::getenv("VSLAM_STREAM_TUNER");
         c->tuner.enabled = t && t[0] == '1';
@@ -2275,10 +2291,17 @@ int vslam_detect_batch_dev(vslam_ctx* c, const vslam_params* pp, const uint8_t* 
         const char* e = std::getenv("VSLAM_ORIENT_SPREAD");
         return !(e && e[0] == '0');
     }();
-    // Under stream capture (hipGraph) a fork may only start from the capturing stream itself: this runtime ends the capture
-    // with a fault when a side stream forks to another side stream and takes the join back (tools/graph_try.py found it in
-    // the orientation stage).  The two nested forks of that stage - the early edge test and the spread launches - stay on
-    // their own stream while a capture is on; everything else forks from and joins to the main stream.
+    // Under stream capture (hipGraph) no two SIDE streams of the call may wait on each other's events.  The topology is legal
+    // (fork from the origin stream, cross-dependencies between the forked streams, all joined back), but this HIP runtime
+    // (libamdhip64 of ROCm 7.0, the copy torch 2.10 bundles) books every hipStreamWaitEvent of a non-origin stream on a captured
+    // event as "this stream becomes a capture child of the event's stream": side stream B waiting on A's event and, later, A
+    // waiting on B's leaves A in B's child list and B in A's, and hipStreamEndCapture walks the child lists recursively -
+    // for ever.  The process dies of stack exhaustion inside libamdhip64.so (tools/graph_try.py reproduces it in a child
+    // process: SIGSEGV, 64 of 64 backtrace frames at libamdhip64.so+0x2d34a8, a function that calls itself for every entry
+    // of the vector at this+0x2e0 after clearing the list at this+0x308; profiles/r05_graph_try.json).  The orientation stage
+    // has two such pairs - the early edge test (list stream -> Harris stream -> back) and the spread launches (list stream
+    // -> two idle side streams -> back); each alone reproduces the crash.  While a capture is on, both stay on the list
+    // stream; everything else forks from and joins to the main (origin) stream, which the runtime never files as a child.
     bool capturing = false, cap_early = false, cap_spread = false;  // the nested forks stay out of a capture
     {
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -2408,6 +2431,13 @@ int vslam_ctx_side_stream_report(const vslam_ctx* c, int* pair, int* state) {
     if (!c) return VSLAM_ERR_INVALID;
     if (pair) *pair = c->tuner.chosen;
     if (state) *state = c->tuner.done ? 2 : ((c->tuner.enabled && c->tuner.calls > 1) ? 1 : 0);
+    return VSLAM_OK;
+}
+
+int vslam_ctx_set_side_stream_priority(vslam_ctx* c, int low) {
+    if (!c) return VSLAM_ERR_INVALID;
+    if (c->ev_fork) return fail(c, VSLAM_ERR_UNSUPPORTED, "set_side_stream_priority: the side streams exist already - call it before the context's first batch call");
+    if (!c->watch.pinned) c->watch.level = low ? 0 : 1;
     return VSLAM_OK;
 }
 

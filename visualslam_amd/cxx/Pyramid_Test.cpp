@@ -3,6 +3,7 @@
 // sources.  building.jpg is 868x600; geometry needs only its size.
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 
 #include "imgio.hpp"
 #include "vslam_cxx.hpp"
@@ -59,6 +60,22 @@ int main() {
             GaussPyramid sp{small_img, 2, 1.6};
             EXPECT(sp.pyramidGradX().size() == 2 && sp.pyramidGradOrient().at(1).size() == 6);
             EXPECT(sp.pyramidGradMag().at(0)[5].rows == 96 && sp.pyramidGradY().at(1)[0].cols == 64);
+        }
+        {   // the reference's constructor runs processGradients itself (GaussPyramid.cpp:118): with setEagerGradients the
+            // mirror does too, and what the getters then return equals what the lazy pyramid computes on demand
+            Mat small_img = imgio::synthetic(48, 64, 3);
+            GaussPyramid lazy{small_img, 2, 1.6};
+            GaussPyramid::setEagerGradients(true);
+            GaussPyramid eager{small_img, 2, 1.6};
+            GaussPyramid::setEagerGradients(false);
+            EXPECT(GaussPyramid::eagerGradients() == false);
+            for (int o = 0; o < 2; ++o)
+                for (int l = 0; l < 6; ++l) {
+                    const Mat &a = eager.octaveGradOrient(o)[l], &b = lazy.octaveGradOrient(o)[l];
+                    const Mat &am = eager.octaveGradMag(o)[l], &bm = lazy.octaveGradMag(o)[l];
+                    EXPECT(a.rows == b.rows && a.cols == b.cols && std::memcmp(a.data, b.data, (size_t)a.rows * a.step) == 0);
+                    EXPECT(std::memcmp(am.data, bm.data, (size_t)am.rows * am.step) == 0);
+                }
         }
         GaussPyramid autop{img, 1.6};  // second constructor: floor(log2(600)) - 4 = 5 octaves
         EXPECT(autop.getNumOctaves() == 5);

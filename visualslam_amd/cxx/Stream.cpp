@@ -46,6 +46,7 @@ struct Args {
     int frames = 256, batches = 8, warmup = 6, rows = 1080, cols = 1920, octaves = 4, pipelines = 1;
     bool rdv_selftest = false, no_allgather = false, no_rccl = false, no_tuner = true;
     int hw_queues = 0;
+    std::string side_priority;  // "" = by mode: host-fed low (with its 12 queues), device-resident the library's default (main)
     int compact = 1;  // host-fed: SLAM::point lists cross PCIe as 16-byte records (BatchDetector::Options::compact_points)
 };
 
@@ -73,6 +74,7 @@ Args parse(int argc, char** argv) {
         else if (k == "--no-allgather") a.no_allgather = true;  // diagnosis only: the per-step collective left out
         else if (k == "--no-tuner") a.no_tuner = true;          // (the default since round 5)
         else if (k == "--tuner") a.no_tuner = false;            // opt in to the library's comparison of three side-stream pairs (vslam_ctx_tune_side_streams)
+        else if (k == "--side-priority") a.side_priority = val();  // low | main: vslam_ctx_set_side_stream_priority
         else if (k == "--hw-queues") a.hw_queues = std::stoi(val());  // GPU_MAX_HW_QUEUES for this process (set in main before HIP starts)
         else if (k == "--no-rccl") a.no_rccl = true;            // diagnosis only: single rank without a communicator
         else throw std::runtime_error("unknown argument " + k);
@@ -178,6 +180,7 @@ int main(int argc, char** argv) {
         opt.host_fed = hostfed;
         opt.pipelines = a.pipelines;
         opt.compact_points = hostfed && a.compact != 0;
+        opt.yielding_side_streams = a.side_priority.empty() ? (hostfed && !std::getenv("VSLAM_SIDE_PRIORITY")) : a.side_priority == "low";
         opt.tune_side_streams = !a.no_tuner;  // this host opts in: the library compares three pairs of side streams during the warm-up
         opt.localize = a.lists != "candidates", opt.orient = a.lists == "orient" || a.lists == "describe", opt.describe = a.lists == "describe";
         if (a.octaves != 4) {

@@ -97,6 +97,7 @@ void BatchDetector::init(const Options& opt) {
         pp.stream = cs;
         rc = vslam_ctx_create(opt.device, cs, &pp.ctx);
         if (rc != VSLAM_OK) throw Error(rc, std::string("vslam_ctx_create: ") + vslam_status_string(rc) + " (no usable HIP device: there is no CPU fallback)");
+        if (opt.yielding_side_streams || opt.tune_side_streams) (void)vslam_ctx_set_side_stream_priority(pp.ctx, 1);  // (the tuner compares low-priority pairs)
         (void)vslam_ctx_tune_side_streams(pp.ctx, opt.tune_side_streams ? 1 : 0);
     }
     if (opt.host_fed) {

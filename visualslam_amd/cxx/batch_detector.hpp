@@ -81,7 +81,11 @@ public:
         bool custom_params = false;      // false: vslam_params_default(rows, cols)
         vslam_params params{};
         int slots = 3;                   // host-fed batches in flight (>= 1); device buffers of frames + lists per slot
-        bool tune_side_streams = false;  // vslam_ctx_tune_side_streams on every pipeline's context (include/vslam.h; Stream sets it)
+        bool tune_side_streams = false;  // vslam_ctx_tune_side_streams on every pipeline's context (include/vslam.h; Stream --tuner)
+        // vslam_ctx_set_side_stream_priority(ctx, 1): the library's side streams at the lowest priority (they yield to the octave
+        // kernels).  For a host that controls its hardware-queue layout (GPU_MAX_HW_QUEUES >= the streams of the process): +2-3 %;
+        // on an unlucky layout -18 %, which is why the library's default is the main stream's priority
+        bool yielding_side_streams = false;
         // Batches whose KERNELS may run at the same time (1..4).  Each pipeline is a context + compute stream + set of
         // image buffers (response, mask, pyramid, bitmask: 33 GB for 256 x 1080p) of its own; consecutive batches
         // alternate between them, each starting once its predecessor is past octave 0 (vslam_ctx_follow), so that the

@@ -143,6 +143,18 @@ void GaussPyramid::build(Mat& img, int numOctaves, double sigma) {
     check(vslam_pyramid_get_info(pyr_, &info_), c, "GaussPyramid info");
     for (int o = 0; o < info_.n_octaves; ++o)
         sigmas_[o] = std::vector<double>(info_.sigma[o], info_.sigma[o] + info_.n_levels);
+    if (eagerGradients())  // processGradients for every octave now, as GaussPyramid.cpp:118 does
+        for (int kind = 0; kind < 4; ++kind) (void)allGrads(kind);
+}
+
+namespace {
+int g_eager_gradients = -1;  // -1: not set, follow the environment
+}
+void GaussPyramid::setEagerGradients(bool on) { g_eager_gradients = on ? 1 : 0; }
+bool GaussPyramid::eagerGradients() {
+    if (g_eager_gradients >= 0) return g_eager_gradients != 0;
+    const char* e = std::getenv("VSLAM_EAGER_GRADIENTS");
+    return e && e[0] == '1';
 }
 
 void GaussPyramid::checkOctave(int octave) const {

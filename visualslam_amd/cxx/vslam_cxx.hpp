@@ -121,6 +121,12 @@ public:
     const std::map<int, std::vector<cv::Mat>>& pyramidGradOrient() { return allGrads(3); }
     static std::vector<cv::Mat> padOctave(int padding, const std::vector<cv::Mat>& images);
     const vslam_pyramid* handle() const { return pyr_; }  // the HBM-resident pyramid
+    // The reference runs processGradients INSIDE the constructor (GaussPyramid.cpp:118): every level's gradX / gradY /
+    // magnitude / orientation exist when it returns.  Here they are formed on first access (same values through the same
+    // getters; 96 bytes per pyramid pixel saved for callers that never ask).  A caller that wants the reference's timing -
+    // all the work in the constructor, getters free - switches this on before constructing (or sets VSLAM_EAGER_GRADIENTS=1).
+    static void setEagerGradients(bool on);
+    static bool eagerGradients();
 
 private:
     void build(cv::Mat& img, int numOctaves, double sigma);
