@@ -1,6 +1,8 @@
 """One-off randomized parity soak of the batched path (not part of the test suite).
 
-    [VSLAM_MX=1] python tools/soak_batch.py <seed> <seconds> [big]
+    [VSLAM_MX=1] python tools/soak_batch.py <seed> <seconds> [big|deep]
+`deep` (round 5): 1..6 octaves whatever the frame size (the reference's constructor takes any count) - octaves 4 and 5 run
+kernels of hundreds of taps on images of a few pixels (strip kernels up to 2047 taps, repeated BORDER_REFLECT_101).
 `big`: frames up to 400 x 700 in batches of 1-9 (octave 0 up to 800 x 1400: several seams and straddling lattice rows of the
 matrix path's fused scan per frame); with VSLAM_MX=1 the whole sweep runs on the opt-in matrix path."""
 import os, sys, time
@@ -16,7 +18,10 @@ while time.time() - t0 < (float(sys.argv[2]) if len(sys.argv) > 2 else 120):
     big = len(sys.argv) > 3 and sys.argv[3] == "big"
     rows, cols = (int(rng.integers(17, 400)), int(rng.integers(17, 700))) if big else (int(rng.integers(17, 140)), int(rng.integers(17, 200)))
     n = int(rng.choice([1, 2, 3, 9])) if big else int(rng.choice([1, 2, 5, 31, 32, 33, 63, 64, 65, 90]))
-    n_oct = int(rng.integers(1, max(1, min(4, capi.auto_num_octaves(rows, cols))) + 1))
+    deep = len(sys.argv) > 3 and sys.argv[3] == "deep"
+    n_oct = int(rng.integers(1, 7)) if deep else int(rng.integers(1, max(1, min(4, capi.auto_num_octaves(rows, cols))) + 1))
+    if deep:  # (the batches stay small: the oracle's 977-tap blurs are what takes the time)
+        n = int(rng.choice([1, 2, 5, 33]))
     mode = int(rng.integers(0, 3))
     kinds = ["checker", "noise"]
     frames = np.stack([synth.frame_np(rows, cols, f, int(rng.integers(0, 50)), kinds[int(rng.integers(0, 2))]) for f in range(n)])
@@ -34,6 +39,10 @@ while time.time() - t0 < (float(sys.argv[2]) if len(sys.argv) > 2 else 120):
         assert (off.cpu().numpy() == np.concatenate([[0], np.cumsum(m)])).all()
         want = np.concatenate([out["dog_points"][f][: m[f]] for f in range(n)])
         assert (packed.cpu().numpy()[: len(want)] == want).all()
+        p16 = torch.zeros((int(m.sum()) + 1, 4), dtype=torch.int32, device=dev)  # the 16-byte form and its host-side inverse (round 5)
+        ctx.pack_points16(lists, counts, p16, off)
+        torch.cuda.synchronize()
+        assert capi.points16_expand(p16.cpu().numpy()[: len(want)]).tobytes() == np.ascontiguousarray(want).astype(np.int32).tobytes()
     if it % 5 == 0 and mode == 0:  # the dense 3x3x3 extension in the batch, two frames against the oracle
         import oracle
         pd = capi.default_params(rows, cols, n_octaves=n_oct, extrema_dense=1, dog_cap=1 << 17)
