@@ -2292,16 +2292,18 @@ int vslam_detect_batch_dev(vslam_ctx* c, const vslam_params* pp, const uint8_t* 
         return !(e && e[0] == '0');
     }();
     // Under stream capture (hipGraph) no two SIDE streams of the call may wait on each other's events.  The topology is legal
-    // (fork from the origin stream, cross-dependencies between the forked streams, all joined back), but this HIP runtime
-    // (libamdhip64 of ROCm 7.0, the copy torch 2.10 bundles) books every hipStreamWaitEvent of a non-origin stream on a captured
-    // event as "this stream becomes a capture child of the event's stream": side stream B waiting on A's event and, later, A
-    // waiting on B's leaves A in B's child list and B in A's, and hipStreamEndCapture walks the child lists recursively -
-    // for ever.  The process dies of stack exhaustion inside libamdhip64.so (tools/graph_try.py reproduces it in a child
-    // process: SIGSEGV, 64 of 64 backtrace frames at libamdhip64.so+0x2d34a8, a function that calls itself for every entry
-    // of the vector at this+0x2e0 after clearing the list at this+0x308; profiles/r05_graph_try.json).  The orientation stage
-    // has two such pairs - the early edge test (list stream -> Harris stream -> back) and the spread launches (list stream
-    // -> two idle side streams -> back); each alone reproduces the crash.  While a capture is on, both stay on the list
-    // stream; everything else forks from and joins to the main (origin) stream, which the runtime never files as a child.
+    // (fork from the origin stream, cross edges between the forked streams, all joined back) and every event is recorded on
+    // a stream that is already part of the capture; but this HIP runtime (ROCm 7.2's libamdhip64.so.7 and the copy torch 2.10
+    // bundles alike) never returns from hipStreamEndCapture then: a function that calls itself for every entry of a
+    // per-stream vector (the shape of hip::Stream::EndCapture over parallelCaptureStreams_) recurses 174,000 frames deep and
+    // the process dies of stack exhaustion - no HIP status is ever seen.  tools/graph_try.py reproduces it through this
+    // library (each case in a child process; both ends of the stack in profiles/r05_graph_try.json), and
+    // tools/capture_cycle_repro.hip WITHOUT it: two side streams that wait on each other's events are harmless by themselves
+    // (modes 2-4) and fatal as soon as each also waits on an origin-stream event again in between (mode 5) - which this
+    // library's side streams do on every octave's event.  The orientation stage has two such pairs - the early edge test
+    // (list stream -> Harris stream -> back) and the spread launches (list stream -> two idle side streams -> back); each
+    // alone reproduces the crash.  While a capture is on, both stay on the list stream; everything else forks from and joins
+    // to the main (origin) stream.
     bool capturing = false, cap_early = false, cap_spread = false;  // the nested forks stay out of a capture
     {
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
