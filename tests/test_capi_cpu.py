@@ -133,6 +133,31 @@ def test_batch_out_required_sizes(lib):
     assert fields == want
 
 
+def test_points16_expand_is_the_inverse_of_the_device_packing(lib):
+    # vslam_points16_expand (host, no GPU): the 16-byte record {row, col, value, level | octave << 8 | padding << 16} back to
+    # SLAM::point - every field combination the detector writes (padding 0 / 1, octave < VSLAM_MAX_OCTAVES, level < 6), extreme
+    # coordinates and values, and the record layout itself (tests/test_gpu_batch.py::test_pack_points16 checks the device side)
+    import ctypes as C
+
+    rng = np.random.default_rng(3)
+    n = 4096
+    pts = np.zeros(n, capi.POINT_DTYPE)
+    pts["row"] = rng.integers(-(1 << 31), (1 << 31) - 1, n)
+    pts["col"] = rng.integers(-(1 << 31), (1 << 31) - 1, n)
+    pts["value"] = rng.integers(-(1 << 31), (1 << 31) - 1, n)
+    pts["padding"] = rng.integers(0, 2, n)
+    pts["octave"] = rng.integers(0, 10, n)
+    pts["level"] = rng.integers(0, 6, n)
+    packed = np.zeros((n, 4), np.uint32)
+    packed[:, 0] = pts["row"].view(np.uint32)
+    packed[:, 1] = pts["col"].view(np.uint32)
+    packed[:, 2] = pts["value"].view(np.uint32)
+    packed[:, 3] = pts["level"].astype(np.uint32) | (pts["octave"].astype(np.uint32) << 8) | (pts["padding"].astype(np.uint32) << 16)
+    assert capi.points16_expand(packed).tobytes() == pts.tobytes()
+    assert capi.points16_expand(np.zeros((0, 4), np.uint32)).shape == (0,)
+    lib.vslam_points16_expand(None, 5, None)  # null arguments: nothing happens
+
+
 def test_dense_mode_layout(lib):
     # extension: the dense 3x3x3 scan's bitmask has one site per pixel of levels 1..3
     p = capi.default_params(1080, 1920, extrema_dense=1)

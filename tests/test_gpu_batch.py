@@ -674,6 +674,8 @@ def test_join_watchdog_levels_give_the_same_results_and_the_watch_ends():
                             break
                     lv, done, lag = ctx.join_watch_report()
                     assert done and lv in (0, 1, 2) and 0.0 <= lag < 1.0, (lv, done, lag)
+                    with pytest.raises(capi.VslamError):  # the side streams exist: their priority can no longer be chosen
+                        ctx.set_side_stream_priority(True)
                 else:
                     assert ctx.join_watch_report()[:2] == (level, True)
                     ctx.detect_batch(p, frames, **o)
