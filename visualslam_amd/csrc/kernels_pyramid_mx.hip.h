@@ -143,9 +143,41 @@ __device__ __forceinline__ void mx_stage_tile(const uint8_t* __restrict__ src, i
                 *reinterpret_cast<uint4*>(rp + yq * RWP + 16 * xs + 4 * q) = t;
             }
         }
+    } else if (cols >= 4 && R < cols && tile_x0 + TW + R - 1 <= 2 * (cols - 1) && R < rows && tile_y0 + TH + R - 1 <= 2 * (rows - 1)) {
+        // Border tiles whose halo reaches at most ONE reflection on either side (every tile of the coarse octaves at camera
+        // sizes: 30 of 40 tiles of a 960 x 540 octave, all of a 480 x 270 one).  Round 5: branch-free.  Four pixels at columns
+        // x .. x+3 under BORDER_REFLECT_101 always lie within four consecutive bytes of the row - a forward run, a mirrored
+        // run, or a run folded around column 0 / cols-1 - so every case is ONE unaligned dword load at `base` and one v_perm
+        // whose selector holds the four byte positions relative to base.  No divergent paths: the four row loads of an item
+        // issue back to back and two items are in flight per thread (the loop is unrolled by two).  These kernels run with
+        // one workgroup per CU beside the HBM-bound Harris chain and are bound by the latency of exactly these loads.
+        auto f1 = [](int x, int n) { return x < 0 ? -x : (x >= n ? 2 * (n - 1) - x : x); };
+#pragma unroll 2
+        for (int it = tid; it < RQ * (RW / 4); it += NT) {
+            const int yq = it / (RW / 4), xq = it - yq * (RW / 4);
+            const int gy = tile_y0 - R + 4 * yq, gx = tile_x0 - R + 4 * xq;
+            const int p0 = f1(gx, cols), p1 = f1(gx + 1, cols), p2 = f1(gx + 2, cols), p3 = f1(gx + 3, cols);
+            const int base = min(min(min(p0, p1), min(p2, p3)), cols - 4);
+            const uint32_t sel = (uint32_t)(p0 - base) | ((uint32_t)(p1 - base) << 8) | ((uint32_t)(p2 - base) << 16) | ((uint32_t)(p3 - base) << 24);
+            uint32_t a[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                uint32_t v;
+                __builtin_memcpy(&v, src + (size_t)f1(gy + k, rows) * pitch + base, 4);
+                a[k] = __builtin_amdgcn_perm(0u, v, sel);
+            }
+            const uint32_t p01l = __builtin_amdgcn_perm(a[1], a[0], 0x05010400), p01h = __builtin_amdgcn_perm(a[1], a[0], 0x07030602);
+            const uint32_t p23l = __builtin_amdgcn_perm(a[3], a[2], 0x05010400), p23h = __builtin_amdgcn_perm(a[3], a[2], 0x07030602);
+            uint4 t;
+            t.x = __builtin_amdgcn_perm(p23l, p01l, 0x05040100) ^ bias;
+            t.y = __builtin_amdgcn_perm(p23l, p01l, 0x07060302) ^ bias;
+            t.z = __builtin_amdgcn_perm(p23h, p01h, 0x05040100) ^ bias;
+            t.w = __builtin_amdgcn_perm(p23h, p01h, 0x07060302) ^ bias;
+            *reinterpret_cast<uint4*>(rp + yq * RWP + 4 * xq) = t;
+        }
     } else {
-        // border tiles (most tiles of the coarse octaves): one dword column (4 pixels) x 4 rows per item, rows reflected per
-        // row, columns per dword (mx_load4_reflect)
+        // tiny images (a halo wider than the image: repeated reflection): one dword column (4 pixels) x 4 rows per item, rows
+        // reflected per row, columns per dword (mx_load4_reflect)
         for (int it = tid; it < RQ * (RW / 4); it += NT) {
             const int yq = it / (RW / 4), xq = it - yq * (RW / 4);
             const int gy = tile_y0 - R + 4 * yq, gx = tile_x0 - R + 4 * xq;
