@@ -1067,7 +1067,12 @@ static int enqueue_dog(vslam_ctx* c, const vslam_params& p, const vslam_batch_la
         // tile shape: the wide tile (256 x 32) when it needs no more tile area than the tall one (128 x 64).
         // A 384 x 32 tile (1920 = 5 x 384) on 384-thread workgroups was measured in round 3: six waves per
         // workgroup sit 2-2-1-1 on the four SIMDs and meet at every barrier: 21.3 vs 18.3 ms per step.
-        const int shape = (long)((cols + 255) / 256) * ((rows + 31) / 32) <= (long)((cols + 127) / 128) * ((rows + 63) / 64) ? 1 : 0;
+        static const int force_shape = [] {
+            const char* e = std::getenv("VSLAM_TILE_SHAPE");  // A/B runs: 0 = 128 x 64 everywhere, 1 = 256 x 32 everywhere
+            return e ? std::atoi(e) : -1;
+        }();
+        const int shape = force_shape >= 0 ? (force_shape ? 1 : 0)
+                                           : ((long)((cols + 255) / 256) * ((rows + 31) / 32) <= (long)((cols + 127) / 128) * ((rows + 63) / 64) ? 1 : 0);
         // matrix path: the plain lattice scan (window 3, candidates + contrast list) runs inside the octave kernel
         // while the DoG rows are in LDS (kernels_pyramid_mx.hip.h); k_extrema_pack then replaces k_extrema_w3
         MxScan scan{};
