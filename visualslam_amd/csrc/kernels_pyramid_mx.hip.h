@@ -149,10 +149,10 @@ __device__ __forceinline__ void mx_stage_tile(const uint8_t* __restrict__ src, i
         // x .. x+3 under BORDER_REFLECT_101 always lie within four consecutive bytes of the row - a forward run, a mirrored
         // run, or a run folded around column 0 / cols-1 - so every case is ONE unaligned dword load at `base` and one v_perm
         // whose selector holds the four byte positions relative to base.  No divergent paths: the four row loads of an item
-        // issue back to back and two items are in flight per thread (the loop is unrolled by two).  These kernels run with
+        // issue back to back and four items are in flight per thread (the loop is unrolled by four).  These kernels run with
         // one workgroup per CU beside the HBM-bound Harris chain and are bound by the latency of exactly these loads.
         auto f1 = [](int x, int n) { return x < 0 ? -x : (x >= n ? 2 * (n - 1) - x : x); };
-#pragma unroll 2
+#pragma unroll 4
         for (int it = tid; it < RQ * (RW / 4); it += NT) {
             const int yq = it / (RW / 4), xq = it - yq * (RW / 4);
             const int gy = tile_y0 - R + 4 * yq, gx = tile_x0 - R + 4 * xq;
