@@ -13,6 +13,6 @@ import sys,json
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k={}
 for e in d['roofline_by_kernel']: k[(e['kernel'],e['octave'])]=round(e['ms_per_step'],3)
 kn='k_pyr_octave_mx' if d['config']['matrix_path'] else 'k_pyr_octave'
-print('$label', 'value', round(d['value'],1), 'ms', round(d['ms_per_step'],3), 'oct', [k.get((kn,o)) for o in range(4) if (kn,o) in k], 'harris', k.get(('k_harris_strip',None)))"
+print('$label', 'strips', [k.get(('k_gauss_h_strip',o)) for o in (2,3)], 'value', round(d['value'],1), 'ms', round(d['ms_per_step'],3), 'oct', [k.get((kn,o)) for o in range(4) if (kn,o) in k], 'harris', k.get(('k_harris_strip',None)))"
   done < $spec
 done

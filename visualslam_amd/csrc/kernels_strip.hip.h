@@ -192,13 +192,16 @@ __global__ __launch_bounds__(256) void k_gauss_h_strip(const uint16_t* __restric
     const size_t P = (size_t)rows * pitch;
     uint8_t* out = oct_out + blockIdx.z * pframe;
     const int ncg = (cols + 7) >> 3, items = ncg * (SH / RI);
-    uint32_t prev_e[2][RI][2], prev_o[2][RI][2];
+    // items per thread: two of 8 columns x 4 rows, or four of fewer rows (the row count per item is chosen on the host so that the
+    // items fill whole waves: 960 columns x 16 rows are 480 items of 4 rows = 7.5 waves, but 960 items of 2 rows = 15)
+    constexpr int NI = RI == 4 ? 2 : 4;
+    uint32_t prev_e[NI][RI][2], prev_o[NI][RI][2];
     // this thread's (at most two) items and the plane offset of each item's first row: the same for every
     // level, so the division and the multiply are done once (a dozen instructions saved per level)
-    int item_cg[2], item_rg[2];
-    uint32_t item_off[2];
+    int item_cg[NI], item_rg[NI];
+    uint32_t item_off[NI];
 #pragma unroll
-    for (int ii = 0; ii < 2; ++ii) {
+    for (int ii = 0; ii < NI; ++ii) {
         const int it = tid + ii * 256;
         item_cg[ii] = it % ncg, item_rg[ii] = it / ncg;
         item_off[ii] = (uint32_t)(y0 + RI * item_rg[ii]) * (uint32_t)pitch + (uint32_t)(8 * item_cg[ii]);
@@ -235,7 +238,7 @@ __global__ __launch_bounds__(256) void k_gauss_h_strip(const uint16_t* __restric
         const int nb = (((7 + dl + 2 * r) >> 1) >> 2) + 1;
         const uint32_t* tp = &taps->hp[l][0];
 #pragma unroll
-        for (int ii = 0; ii < 2; ++ii) {
+        for (int ii = 0; ii < NI; ++ii) {
             const int it = tid + ii * 256;
             if (it < items) {
                 const int cg = item_cg[ii], rg = item_rg[ii];

@@ -696,6 +696,28 @@ static int enqueue_strip_octave(vslam_ctx* c, double sigma0, int o, const OctPla
     // ... and, when even that leaves most threads without an item, one row per item
     const bool fine = sh == 4 && (long)((rows + 3) / 4) * nf < 256 && ((cols + 7) / 8) * 4 <= 512;
     if (fine) return launch_h_strip<4, 1>(c, h, 6 * P, oct, pframe, rows, cols, pitch, pw, nf, taps, next_base, nframe, nrows, ncols, npitch);
+    if (sh == 16) {
+        // rows per item (round 5): the items of a workgroup should fill whole waves.  960 columns x 16 rows are 480 items of 8
+        // columns x 4 rows = 7.5 waves (every eighth wave-instruction wasted: the kernel runs AT its VALU issue time), but 960
+        // items of 2 rows = 15 waves; 480 columns need 1 row per item.  Fewer rows per item amortise the scalar tap loads over
+        // fewer dots, so the smaller item must be at least 2 % fuller to be chosen.  VSLAM_STRIP_RI forces a value (A/B runs).
+        const int ncg = (cols + 7) / 8;
+        auto waste = [&](int ri) {
+            const long items = (long)ncg * (16 / ri);
+            if (items > (ri == 4 ? 512 : 1024)) return 1e9;
+            return (double)((items + 63) / 64 * 64 - items) / (double)items;
+        };
+        static const int force_ri = [] {
+            const char* e = std::getenv("VSLAM_STRIP_RI");
+            return e ? std::atoi(e) : 0;
+        }();
+        int ri = 4;
+        for (int r : {2, 1})
+            if (waste(r) + 0.02 < waste(ri)) ri = r;
+        if ((force_ri == 1 || force_ri == 2 || force_ri == 4) && waste(force_ri) < 1e8) ri = force_ri;
+        if (ri == 2) return launch_h_strip<16, 2>(c, h, 6 * P, oct, pframe, rows, cols, pitch, pw, nf, taps, next_base, nframe, nrows, ncols, npitch);
+        if (ri == 1) return launch_h_strip<16, 1>(c, h, 6 * P, oct, pframe, rows, cols, pitch, pw, nf, taps, next_base, nframe, nrows, ncols, npitch);
+    }
     switch (sh) {
         case 16: return launch_h_strip<16, 4>(c, h, 6 * P, oct, pframe, rows, cols, pitch, pw, nf, taps, next_base, nframe, nrows, ncols, npitch);
         case 8: return launch_h_strip<8, 4>(c, h, 6 * P, oct, pframe, rows, cols, pitch, pw, nf, taps, next_base, nframe, nrows, ncols, npitch);
