@@ -901,6 +901,22 @@ def test_matrix_path_two_chunks_of_1080p_frames(env):
         assert a["dog_points"][f][:m].cpu().numpy().view(capi.POINT_DTYPE).reshape(-1).tobytes() == allp[:m].tobytes(), f
 
 
+@pytest.mark.parametrize("shape,n_oct,mode", [((40, 56), 6, "candidates"), ((75, 131), 5, "localized"), ((17, 200), 6, "candidates"), ((96, 160), 6, "oriented")])
+def test_batch_deep_octaves_on_small_frames(env, path, shape, n_oct, mode):
+    # the reference's constructor takes ANY octave count, and sigma doubles per octave while the image halves:
+    # octave 4 / 5 of these frames are a few pixels across with kernels of 155 .. 977 taps - the strip kernels' wide-kernel
+    # reach (2047 taps since round 5; the generic one-thread-per-pixel kernels before) with BORDER_REFLECT_101 folded many
+    # times over.  Every plane, mask and list of every octave against the oracle, both kernel families.
+    ctx, torch = env
+    rows, cols = shape
+    frames = synth.frames_np(3, rows, cols, stream_id=rows + cols)
+    frames[1] = synth.frame_np(rows, cols, kind="noise")
+    p, L, out = run_batch(ctx, torch, frames, n_octaves=n_oct, localize=int(mode != "candidates"), orient=int(mode == "oriented"))
+    assert L.rows[n_oct - 1] >= 1 and L.cols[n_oct - 1] >= 1
+    for f in range(3):
+        check_frame(p, L, out, f, frames[f], n_oct)
+
+
 def test_batch_random_shapes(env, path):
     # seeded sweep over frame sizes (multiples of 4/8/16 and ragged ones) through every dispatch
     # path of the batch: specialised and generic kernels must agree with the oracle everywhere
