@@ -712,6 +712,7 @@ __global__ __launch_bounds__(CFG::NT) void k_pyr_octave_mx(const uint8_t* __rest
 //     here from the seam map, the two DoG columns the strips on either side left for every level (MxExtArgs::colmap).
 // grid = (ceil(8 wpr / 256), ceil(lat_rows / MX_PACK_ROWS), frames), block 256.
 constexpr int MX_PACK_ROWS = 8;
+#ifndef VSLAM_MX_OCT0_TU  // (a plain, non-template kernel: defined in one translation unit)
 __global__ __launch_bounds__(256) void k_extrema_pack(const uint8_t* __restrict__ sitemap, size_t mframe, int mpitch, const uint8_t* __restrict__ colmap,
                                                       size_t cframe, int nseams, int rows, int lat_rows, int lat_cols, int wpr, int sh, int sw,
                                                       int min_contrast, unsigned long long* __restrict__ bits, unsigned long long* __restrict__ lflags,
@@ -783,6 +784,8 @@ __global__ __launch_bounds__(256) void k_extrema_pack(const uint8_t* __restrict_
         }
     }
 }
+
+#endif  // !VSLAM_MX_OCT0_TU
 
 // Host side: the quantised taps as MFMA operand fragments.
 //   b1[l][s][lane] byte j: pass-1 B[k][y'] with y' = lane & 31 the output row and k = 16 (lane >> 5) + j the input row

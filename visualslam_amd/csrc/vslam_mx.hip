@@ -11,6 +11,15 @@
 
 namespace vslam {
 
+// Octave 0's kernel (configuration 1: fused x2 upsample + lattice scan) is compiled in a translation unit of its own
+// (vslam_mx0.hip = this file with VSLAM_MX_OCT0_TU defined) under -amdgpu-sched-strategy=max-ilp: same box, four
+// alternations, that scheduling takes octave 0 from 6.8-7.1 to 6.4-6.6 ms per 256-frame step and costs the other three
+// configurations 4-5 % (profiles/r05_mx_maxilp_ab.txt) - so only octave 0 gets it.
+hipError_t mx_prepare_oct0();
+hipError_t mx_launch_oct0(hipStream_t stream, const void* d_table, const uint8_t* base, size_t bframe, uint8_t* oct_out, size_t pframe, int rows,
+                          int cols, int pitch, int nf, uint8_t* next_base, size_t nframe, int nrows, int ncols, int npitch, const MxScan* scan, int up2_step);
+
+#ifndef VSLAM_MX_OCT0_TU
 template <class CFG>
 static bool widths_match(const int ke[6]) {
     for (int l = 0; l < 6; ++l)
@@ -41,13 +50,15 @@ bool mx_pack(int cfg, const uint16_t* const taps[6], void* host_table) {
 bool mx_scan_supported(int cfg) { return cfg == 1 || cfg == 2; }  // the configurations with a D buffer in LDS (MxCfg::DBUF)
 bool mx_up2_supported(int cfg) { return cfg == 1; }                // the reference's pyramid upsamples in front of octave 0 only
 
+#endif  // !VSLAM_MX_OCT0_TU
+
 template <class CFG>
 static hipError_t prepare() {
     if (CFG::DBUF) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pyr_octave_mx<CFG, CFG::DBUF != 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES);
         if (e != hipSuccess) return e;
     }
-    if (std::is_same<CFG, MxCfgOct0>::value) {
+    if constexpr (std::is_same<CFG, MxCfgOct0>::value) {  // (constexpr: the other configurations' instantiations must not pull octave 0's kernels into their translation unit)
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pyr_octave_mx<MxCfgOct0, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pyr_octave_mx<MxCfgOct0, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES);
         if (e != hipSuccess) return e;
@@ -55,10 +66,13 @@ static hipError_t prepare() {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pyr_octave_mx<CFG, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES);
 }
 
+#ifdef VSLAM_MX_OCT0_TU
+hipError_t mx_prepare_oct0() { return prepare<MxCfgOct0>(); }
+#else
 hipError_t mx_prepare(int cfg) {
-
-    return cfg == 1 ? prepare<MxCfgOct0>() : cfg == 2 ? prepare<MxCfgOct1>() : cfg == 3 ? prepare<MxCfgOct2>() : cfg == 4 ? prepare<MxCfgOct3>() : hipErrorInvalidValue;
+    return cfg == 1 ? mx_prepare_oct0() : cfg == 2 ? prepare<MxCfgOct1>() : cfg == 3 ? prepare<MxCfgOct2>() : cfg == 4 ? prepare<MxCfgOct3>() : hipErrorInvalidValue;
 }
+#endif
 
 template <class CFG>
 static hipError_t launch(hipStream_t stream, const void* d_table, const uint8_t* base, size_t bframe, uint8_t* oct_out, size_t pframe, int rows,
@@ -66,7 +80,10 @@ static hipError_t launch(hipStream_t stream, const void* d_table, const uint8_t*
     const dim3 grid((cols + CFG::TW - 1) / CFG::TW, (rows + CFG::TH - 1) / CFG::TH, nf);
     MxExtArgs ext{};
     if (up2_step > 0) {
-        if (!std::is_same<CFG, MxCfgOct0>::value || (rows & 1) || (cols & 1)) return hipErrorInvalidValue;
+      if constexpr (!std::is_same<CFG, MxCfgOct0>::value) {
+        return hipErrorInvalidValue;
+      } else {
+        if ((rows & 1) || (cols & 1)) return hipErrorInvalidValue;
         if (scan) {
             ext = MxExtArgs{scan->sitemap, scan->mframe, scan->lat_rows, scan->lat_cols, scan->mpitch, scan->min_contrast, scan->colmap, scan->cframe, scan->nseams};
             hipLaunchKernelGGL((k_pyr_octave_mx<MxCfgOct0, true, true>), grid, dim3(CFG::NT), CFG::LDS_BYTES, stream, base, bframe, oct_out, pframe, rows, cols, pitch,
@@ -76,6 +93,7 @@ static hipError_t launch(hipStream_t stream, const void* d_table, const uint8_t*
                                static_cast<const MxTaps<MxCfgOct0>*>(d_table), next_base, nframe, nrows, ncols, npitch, ext, up2_step);
         }
         return hipGetLastError();
+      }
     }
     if (scan && CFG::DBUF) {
         ext = MxExtArgs{scan->sitemap, scan->mframe, scan->lat_rows, scan->lat_cols, scan->mpitch, scan->min_contrast, scan->colmap, scan->cframe, scan->nseams};
@@ -89,6 +107,12 @@ static hipError_t launch(hipStream_t stream, const void* d_table, const uint8_t*
     return hipGetLastError();
 }
 
+#ifdef VSLAM_MX_OCT0_TU
+hipError_t mx_launch_oct0(hipStream_t stream, const void* d_table, const uint8_t* base, size_t bframe, uint8_t* oct_out, size_t pframe, int rows,
+                          int cols, int pitch, int nf, uint8_t* next_base, size_t nframe, int nrows, int ncols, int npitch, const MxScan* scan, int up2_step) {
+    return launch<MxCfgOct0>(stream, d_table, base, bframe, oct_out, pframe, rows, cols, pitch, nf, next_base, nframe, nrows, ncols, npitch, scan, up2_step);
+}
+#else
 hipError_t mx_launch_pack(hipStream_t stream, const MxScan& scan, int rows, int wpr, int nf, unsigned long long* bits, unsigned long long* lflags,
                           size_t bframe) {
     // strips of 32 rows x 128 columns in every configuration with a fused scan (MxCfgOct0 / MxCfgOct1)
@@ -101,11 +125,12 @@ hipError_t mx_launch_pack(hipStream_t stream, const MxScan& scan, int rows, int 
 
 hipError_t mx_launch(int cfg, hipStream_t stream, const void* d_table, const uint8_t* base, size_t bframe, uint8_t* oct_out, size_t pframe,
                      int rows, int cols, int pitch, int nf, uint8_t* next_base, size_t nframe, int nrows, int ncols, int npitch, const MxScan* scan, int up2_step) {
-    if (cfg == 1) return launch<MxCfgOct0>(stream, d_table, base, bframe, oct_out, pframe, rows, cols, pitch, nf, next_base, nframe, nrows, ncols, npitch, scan, up2_step);
+    if (cfg == 1) return mx_launch_oct0(stream, d_table, base, bframe, oct_out, pframe, rows, cols, pitch, nf, next_base, nframe, nrows, ncols, npitch, scan, up2_step);
     if (cfg == 2) return launch<MxCfgOct1>(stream, d_table, base, bframe, oct_out, pframe, rows, cols, pitch, nf, next_base, nframe, nrows, ncols, npitch, scan, up2_step);
     if (cfg == 3) return launch<MxCfgOct2>(stream, d_table, base, bframe, oct_out, pframe, rows, cols, pitch, nf, next_base, nframe, nrows, ncols, npitch, scan, up2_step);
     if (cfg == 4) return launch<MxCfgOct3>(stream, d_table, base, bframe, oct_out, pframe, rows, cols, pitch, nf, next_base, nframe, nrows, ncols, npitch, scan, up2_step);
     return hipErrorInvalidValue;
 }
+#endif  // VSLAM_MX_OCT0_TU
 
 }  // namespace vslam
