@@ -161,7 +161,7 @@ def _rank_env(rank, world, port):
     return dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])  # 8 = the ranks of BASELINE config 5 (one node)
 def test_stream_rendezvous_of_the_rccl_id_without_a_gpu(built, world):
     # the N > 1 bootstrap of the RCCL communicator (rank 0's ncclUniqueId over TCP to every rank) on its own:
     # `world` processes on the CPU, every rank must end up with rank 0's 128 bytes
