@@ -82,6 +82,8 @@ struct JoinWatch {
     float level_best[3] = {0.0f, 0.0f, 0.0f};  // fastest measured call at each level tried
     int level = 1;              // 0: low-priority (yielding) side streams, 1: the main stream's priority, 2: no side streams
     int trial_from = -1;        // the level a running trial came from (-1: the current level is not a trial)
+    unsigned long long key = 0; // shape of the calls being measured (only calls of one shape are compared)
+    int restarts = 0;
     bool done = false, disabled = false, pinned = false;
     float last_lag_frac = -1.0f;
     hipStream_t pair[2][2] = {};  // the side-stream pairs of levels 0 and 1 (both live until the context goes)
@@ -347,10 +349,22 @@ static int watch_set_level(vslam_ctx* c, int level) {
     return VSLAM_OK;
 }
 
-static int watch_before_call(vslam_ctx* c, bool eligible, bool capturing) {
+static int watch_before_call(vslam_ctx* c, unsigned long long key, bool eligible, bool capturing) {
     JoinWatch& w = c->watch;
     w.recording = -1;
     if (w.done || w.disabled || capturing || (c->tuner.enabled && !c->tuner.done)) return VSLAM_OK;
+    if (eligible && key != w.key) {  // calls of another shape: their times say nothing about the ones measured so far
+        for (bool& l : w.live) l = false;
+        w.calls = w.n_meas = 0;
+        w.best_total = 0.0f;
+        if (w.trial_from >= 0 && ++w.restarts > 3) {  // a caller whose shape keeps changing under a trial: end it where it started
+            TRY(watch_set_level(c, w.trial_from));
+            w.trial_from = -1;
+            w.done = true;
+            return VSLAM_OK;
+        }
+        w.key = key;
+    }
     if (w.level <= 1 && !w.pair[w.level][0]) w.pair[w.level][0] = c->aux[0], w.pair[w.level][1] = c->aux[1];
     for (int i = 0; i < JoinWatch::RING; ++i) {
         if (!w.live[i]) continue;
@@ -2358,19 +2372,20 @@ int vslam_detect_batch_dev(vslam_ctx* c, const vslam_params* pp, const uint8_t* 
             (void)hipStreamSynchronize(c->stream);
         }
     } guard{c};
+    // the shape of this call (the stream tuner and the join watchdog compare calls of one shape only)
+    const unsigned long long call_key = ((unsigned long long)(unsigned)n_frames << 40) ^ ((unsigned long long)(unsigned)p.rows << 20) ^ (unsigned)p.cols ^
+                                        ((unsigned long long)(p.localize + 2 * p.orient + 4 * p.extrema_dense + 8 * (out->descriptors != nullptr)) << 60) ^
+                                        ((unsigned long long)(unsigned)p.n_octaves << 56) ^ ((unsigned long long)(c->mx ? 1 : 0) << 39);
     bool side_streams = use_aux;
     if (use_aux) {
         TRY(ensure_aux(c));
         // (calls of a few megapixels are dominated by launch latencies: their lag says nothing about starvation)
-        TRY(watch_before_call(c, dog && harris && n_frames >= 32 && (size_t)n_frames * N >= ((size_t)16 << 20), capturing));
+        TRY(watch_before_call(c, call_key, dog && harris && n_frames >= 32 && (size_t)n_frames * N >= ((size_t)16 << 20), capturing));
         if (c->watch.level == 2) side_streams = false;  // the watchdog's last step: everything on the caller's stream
     }
     if (side_streams) {
         // the side-stream pair of this call (StreamTuner): only full-size batches with both paths are compared
-        const unsigned long long key = ((unsigned long long)(unsigned)n_frames << 40) ^ ((unsigned long long)(unsigned)p.rows << 20) ^ (unsigned)p.cols ^
-                                       ((unsigned long long)(p.localize + 2 * p.orient + 4 * p.extrema_dense + 8 * (out->descriptors != nullptr)) << 60) ^
-                                       ((unsigned long long)(unsigned)p.n_octaves << 56);
-        TRY(tuner_before_call(c, key, dog && harris && n_frames >= 32));
+        TRY(tuner_before_call(c, call_key, dog && harris && n_frames >= 32));
         HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
         for (int i = 0; i < vslam_ctx::kAux; ++i) HIPCHK(c, hipStreamWaitEvent(c->aux[i], c->ev_fork, 0));
         sh = c->aux[0];
