@@ -71,7 +71,7 @@ VARIANTS["stagger_hi2"] = stagger("j >= 32 && j < 64", 2)
 VARIANTS["stagger_hi4"] = stagger("j >= 32 && j < 64", 4)
 VARIANTS["stagger_odd3"] = stagger("j < 64 && (j & 1)", 3)
 VARIANTS["stagger_all_odd1"] = stagger("(j & 1)", 1)
-DEFINES = {}
+DEFINES = {}  # variant -> extra -D flags (round 5 tried MX_PREFETCH_TILES, MX_TAPS_EARLY, MX_FLUSH_WIDE; none paid, the macros are gone)
 
 
 def build(only):
@@ -92,7 +92,7 @@ def build(only):
         open(h, "w").write(s)
         o = os.path.join(d, "mx0.o")
         cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form", "-mllvm",
-               "-amdgpu-sched-strategy=max-ilp"] + (["-DMX_PREFETCH_TILES=%d" % DEFINES[name]] if name in DEFINES else []) + ["-c", "-o", o, os.path.join(d, "visualslam_amd", "csrc", "vslam_mx0.hip")]
+               "-amdgpu-sched-strategy=max-ilp"] + DEFINES.get(name, []) + ["-c", "-o", o, os.path.join(d, "visualslam_amd", "csrc", "vslam_mx0.hip")]
         subprocess.check_call(cmd)
         out = os.path.join(AB, "ko_%s.so" % name)
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, os.path.join(OBJ, "vslam_hip.o"),
