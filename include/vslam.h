@@ -483,7 +483,8 @@ int vslam_pack_lists_dev(vslam_ctx* ctx, const void* lists, size_t record_bytes,
  * what the detector writes: `padding` is 0 or 1, `octave` < VSLAM_MAX_OCTAVES, `level` < 6 - the three small fields share
  * one word, tag = level | octave << 8 | padding << 16.  vslam_points16_expand (host, pure arithmetic) is the inverse:
  * expand(pack(list)) is byte-identical to the list (tests/test_gpu_batch.py::test_pack_points16).  packed_bytes counts
- * bytes of `packed`; records that do not fit are not written, offsets are as for vslam_pack_lists_dev. */
+ * bytes of `packed`; records that do not fit are not written, offsets are as for vslam_pack_lists_dev.  `lists` 8-byte,
+ * `packed` 16-byte aligned (VSLAM_ERR_INVALID otherwise: the records move as 8- and 16-byte words). */
 typedef struct {
     int32_t row, col, value;
     uint32_t tag; /* level | octave << 8 | padding << 16 */

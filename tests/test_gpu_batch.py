@@ -482,6 +482,8 @@ def test_pack_points16(env, n, cap):
         assert got.tobytes() == np.ascontiguousarray(want).tobytes()
         if room > total:
             assert (packed[total:] == -1).all()  # nothing written beyond the records
+    with pytest.raises(capi.VslamError):  # the records move as 16-byte words: a destination 4 bytes off is refused, nothing is launched
+        ctx.pack_points16(lists, cnt, packed.view(-1)[1:], offsets)
 
 
 @pytest.mark.parametrize("localize", [0, 1])
@@ -696,6 +698,20 @@ def test_join_watchdog_levels_give_the_same_results_and_the_watch_ends():
         for f in range(n):
             assert torch.equal(res[None]["dog_points"][f, : int(cnt[f])], res[level]["dog_points"][f, : int(cnt[f])]), (level, f)
             assert torch.equal(res[None]["harris_kps"][f, : int(hcn[f])], res[level]["harris_kps"][f, : int(hcn[f])]), (level, f)
+    # (c) only calls of one shape are compared: a caller that alternates two full-size shapes never fills a window of three
+    # measurements; the watch gives up after a few restarts and stays on the default form
+    ctx = capi.Context(0, torch.cuda.current_stream().cuda_stream)
+    try:
+        o = outs()
+        for i in range(12):
+            m = n if i % 2 == 0 else n - 8
+            ctx.detect_batch(p, frames[:m], **{k: v[:m] for k, v in o.items()})
+            torch.cuda.synchronize()
+        assert ctx.join_watch_report()[:2] == (1, True)
+        for k in ("response", "harris_counts", "pyramid", "dog_counts"):
+            assert torch.equal(res[None][k][: n - 8], o[k][: n - 8]), k
+    finally:
+        ctx.close()
 
 
 def test_fast_paths_are_the_ones_that_run(env):

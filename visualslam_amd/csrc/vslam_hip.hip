@@ -357,8 +357,8 @@ static int watch_before_call(vslam_ctx* c, unsigned long long key, bool eligible
         for (bool& l : w.live) l = false;
         w.calls = w.n_meas = 0;
         w.best_total = 0.0f;
-        if (w.trial_from >= 0 && ++w.restarts > 3) {  // a caller whose shape keeps changing under a trial: end it where it started
-            TRY(watch_set_level(c, w.trial_from));
+        if (w.key != 0 && ++w.restarts > 3) {  // a caller whose shape keeps changing: stop watching (a running trial ends where it started)
+            if (w.trial_from >= 0) TRY(watch_set_level(c, w.trial_from));
             w.trial_from = -1;
             w.done = true;
             return VSLAM_OK;
@@ -2609,6 +2609,8 @@ int vslam_pack_points16_dev(vslam_ctx* c, const vslam_point* lists, uint32_t cap
     TRY(bind_device(c));
     ARGCHK(c, lists && counts && offsets && n_frames > 0 && n_frames <= 65535 && cap > 0 && (packed || packed_bytes == 0),
            "pack_points16: bad arguments (1 .. 65535 frames per call)");
+    ARGCHK(c, (reinterpret_cast<uintptr_t>(lists) & 7) == 0 && (reinterpret_cast<uintptr_t>(packed) & 15) == 0 && (reinterpret_cast<uintptr_t>(offsets) & 7) == 0,
+           "pack_points16: lists must be 8-byte aligned, packed 16-byte aligned (the records move as 8- and 16-byte words)");
     static_assert(sizeof(vslam_point) == 24 && sizeof(vslam_point16) == 16, "record layouts");
     LAUNCH(c, "k_pack_offsets", k_pack_offsets, dim3(1), dim3(256), counts, cap, n_frames, (unsigned long long*)offsets);
     const unsigned int gx = (unsigned int)std::min<unsigned long long>(((unsigned long long)cap + 1023) / 1024, 96);

@@ -14,6 +14,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <utility>
 #include <vector>
 
 #include "batch_detector.hpp"
@@ -199,6 +200,17 @@ int main(int argc, char** argv) {
                 EXPECT(fk.n_dog == doff[f + 1] - doff[f] && fk.dog == fk.dog_expanded.data());
                 EXPECT(fk.n_dog == 0 || std::memcmp(fk.dog, pt0.data() + doff[f], fk.n_dog * sizeof(vslam_point)) == 0);
                 seen += fk.n_dog;
+                // a copy owns its own expanded list (and outlives the original); a moved one keeps the buffer
+                vslam::FrameKeypoints copy;
+                {
+                    vslam::FrameKeypoints tmp = rc.frame(f);
+                    copy = tmp;
+                    EXPECT(copy.dog == copy.dog_expanded.data() && (copy.n_dog == 0 || copy.dog != tmp.dog));
+                }
+                EXPECT(copy.n_dog == fk.n_dog && (copy.n_dog == 0 || std::memcmp(copy.dog, fk.dog, fk.n_dog * sizeof(vslam_point)) == 0));
+                const vslam_point* before = copy.dog;
+                const vslam::FrameKeypoints moved = std::move(copy);
+                EXPECT(moved.dog == before && moved.dog == moved.dog_expanded.data());
             }
             EXPECT(seen == pt0.size() && seen > 0);
         }

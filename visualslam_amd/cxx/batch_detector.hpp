@@ -44,6 +44,26 @@ struct FrameKeypoints {
     // Options::compact_points: the batch's SLAM::point lists travelled as 16-byte records; `dog` / `oriented` then point
     // into these re-expanded copies, which the FrameKeypoints owns (a moved vector keeps its buffer: the pointers stay valid)
     std::vector<vslam_point> dog_expanded, oriented_expanded;
+
+    FrameKeypoints() = default;
+    FrameKeypoints(FrameKeypoints&&) = default;
+    FrameKeypoints& operator=(FrameKeypoints&&) = default;
+    // a COPY owns copies of the expanded lists: its pointers follow them
+    FrameKeypoints(const FrameKeypoints& o) { copy_from(o); }
+    FrameKeypoints& operator=(const FrameKeypoints& o) {
+        if (this != &o) copy_from(o);
+        return *this;
+    }
+
+private:
+    void copy_from(const FrameKeypoints& o) {
+        harris = o.harris, n_harris = o.n_harris, n_dog = o.n_dog, harris_total = o.harris_total, dog_total = o.dog_total;
+        n_oriented = o.n_oriented, oriented_total = o.oriented_total, oriented_survivors = o.oriented_survivors;
+        descriptors = o.descriptors, descriptor_defined = o.descriptor_defined;
+        dog_expanded = o.dog_expanded, oriented_expanded = o.oriented_expanded;
+        dog = o.dog == o.dog_expanded.data() ? dog_expanded.data() : o.dog;
+        oriented = o.oriented == o.oriented_expanded.data() ? oriented_expanded.data() : o.oriented;
+    }
 };
 
 struct BatchResult {
