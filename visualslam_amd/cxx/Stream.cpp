@@ -181,7 +181,7 @@ int main(int argc, char** argv) {
         opt.pipelines = a.pipelines;
         opt.compact_points = hostfed && a.compact != 0;
         opt.yielding_side_streams = a.side_priority.empty() ? (hostfed && !std::getenv("VSLAM_SIDE_PRIORITY")) : a.side_priority == "low";
-        opt.tune_side_streams = !a.no_tuner;  // this host opts in: the library compares three pairs of side streams during the warm-up
+        opt.tune_side_streams = !a.no_tuner;  // --tuner: the library compares three pairs of (yielding) side streams during the warm-up; off by default
         opt.localize = a.lists != "candidates", opt.orient = a.lists == "orient" || a.lists == "describe", opt.describe = a.lists == "describe";
         if (a.octaves != 4) {
             opt.custom_params = true;
