@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <functional>
 #include <map>
 #include <string>
@@ -138,7 +139,7 @@ struct vslam_ctx {
     std::string timing_name;
     int launch_tag = -1;  // octave of the launch being enqueued, for helpers that do not get it as an argument
     int timing_tag = -1;  // "name@N": only launches tagged N (the octave)
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> timing_ev;
+    std::deque<std::pair<hipEvent_t, hipEvent_t>> timing_ev;  // (a deque: a TimedScope keeps a pointer to its slot while later scopes append)
     size_t timing_used = 0;
 };
 
@@ -231,7 +232,7 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 // choose.  Measured: depending on the queue a LOW-priority side stream lands on, the batch runs up
 // to 20 % slower (the same binary: 11.4 k frames/s with 3 queues per level, 14.2 k with 12) - on one bad queue the side
 // kernels crawl while the main stream's queue sits on the barrier that waits for them.  A host that wants the library to
-// look for a better pair OPTS IN (vslam_ctx_tune_side_streams; the Stream executable does): the 2nd to 5th full-size batch
+// look for a better pair OPTS IN (vslam_ctx_tune_side_streams; `Stream --tuner`): the 2nd to 5th full-size batch
 // call of the context then run on three candidate pairs of side streams (the first pair twice), each call bracketed by two
 // events on the main stream, and the first later call that finds all of them complete (hipEventQuery: the entry point stays
 // asynchronous, nothing waits on the host) adopts the fastest pair - the first one unless another is at least 3 % faster.
