@@ -252,9 +252,18 @@ __device__ __forceinline__ void mx_stage_tile_up2(const uint8_t* __restrict__ s,
     constexpr int RW = TW + 2 * R, RH = TH + 2 * R, NG = RW / 8, NSEG = RH / 16;
     static_assert(RW % 8 == 0 && RH % 16 == 0, "16 x 8 staging items");
     const int H2 = 2 * rows_s, W2 = 2 * cols_s;
+    // Items whose eight columns lie wholly left or right of the image are BORDER_REFLECT_101 images of columns this tile
+    // stages anyway: they are skipped here and filled afterwards by dword copies inside LDS (a column of the byte-transposed
+    // tile is one dword per row quad).  Computed pixel by pixel - four byte loads and ~25 operations each, 128 pixels per
+    // item, on threads of all four waves - they made every left / right border tile (34 of 510 at 1080p) about twice as long.
+    // (block-uniform; the mirrored columns must lie inside the image AND inside the staged range)
+    const int x_lo = tile_x0 - R, x_hi = tile_x0 + TW + R;  // staged columns [x_lo, x_hi)
+    const bool mir_l = x_lo < 0 && -x_lo < W2 && -x_lo < x_hi;
+    const bool mir_r = x_hi > W2 && 2 * (W2 - 1) - (x_hi - 1) >= max(x_lo, 0);
     for (int it = threadIdx.x; it < NSEG * NG; it += NT) {
         const int seg = it / NG, g = it - seg * NG;
         const int by = tile_y0 - R + 16 * seg, bx = tile_x0 - R + 8 * g;  // both even
+        if ((mir_l && bx + 7 < 0) || (mir_r && bx >= W2)) continue;
         // four base rows of the item (8 columns each): two 4 x 4 byte transposes, 8 columns x 4 vertical pixels = two 16-byte LDS stores
         auto put_quad = [&](int q, const uint2& a0, const uint2& a1, const uint2& a2, const uint2& a3) {
 #pragma unroll
@@ -334,6 +343,16 @@ __device__ __forceinline__ void mx_stage_tile_up2(const uint8_t* __restrict__ s,
                 }
                 put_quad(q, row[0], row[1], row[2], row[3]);
             }
+        }
+    }
+    if (mir_l || mir_r) {
+        __syncthreads();  // the columns the copies read are complete (every row of them: row reflection was resolved by their own items)
+        const int nl = mir_l ? -x_lo : 0, nr = mir_r ? x_hi - W2 : 0;  // (x_lo, W2 even: whole 8-column items, all of them skipped above)
+        for (int it = threadIdx.x; it < (RH / 4) * (nl + nr); it += NT) {
+            const int yq = it / (nl + nr), k = it - yq * (nl + nr);
+            const int x = k < nl ? x_lo + k : W2 + (k - nl);
+            const int m = x < 0 ? -x : 2 * (W2 - 1) - x;
+            rp[yq * RWP + (x - x_lo)] = rp[yq * RWP + (m - x_lo)];
         }
     }
 }
