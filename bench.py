@@ -4,6 +4,9 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--frames F]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+Outside torchrun `--gpus N` with N > 1 starts the N ranks itself (a torch.distributed.run child job, launch_ranks) and
+relays rank 0's line: both forms measure BASELINE config 5.
+
 A "step" is one pass of the fused hot path (vslam_detect_batch_dev) over one batch of F
 synthetic 1080p frames per GPU (BASELINE config 4: F = 256).  Frames are generated on the
 device and are resident in HBM before the timed region.  Frames shard across ranks (one
@@ -142,12 +145,12 @@ def live_traffic(kname, rows, cols, octaves, frames=64, matrix_path=0):
     prof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if not prof:
         return None
-    sums, launches = {}, 0
+    sums, launches, step_sums = {}, 0, {}
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             with tempfile.TemporaryDirectory(dir="/tmp") as td:
                 cmd = [prof, "--pmc", counter, "--output-format", "csv", "-d", td, "-o", "r", "--", sys.executable, os.path.join(ROOT, "bench.py"),
-                       "--frames", str(frames), "--steps", "1", "--warmup", "1", "--cpu-sample", "0", "--modes", "0", "--cxx-host", "0", "--live-traffic", "0", "--mx", "0",
+                       "--frames", str(frames), "--steps", "1", "--warmup", "1", "--cpu-sample", "0", "--modes", "0", "--cxx-host", "0", "--live-traffic", "0", "--mx", "0", "--roofline-pass", "0",
                        "--matrix-path", str(int(matrix_path)), "--rows", str(rows), "--cols", str(cols), "--octaves", str(octaves)]
                 env = dict(os.environ, TMPDIR="/tmp")
                 for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
@@ -156,21 +159,29 @@ def live_traffic(kname, rows, cols, octaves, frames=64, matrix_path=0):
                 files = glob.glob(td + "/**/*_counter_collection.csv", recursive=True)
                 if r.returncode != 0 or not files:
                     return None
-                tot, n_l = 0.0, 0
+                tot, n_l, tot_all = 0.0, 0, 0.0
                 for f in files:
                     for row in csv.DictReader(open(f)):
-                        if kname in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                        if row["Counter_Name"] != counter:
+                            continue
+                        kn = row["Kernel_Name"]
+                        if kname in kn:
                             tot += float(row["Counter_Value"])
                             n_l += 1
+                        # every kernel of the library (all vslam::k_*; torch's own kernels - frame synthesis, fills - are not the step)
+                        if "vslam::k_" in kn or kn.startswith("k_"):
+                            tot_all += float(row["Counter_Value"])
                 if n_l == 0:
                     return None
-                sums[counter], launches = tot, n_l
+                sums[counter], launches, step_sums[counter] = tot, n_l, tot_all
     except Exception:
         return None
     batches = 2  # warm-up + the step
     bytes_total = (2.0 * sums["FETCH_SIZE"] + sums["WRITE_SIZE"]) * 1024.0
+    step_total = (2.0 * step_sums["FETCH_SIZE"] + step_sums["WRITE_SIZE"]) * 1024.0
     return {"hbm_bytes_per_frame": bytes_total / (frames * batches), "frames_per_batch": frames, "batches": batches, "launches": launches,
-            "fetch_KiB": sums["FETCH_SIZE"], "write_KiB": sums["WRITE_SIZE"]}
+            "fetch_KiB": sums["FETCH_SIZE"], "write_KiB": sums["WRITE_SIZE"],
+            "step_hbm_bytes_per_frame": step_total / (frames * batches)}  # all k_* kernels of the step together
 
 
 def cxx_host_runs(rows, cols, n, octaves, rank=0, world=1, local_rank=0):
@@ -209,6 +220,46 @@ def cxx_host_runs(rows, cols, n, octaves, rank=0, world=1, local_rank=0):
     return res
 
 
+def launch_ranks(n, argv):
+    """BASELINE config 5 from the plain command: `python bench.py --gpus N ...` outside torchrun starts
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same args>` as a CHILD process (never an
+    exec: this process has not touched the GPU and never will), relays rank 0's one JSON line and the child's exit code,
+    and fails when the line does not show N ranks gathered."""
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.setdefault("OMP_NUM_THREADS", "1")  # what torchrun sets itself, without its warning
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    print(f"bench.py: --gpus {n} outside torchrun: starting {n} ranks as a child job (port {port})", file=sys.stderr, flush=True)
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env, cwd=ROOT)
+    line = None
+    for out in child.stdout:  # stderr goes straight through; stdout is relayed as it comes, the JSON line kept
+        sys.stdout.write(out)
+        sys.stdout.flush()
+        if out.startswith("{"):
+            line = out
+    rc = child.wait()
+    if rc != 0:
+        print(f"bench.py: the {n}-rank child job exited with {rc}", file=sys.stderr)
+        return rc
+    try:
+        d = json.loads(line)
+        got = d["distributed"]["ranks_gathered"]
+    except Exception:
+        print("bench.py: the child job printed no JSON line", file=sys.stderr)
+        return 3
+    if got != n or d.get("n_gpus") != n:
+        print(f"bench.py: asked for {n} ranks, the line shows ranks_gathered={got} n_gpus={d.get('n_gpus')}", file=sys.stderr)
+        return 4
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -227,6 +278,7 @@ def main():
     ap.add_argument("--modes", type=int, default=1, help="1: also time the localize / orient list modes (the `modes` object)")
     ap.add_argument("--live-traffic", type=int, default=1,
                     help="1: measure roofline.traffic in this run (two rocprofv3 --pmc child passes on a 64-frame batch, N = 1 only); 0: the committed profile's figure")
+    ap.add_argument("--roofline-pass", type=int, default=1, help="0: skip the hooked pass behind `value` (the PMC child passes: exactly warm-up + one step)")
     ap.add_argument("--cxx-host", type=int, default=1, help="1: also run the C++ Stream executable on the same workload (one process per rank, after the measurement)")
     ap.add_argument("--matrix-path", type=int, default=0,
                     help="PROFILING ONLY: 1 runs the timed region itself on the opt-in matrix-core kernels (vslam_ctx_set_matrix_path); the line then says so "
@@ -236,6 +288,9 @@ def main():
     ap.add_argument("--stream", choices=["side", "null"], default="side",
                     help="stream of the whole job: a torch side stream (default) or torch's default (NULL) stream")
     args = ap.parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        # the plain form `python bench.py --gpus N`: this process becomes the launcher (nothing here has touched the GPU)
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -279,6 +334,19 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
     if args.gpus != world and rank == 0:
         print(f"note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    # who is really in the job: every rank's id and the identity of its GPU, gathered through the job's own backend
+    # (ranks_gathered / n_gpus of the line are COUNTED from this, not copied from WORLD_SIZE)
+    try:
+        pr = torch.cuda.get_device_properties(dev)
+        my_gpu = {"rank": rank, "device_index": local_rank_dev, "name": pr.name, "uuid": str(getattr(pr, "uuid", "")),
+                  "pci_bus_id": getattr(pr, "pci_bus_id", None), "pci_device_id": getattr(pr, "pci_device_id", None)}
+    except Exception as e:
+        my_gpu = {"rank": rank, "device_index": local_rank_dev, "error": repr(e)}
+    members = [my_gpu]
+    if use_dist:
+        members = [None] * world
+        dist.all_gather_object(members, my_gpu)
+    ranks_gathered = len({m["rank"] for m in members if m})
 
     # one rank per node compiles (a no-op when the in-tree .so is current); the others wait
     if local_rank == 0:
@@ -499,9 +567,13 @@ def main():
 
     kname = args.kernel or ("k_pyr_octave_mx" if args.matrix_path else "k_pyr_octave")
     leg("setup")
-    main = run_mode(args.localize, args.orient, args.steps, args.warmup, kname)
+    # `value`: K steps with NO per-launch event hook; the roofline's kernel durations come from a
+    # second pass of the same K steps with the hook around the dominant kernel's launches, outside `value`
+    main = run_mode(args.localize, args.orient, args.steps, args.warmup, None)
     leg("value")
-    p, L, dt, launches, kms = main["p"], main["L"], main["dt"], main["launches"], main["kms"]
+    hooked = run_mode(args.localize, args.orient, args.steps, 0, kname) if args.roofline_pass else {"launches": 0, "kms": 0.0, "dt": 0.0}
+    leg("roofline_pass")
+    p, L, dt, launches, kms = main["p"], main["L"], main["dt"], hooked["launches"], hooked["kms"]
     # keypoints of the first frames of this rank's batch, for the CPU baseline's count check
     cs = min(args.cpu_sample, n)
     gpu_kp_sample = None
@@ -524,7 +596,9 @@ def main():
     if args.mx and secondary and not args.matrix_path and args.octaves >= 1 and not (args.localize or args.orient):
         try:
             ctx.set_matrix_path(True)
-            mm = run_mode(0, 0, args.steps, 2, "k_pyr_octave_mx")
+            mm = run_mode(0, 0, args.steps, 2, None)
+            mh = run_mode(0, 0, args.steps, 0, "k_pyr_octave_mx")  # the hooked pass, as for `value`
+            mm["launches"], mm["kms"] = mh["launches"], mh["kms"]
             ma = kernel_alone("k_pyr_octave_mx", 3) if args.octaves >= 2 else None
             try:
                 mk = by_kernel(mm["p"], mm["L"], {k: v for k, v in shared.items() if k != "dense_bits"}, True) if args.modes else None
@@ -619,6 +693,7 @@ def main():
         kp_per_step = main["harris"] + main["dog"]
         bytes_frame = L.algorithmic_bytes_harris + L.algorithmic_bytes_dog - rows * cols  # fused: input counted once
         roof = None
+        step_traffic = None
         if launches and kms > 0:
             ach = algo.get(kname, 0) * n * args.steps / (kms * 1e-3) / 1e9
             # HBM bytes per launch measured by rocprofv3 PMC passes of this same command (separate
@@ -635,11 +710,13 @@ def main():
                 traffic = lt["hbm_bytes_per_frame"] * n * args.steps / launches
                 tsrc = "measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child passes (separate), 2*FETCH_SIZE + WRITE_SIZE KiB"
                 tprof = dict(lt, live=True, scaled_to_frames_per_launch=n * args.steps / launches)
+                step_traffic = lt.get("step_hbm_bytes_per_frame")
             elif os.path.exists(tpath):
                 tj = json.load(open(tpath))
                 t = tj.get(kname)
                 if t:
                     traffic = t["hbm_bytes_per_frame"] * n * args.steps / launches
+                    step_traffic = tj.get("_total_bytes_per_frame")
                     tsrc = "profiles/traffic.json: " + tj.get("_round", "rocprofv3 --pmc passes")
                     # NOT measured in this run: the committed profile's per-frame figure times this run's frames per launch
                     tprof = {"live": False, "hbm_bytes_per_frame": t["hbm_bytes_per_frame"], "profiled_frames_per_batch": tj.get("_frames"),
@@ -647,6 +724,8 @@ def main():
             roof = {
                 "kernel": kname, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": tsrc, "traffic_profiled": tprof,
+                "timed_in": "a second pass of the same K steps with the HIP-event hook on (the `value` pass runs with the hook off)",
+                "hooked_pass_ms_per_step": hooked["dt"] / args.steps * 1e3,
                 "limited_by": "valu-dot issue rate, see roofline_valu" if kname == "k_pyr_octave" else ("hbm (write-dominated mix: DESIGN 5.6)" if kname == "k_pyr_octave_mx" else None),
                 "launches": launches, "avg_launch_ms": kms / launches,
                 "algorithmic_bytes_per_frame": algo.get(kname, 0),
@@ -719,7 +798,7 @@ def main():
             "metric": "frames/sec @1080p (Harris + DoG keypoint detection)",
             "value": fps,
             "unit": "frames/s",
-            "n_gpus": world,
+            "n_gpus": ranks_gathered,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
@@ -736,7 +815,9 @@ def main():
                 "parallelism": f"frames sharded 1 stream/GPU x{world}; RCCL all-gather of counts only",
             },
             "distributed": {"initialized": bool(use_dist), "world_size": dist.get_world_size() if use_dist else 1,
-                            "backend": dist.get_backend() if use_dist else None, "ranks_gathered": int(world)},
+                            "backend": dist.get_backend() if use_dist else None, "ranks_gathered": int(ranks_gathered),
+                            "distinct_gpus": len({(m.get("uuid"), m.get("pci_bus_id"), m.get("device_index")) for m in members if m}),
+                            "members": members if world > 1 else None},
             "join_watch": dict(zip(("level", "done", "last_lag_fraction"), ctx.join_watch_report())),  # 0 = low-priority side streams kept
             "side_streams": dict(zip(("pair", "tuner_state"), ctx.side_stream_report())),  # which candidate pair the library's stream tuner kept (0 = the first), 2 = decided: DESIGN section 5.4
             "keypoints_per_sec": kp_per_step * args.steps / dt,
@@ -749,6 +830,9 @@ def main():
                 "algorithmic_bytes_per_frame": bytes_frame,
                 "achieved_GBps": bytes_frame * fps / world / 1e9,
                 "frac_of_peak": bytes_frame * fps / world / 1e9 / HBM_PEAK_GBPS,
+                # HBM bytes ALL kernels of the step moved per frame (the same two PMC child passes as roofline.traffic) over the algorithmic bytes
+                "traffic_bytes_per_frame": step_traffic,
+                "traffic_ratio": (step_traffic / bytes_frame) if step_traffic else None,
             },
             "roofline": roof,
             "roofline_valu": valu,

@@ -55,6 +55,52 @@ def test_bench_two_ranks_share_one_gpu():
 
 
 @pytest.mark.gpu
+def test_plain_bench_command_forms_its_ranks_itself():
+    # `python bench.py --gpus 2` WITHOUT torchrun around it (the form the driver uses for --gpus 1) must
+    # measure two ranks: bench.py starts the torch.distributed.run job as a child, relays rank 0's line, and fails unless
+    # the line shows two ranks gathered.  Same rehearsal switches as above (two ranks on the one GPU, gloo).
+    env = dict(os.environ, VSLAM_BENCH_BACKEND="gloo", VSLAM_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--frames", "4", "--rows", "240", "--cols", "320", "--steps", "2",
+                        "--warmup", "1", "--cpu-sample", "0", "--live-traffic", "0", "--cxx-host", "0"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
+    dd = d["distributed"]
+    assert dd["initialized"] is True and dd["world_size"] == 2 and dd["ranks_gathered"] == 2 and dd["backend"] == "gloo"
+    assert sorted(m["rank"] for m in dd["members"]) == [0, 1]
+    assert dd["distinct_gpus"] == 1  # the rehearsal's two ranks share cuda:0, and the line says so
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--frames", "4", "--rows", "240", "--cols", "320", "--steps", "2", "--warmup", "1",
+                          "--cpu-sample", "0", "--live-traffic", "0", "--modes", "0", "--mx", "0", "--cxx-host", "0"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert one.returncode == 0, one.stderr[-2000:]
+    d1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][0])
+    assert d1["n_gpus"] == 1 and d1["distributed"]["initialized"] is False
+    # two different camera streams in the totals
+    assert d["keypoints_per_step"]["harris"] > d1["keypoints_per_step"]["harris"] and d["keypoints_per_step"]["dog"] > d1["keypoints_per_step"]["dog"]
+    assert d["keypoints_per_step"]["dog"] != 2 * d1["keypoints_per_step"]["dog"] or d["keypoints_per_step"]["harris"] != 2 * d1["keypoints_per_step"]["harris"]
+
+
+def test_plain_bench_command_with_ranks_fails_loudly_without_gpus():
+    # the launcher itself on the CPU box: the child job starts (two ranks under torch.distributed.run), every rank refuses to
+    # run without a GPU, the launcher hands the failure on instead of printing a one-GPU line
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("CPU-box behaviour")
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--frames", "2", "--rows", "64", "--cols", "64", "--steps", "1", "--warmup", "0",
+                        "--cpu-sample", "0", "--cxx-host", "0"], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode != 0
+    assert "starting 2 ranks" in r.stderr and "needs a GPU" in r.stderr, r.stderr[-1500:]
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+@pytest.mark.gpu
 def test_bench_one_rank_goes_through_rccl():
     # the driver launches N ranks with torch.distributed.run over RCCL; with one rank on the one GPU of
     # the test box the same code path runs: init_process_group("nccl"), the barrier / max-over-ranks
@@ -75,7 +121,8 @@ def test_bench_one_rank_goes_through_rccl():
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["value"] > 0
-    assert d["distributed"] == {"initialized": True, "world_size": 1, "backend": "nccl", "ranks_gathered": 1}
+    assert d["distributed"] == {"initialized": True, "world_size": 1, "backend": "nccl", "ranks_gathered": 1, "distinct_gpus": 1, "members": None}
+    assert "hook off" in d["roofline"]["timed_in"] and d["roofline"]["launches"] > 0  # the kernel durations come from a pass of their own
     assert d["two_in_flight"]["frames_per_sec"] > 0 and d["two_in_flight"]["same_counts_on_both_contexts"] is True  # secondary figure, DESIGN 5.4
     # the opt-in matrix path beside the headline: same counts, its own kernel figures, never `value`
     assert d["config"]["matrix_path"] is False and d["mx_path"]["same_keypoint_counts_as_value"] is True and d["mx_path"]["frames_per_sec"] > 0
