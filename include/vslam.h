@@ -81,13 +81,17 @@ const char* vslam_status_string(int status);
 int vslam_ctx_create(int device, void* stream, vslam_ctx** out);
 int vslam_ctx_destroy(vslam_ctx* ctx);
 int vslam_ctx_sync(vslam_ctx* ctx);
-/* The batched path runs its Harris chain and its scans / lists on two low-priority side streams.  HIP binds a stream to a
- * hardware queue of its choosing, and on an unlucky queue those kernels crawl (up to -20 %).  A host
- * that wants the library to look for a better pair opts in with vslam_ctx_tune_side_streams(ctx, 1) (off by default; the
- * environment variable VSLAM_STREAM_TUNER=1 switches it on for contexts created afterwards): the context then times its
- * 2nd to 5th full-size batch call of one shape on three candidate pairs of side streams and adopts the fastest at the first
- * later call that finds those calls finished (an event query: no call ever waits on the host, and nothing is timed
- * while the context's stream is being captured; results never depend on the pair).
+/* The batched path runs its Harris chain and its scans / lists on two side streams.  When those YIELD to the octave kernels
+ * (lowest stream priority, vslam_ctx_set_side_stream_priority below) HIP's choice of hardware queue decides how they fare:
+ * on an unlucky queue they crawl (up to -20 %).  A host that wants the library to look for a better
+ * pair of yielding streams opts in with vslam_ctx_tune_side_streams(ctx, 1) BEFORE the context's first batch call
+ * (VSLAM_ERR_UNSUPPORTED afterwards; off by default; VSLAM_STREAM_TUNER=1 does the same for contexts created afterwards).
+ * Opting in also selects yielding side streams (as set_side_stream_priority(ctx, 1) would), unless a level has been pinned:
+ * at any other level there is nothing to compare, the tuner ends at its first call (state 2, pair 0) and the join watchdog
+ * below runs as usual.  The context then times its 2nd to 5th full-size batch call of one shape on three candidate pairs of
+ * side streams and adopts the fastest at the first later call that finds those calls finished (an event query: no call
+ * ever waits on the host, and nothing is timed while the context's stream is being captured; results never depend on the
+ * pair); the join watchdog starts once the comparison has ended.
  * vslam_ctx_side_stream_report: the index of the pair in use (0 = the first created) and the state of the comparison
  * (0 off or not started, 1 measuring, 2 decided).  Diagnostic only. */
 int vslam_ctx_tune_side_streams(vslam_ctx* ctx, int on);
@@ -105,8 +109,18 @@ int vslam_ctx_set_side_stream_priority(vslam_ctx* ctx, int low);
  * wait exceeds the level's limit (3 % of the call with yielding side streams = level 0, 10 % at the default level 1) start a
  * trial of the next level - 1: side streams at the context stream's priority, 2: side work on the context's stream itself -
  * which is kept only if its fastest call is 1 % faster than the previous level's; then the watch ends (done).  Results
- * never depend on the level.  last_lag_fraction: the most recent measurement (-1: none yet). */
+ * never depend on the level.  last_lag_fraction: the most recent measurement (-1: none yet).
+ * CAPTURE NOTE: the watch (like the tuner) calls hipEventQuery / hipEventElapsedTime and records timing events on the
+ * context's stream.  It checks the capture status of THAT stream only: a process that captures in GLOBAL mode on another
+ * stream (torch.cuda.graph's default) while this context makes un-captured batch calls should switch the watch off for the
+ * context - vslam_ctx_set_join_watch(ctx, 0), or VSLAM_JOIN_WATCH=0 for every context - or pin a level. */
 int vslam_ctx_join_watch_report(const vslam_ctx* ctx, int* level, int* done, float* last_lag_fraction);
+/* on = 0: this context takes no more measurements and stays at its current level; on = 1 (the default) resumes. */
+int vslam_ctx_set_join_watch(vslam_ctx* ctx, int on);
+/* Pins the side-stream level of a context and ends its watch: 0 yielding side streams, 1 side streams at the context
+ * stream's priority, 2 no side streams (every kernel of a batch call on the context's stream, in order).  Before the
+ * context's first batch call only (VSLAM_ERR_UNSUPPORTED afterwards).  Results never depend on the level. */
+int vslam_ctx_pin_side_streams(vslam_ctx* ctx, int level);
 int vslam_ctx_side_stream_report(const vslam_ctx* ctx, int* pair, int* state);
 /* Two batches in flight: a second context (own stream, own output buffers) whose batch starts when `leader`'s most
  * recent vslam_detect_batch_dev call is past its octave-0 kernels - the long, issue-bound part - instead of beside

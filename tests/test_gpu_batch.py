@@ -584,6 +584,81 @@ def test_stream_tuner_compares_side_stream_pairs_without_touching_the_results():
         ctx.close()
 
 
+def test_tuner_alone_does_not_lock_the_watchdog_out():
+    # a caller that used only the documented opt-in - vslam_ctx_tune_side_streams(ctx, 1), no
+    # set_side_stream_priority - got neither the tuner nor the watchdog for the life of the context (each waited for the
+    # other).  Now the opt-in selects the yielding streams the tuner compares; the comparison ends, then the watch runs and ends.
+    import torch
+
+    capi.build()
+    rows, cols, n = 540, 960, 48
+    dev = "cuda:0"
+    frames = synth.frames_torch(n, rows, cols, stream_id=4, device=torch.device(dev))
+    p = capi.default_params(rows, cols)
+    L = capi.batch_layout(p)
+
+    def outs():
+        return dict(response=torch.zeros((n, rows, cols), dtype=torch.float32, device=dev), nms_mask=torch.zeros((n, rows, cols), dtype=torch.uint8, device=dev),
+                    harris_kps=torch.zeros((n, p.harris_cap, 3), dtype=torch.int32, device=dev), harris_counts=torch.zeros(n, dtype=torch.int32, device=dev),
+                    pyramid=torch.zeros((n, L.pyramid_frame_bytes), dtype=torch.uint8, device=dev),
+                    extrema_bits=torch.zeros((n, L.bits_frame_words), dtype=torch.int64, device=dev),
+                    dog_points=torch.zeros((n, p.dog_cap, 6), dtype=torch.int32, device=dev), dog_counts=torch.zeros(n, dtype=torch.int32, device=dev))
+
+    ctx = capi.Context(0, torch.cuda.current_stream().cuda_stream)
+    try:
+        ctx.tune_side_streams(True)  # and nothing else
+        assert ctx.join_watch_report()[0] == 0  # asking for the comparison asks for yielding streams
+        o = outs()
+        for _ in range(40):
+            ctx.detect_batch(p, frames, **o)
+            torch.cuda.synchronize()
+            if ctx.side_stream_report()[1] == 2 and ctx.join_watch_report()[1]:
+                break
+        assert ctx.side_stream_report()[1] == 2, ctx.side_stream_report()
+        lv, done, lag = ctx.join_watch_report()
+        assert done and 0.0 <= lag < 1.0, (lv, done, lag)  # the watchdog measured and ended too
+        ctx.tune_side_streams(True)  # a finished comparison stays finished: accepted, changes nothing
+        assert ctx.side_stream_report()[1] == 2
+        ref = {k: v.clone() for k, v in o.items()}
+    finally:
+        ctx.close()
+    #  not after the side streams exist: the watchdog has cached the pair in use by then
+    ctx = capi.Context(0, torch.cuda.current_stream().cuda_stream)
+    try:
+        o = outs()
+        ctx.detect_batch(p, frames, **o)
+        torch.cuda.synchronize()
+        with pytest.raises(capi.VslamError):
+            ctx.tune_side_streams(True)
+        ctx.tune_side_streams(False)  # switching it off is always possible
+    finally:
+        ctx.close()
+    # a pinned level other than 0: the tuner has nothing to compare, ends at its first call, and the results are the same
+    ctx = capi.Context(0, torch.cuda.current_stream().cuda_stream)
+    try:
+        ctx.pin_side_streams(1)
+        ctx.tune_side_streams(True)
+        o = outs()
+        ctx.detect_batch(p, frames, **o)
+        torch.cuda.synchronize()
+        assert ctx.side_stream_report() == (0, 2) and ctx.join_watch_report()[:2] == (1, True)
+        for k in ("response", "nms_mask", "harris_counts", "pyramid", "extrema_bits", "dog_counts"):
+            assert torch.equal(ref[k], o[k]), k
+    finally:
+        ctx.close()
+    # the per-context off switch of the watchdog: no measurement is ever taken
+    ctx = capi.Context(0, torch.cuda.current_stream().cuda_stream)
+    try:
+        ctx.set_join_watch(False)
+        o = outs()
+        for _ in range(6):
+            ctx.detect_batch(p, frames, **o)
+            torch.cuda.synchronize()
+        assert ctx.join_watch_report() == (1, False, -1.0)
+    finally:
+        ctx.close()
+
+
 def test_stream_tuner_never_blocks_the_host():
     # the comparison used to wait on the host (hipEventSynchronize) inside the 6th call of an asynchronous
     # entry point.  Eight calls of ~4 ms of GPU work each are enqueued back to back with no synchronisation: no call's
@@ -637,7 +712,7 @@ def test_join_watchdog_levels_give_the_same_results_and_the_watch_ends():
     # the end of a call exceeds 3 % of the call) and tries the next form - side streams at the main stream's priority (level 1),
     # then none (level 2) - keeping a form only if it is measurably faster.  Here: (a) a context left alone measures its first full-size calls without blocking,
     # reports a lag fraction and ends the watch (on a quiet box at level 0; whatever level it ends on, results are the
-    # same); (b) contexts forced to levels 1 and 2 (VSLAM_JOIN_WATCH_LEVEL) produce byte-identical outputs.
+    # same); (b) contexts pinned to levels 0, 1 and 2 (vslam_ctx_pin_side_streams) produce byte-identical outputs.
     import os
 
     import torch
@@ -657,38 +732,31 @@ def test_join_watchdog_levels_give_the_same_results_and_the_watch_ends():
                     dog_points=torch.zeros((n, p.dog_cap, 6), dtype=torch.int32, device=dev), dog_counts=torch.zeros(n, dtype=torch.int32, device=dev))
 
     res = {}
-    saved = os.environ.pop("VSLAM_JOIN_WATCH_LEVEL", None)
-    try:
-        for level in (None, 0, 1, 2):
+    for level in (None, 0, 1, 2):
+        ctx = capi.Context(0, torch.cuda.current_stream().cuda_stream)
+        try:
+            o = outs()
             if level is None:
-                os.environ.pop("VSLAM_JOIN_WATCH_LEVEL", None)
-            else:
-                os.environ["VSLAM_JOIN_WATCH_LEVEL"] = str(level)
-            ctx = capi.Context(0, torch.cuda.current_stream().cuda_stream)
-            try:
-                o = outs()
-                if level is None:
-                    assert ctx.join_watch_report() == (1, False, -1.0)  # the default: side streams at the context stream's priority
-                    for _ in range(16):  # call 1 of a level is not measured; three more are, and read by a later call once finished
-                        ctx.detect_batch(p, frames, **o)
-                        torch.cuda.synchronize()
-                        if ctx.join_watch_report()[1]:
-                            break
-                    lv, done, lag = ctx.join_watch_report()
-                    assert done and lv in (0, 1, 2) and 0.0 <= lag < 1.0, (lv, done, lag)
-                    with pytest.raises(capi.VslamError):  # the side streams exist: their priority can no longer be chosen
-                        ctx.set_side_stream_priority(True)
-                else:
-                    assert ctx.join_watch_report()[:2] == (level, True)
+                assert ctx.join_watch_report() == (1, False, -1.0)  # the default: side streams at the context stream's priority
+                for _ in range(16):  # call 1 of a level is not measured; three more are, and read by a later call once finished
                     ctx.detect_batch(p, frames, **o)
                     torch.cuda.synchronize()
-                res[level] = o
-            finally:
-                ctx.close()
-    finally:
-        os.environ.pop("VSLAM_JOIN_WATCH_LEVEL", None)
-        if saved is not None:
-            os.environ["VSLAM_JOIN_WATCH_LEVEL"] = saved
+                    if ctx.join_watch_report()[1]:
+                        break
+                lv, done, lag = ctx.join_watch_report()
+                assert done and lv in (0, 1, 2) and 0.0 <= lag < 1.0, (lv, done, lag)
+                with pytest.raises(capi.VslamError):  # the side streams exist: their priority can no longer be chosen
+                    ctx.set_side_stream_priority(True)
+                with pytest.raises(capi.VslamError):
+                    ctx.pin_side_streams(2)
+            else:
+                ctx.pin_side_streams(level)
+                assert ctx.join_watch_report()[:2] == (level, True)
+                ctx.detect_batch(p, frames, **o)
+                torch.cuda.synchronize()
+            res[level] = o
+        finally:
+            ctx.close()
     cnt = res[None]["dog_counts"].cpu().numpy()
     hcn = res[None]["harris_counts"].cpu().numpy()
     assert cnt.min() > 0
@@ -749,13 +817,13 @@ def test_batch_tiny_frames(env, shape, n_oct, path):
 
 def test_serial_stream_mode_matches_oracle():
     # the default run forks the Harris / extrema chains onto auxiliary streams; the single-stream
-    # mode (VSLAM_AUX_STREAMS=0, read once per process) must give the same results
+    # mode (VSLAM_AUX_STREAMS=0 in the diagnostics build lib/libvslam_diag.so, read once per process) must give the same results
     import os
     import subprocess
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, VSLAM_AUX_STREAMS="0")
+    env = dict(os.environ, VSLAM_AUX_STREAMS="0", VSLAM_LIBRARY=capi.DIAG_LIB_PATH)  # a diagnostics-build switch (the API: pin_side_streams(2))
     r = subprocess.run([sys.executable, os.path.join(root, "__graft_entry__.py"), "smoke"], capture_output=True, text=True,
                        timeout=600, env=env, cwd=root)
     assert r.returncode == 0 and "smoke ok" in r.stdout, r.stdout + r.stderr
@@ -772,7 +840,7 @@ def test_fused_band_kernel_matches_oracle():
     if os.environ.get("VSLAM_BAND_KERNEL") == "1":
         pytest.skip("already inside the band-kernel run")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, VSLAM_BAND_KERNEL="1")
+    env = dict(os.environ, VSLAM_BAND_KERNEL="1", VSLAM_LIBRARY=capi.DIAG_LIB_PATH)  # the switch exists in the diagnostics build only
     sel = "random_shapes or ragged or tiny_frames or config2_and_3 or small_frames_all_outputs or band_kernel_is_dispatched"
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_batch.py"), "-m", "gpu", "-q", "-x", "-k", sel],
                        capture_output=True, text=True, timeout=1200, env=env, cwd=root)
@@ -1081,7 +1149,7 @@ def test_orientation_packed_and_scalar_kernels_agree(env, tmp_path):
             "capi.build(); ctx = capi.Context(0)\n"
             "p, L, b = run_batch(ctx, torch, np.load(%r), n_octaves=3, localize=1, orient=1)\n"
             "np.savez(%r, pts=b['oriented_points'], cnt=b['oriented_counts'])\n") % (root, str(tmp_path / "frames.npy"), str(tmp_path / "scalar.npz"))
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, VSLAM_ORIENT_SCALAR="1"), cwd=root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, VSLAM_ORIENT_SCALAR="1", VSLAM_LIBRARY=capi.DIAG_LIB_PATH), cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     b = np.load(tmp_path / "scalar.npz")
     assert np.array_equal(a["oriented_counts"], b["cnt"])

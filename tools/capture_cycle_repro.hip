@@ -10,8 +10,10 @@
 // (modes 3-5 add what the library's call has on top: 3 an eager pass over the same streams and events first, 4 lowest-priority
 // side streams, 5 further waits of the side streams on origin events in between)
 // Mode 0 leaves the A <-> B edges out (A and B only talk to O): capture, instantiate and launch succeed.  Mode 1 adds the
-// A -> B edge only, mode 2 both edges: on the runtimes tried (see profiles/r05_capture_cycle_repro.txt) mode 2 never returns from
-// hipStreamEndCapture - the process dies of stack exhaustion (SIGSEGV) inside libamdhip64.so.
+// A -> B edge only, mode 2 both edges.  On the runtimes tried (profiles/r05_capture_cycle_repro.txt) modes 0-4 all pass -
+// mutual waits between two side streams are harmless by themselves - and MODE 5 (each side stream also waits on an
+// origin-stream event again between the mutual waits, as this library's side streams do on every octave's event) never
+// returns from hipStreamEndCapture: the process dies of stack exhaustion (SIGSEGV) inside libamdhip64.so.
 //
 //   hipcc --offload-arch=gfx950 -O2 tools/capture_cycle_repro.hip -o tools/capture_cycle_repro && tools/capture_cycle_repro <mode>
 #include <hip/hip_runtime.h>

@@ -123,7 +123,9 @@ def main():
         return
     for api in ("raw", "torch"):
         for nested in ((0, 2, 3, 1) if api == "raw" else (0, 1)):  # 2: only the early edge test's fork, 3: only the spread launches', 1: both
-            env = dict(os.environ, VSLAM_CAPTURE_NESTED_FORKS=str(nested))
+            # the switch exists in the diagnostics build only (lib/libvslam_diag.so, -DVSLAM_DIAGNOSTICS): the shipped library cannot
+            # be talked into the crash
+            env = dict(os.environ, VSLAM_CAPTURE_NESTED_FORKS=str(nested), VSLAM_LIBRARY=os.path.join(ROOT, "visualslam_amd", "lib", "libvslam_diag.so"))
             bt = os.path.join(ROOT, "tools", "segv_bt.so")  # gcc -shared -fPIC -O1 -g tools/segv_bt.c -o tools/segv_bt.so
             if os.path.exists(bt):
                 env["LD_PRELOAD"] = (env.get("LD_PRELOAD", "") + " " + bt).strip()

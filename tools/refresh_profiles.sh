@@ -24,7 +24,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_mx -o runc -- 
 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $OUT/mxA -o r -- python3 $B $S --matrix-path 1 > $OUT/mxA.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/mxB -o r -- python3 $B $S --matrix-path 1 > $OUT/mxB.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/mxC -o r -- python3 $B $S --matrix-path 1 > $OUT/mxC.log 2>&1
-VSLAM_AUX_STREAMS=0 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_mx_serial -o runc -- python3 $B $Q --matrix-path 1 > $OUT/prof_mx_serial.log 2>&1
+VSLAM_AUX_STREAMS=0 VSLAM_LIBRARY=$GRAFT_REPO_ROOT/visualslam_amd/lib/libvslam_diag.so rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_mx_serial -o runc -- python3 $B $Q --matrix-path 1 > $OUT/prof_mx_serial.log 2>&1
 cd $GRAFT_REPO_ROOT
 python3 tools/pmc_summary.py $OUT/pmcA $OUT/pmcB $OUT/pmcC > $OUT/pmc_f64.json
 python3 tools/pmc_summary.py $OUT/mxA $OUT/mxB $OUT/mxC > $OUT/pmc_mx_f64.json

@@ -17,6 +17,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # VSLAM_LIBRARY: development switch for A/B timing of two builds of the same library on one box
 # (tools/ab.sh); everything else uses the in-tree build.
 LIB_PATH = os.environ.get("VSLAM_LIBRARY") or os.path.join(_HERE, "lib", "libvslam.so")
+# the diagnostics build (-DVSLAM_DIAGNOSTICS: the A/B environment switches); a test / tool that needs one starts its child
+# process with VSLAM_LIBRARY=DIAG_LIB_PATH
+DIAG_LIB_PATH = os.path.join(_HERE, "lib", "libvslam_diag.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 MAX_OCTAVES = 16
@@ -133,6 +136,8 @@ SIGNATURES = {
     "vslam_ctx_tune_side_streams": (_I, [_P, _I]),
     "vslam_ctx_join_watch_report": (_I, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_float)]),
     "vslam_ctx_set_side_stream_priority": (_I, [_P, _I]),
+    "vslam_ctx_set_join_watch": (_I, [_P, _I]),
+    "vslam_ctx_pin_side_streams": (_I, [_P, _I]),
     "vslam_detect_batch_host": (_I, [_P, C.POINTER(Params), _P, _Z, _I, C.POINTER(HostLists)]),
     "vslam_pack_lists_dev": (_I, [_P, _P, _Z, C.c_uint32, _P, _I, _P, _Z, _P]),
     "vslam_pack_points16_dev": (_I, [_P, _P, C.c_uint32, _P, _I, _P, _Z, _P]),
@@ -145,11 +150,14 @@ SIGNATURES = {
 
 
 def build(force: bool = False) -> str:
-    """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU): lib/libvslam.so, and beside it
+    lib/libvslam_diag.so (DIAG_LIB_PATH: the same sources with -DVSLAM_DIAGNOSTICS, for the tests / tools that need an A/B
+    switch - never loaded by default)."""
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(_HERE, "..", "include", "vslam.h")]
-    stale = force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(s) for s in srcs)
+    newest = max(os.path.getmtime(s) for s in srcs)
+    stale = force or any(not os.path.exists(q) or os.path.getmtime(q) < newest for q in (LIB_PATH, DIAG_LIB_PATH))
     if stale and not os.environ.get("VSLAM_LIBRARY"):
-        r = subprocess.run(["make", "-C", CSRC] + (["-B"] if force else []), capture_output=True, text=True)
+        r = subprocess.run(["make", "-j4", "-C", CSRC] + (["-B"] if force else []), capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("building libvslam.so failed:\n" + r.stdout + r.stderr)
     return LIB_PATH
@@ -515,6 +523,14 @@ class Context:
 
     def matrix_path(self) -> bool:
         return bool(lib().vslam_ctx_get_matrix_path(self._h))
+
+    def set_join_watch(self, on: bool):
+        """vslam_ctx_set_join_watch: False = this context takes no more join-lag measurements (stays at its level)."""
+        self._chk(lib().vslam_ctx_set_join_watch(self._h, 1 if on else 0), "vslam_ctx_set_join_watch")
+
+    def pin_side_streams(self, level: int):
+        """vslam_ctx_pin_side_streams: 0 yielding / 1 the context stream's priority / 2 no side streams; before the first batch call."""
+        self._chk(lib().vslam_ctx_pin_side_streams(self._h, int(level)), "vslam_ctx_pin_side_streams")
 
     def tune_side_streams(self, on: bool = True):
         """vslam_ctx_tune_side_streams: opt in to (or out of) the library's comparison of side-stream pairs; off by default."""

@@ -28,120 +28,11 @@
 #include "kernels_sift.hip.h"
 #include "kernels_extrema_dense.hip.h"
 #include "vslam_internal.h"
+#include "vslam_ctx.h"
 #include "vslam_mx.h"
 
 using namespace vslam;
 
-// ------------------------------------------------------------------------- context
-
-// Which pair of low-priority side streams the batched path runs on: see "side-stream placement" below.
-struct StreamTuner {
-    static constexpr int K = 3;                      // candidate pairs
-    static constexpr int M = K + 1;                  // measured calls: pair 0, 1, 2, 0
-    hipStream_t cand[K][2] = {};                     // cand[0] = the pair ensure_aux created
-    hipEvent_t t0[M] = {}, t1[M] = {};
-    int measured = 0;                                // calls measured so far
-    int measuring = -1;                              // slot being measured by the current call
-    bool enabled = false;                            // vslam_ctx_tune_side_streams (or VSLAM_STREAM_TUNER=1 when the context was created)
-    bool done = false;
-    int chosen = 0;
-    unsigned long long key = 0;                      // shape of the calls being compared (0: none yet)
-    int calls = 0, resets = 0;
-};
-
-// Side-stream priority and the join watchdog (round 5).
-// The batched path's two side streams (Harris chain; scans and lists) may run at the LOWEST stream priority, so that they
-// yield to the octave kernels, or at the main stream's.  Which is faster is decided by the hardware queue each stream
-// happens to land on (HIP multiplexes streams onto GPU_MAX_HW_QUEUES queues per priority level, default 4; DESIGN section
-// 5.4).  Same box, C++ host, device-resident, frames/s with 2 / 3 / 4 / 6 / 12 queues: yielding 14.1 k / 11.5 k / 13.4 k /
-// 14.0 k / 14.0 k, same priority 13.7 k / 13.7 k / 14.0 k / 13.7 k / 14.2 k - yielding wins 2-3 % on a lucky layout and
-// loses 18 % on an unlucky one (a low-priority queue behind the main queue's barrier packet crawls), same priority never
-// moves more than 3.5 %.  The default is therefore the SAME priority (level 1): a caller that embeds the library in a
-// process with streams of its own gets a sane schedule with HIP's default queue count, without setting an environment
-// variable or opting in to anything.  A host that owns its queue layout asks for yielding streams (level 0) with
-// vslam_ctx_set_side_stream_priority / VSLAM_SIDE_PRIORITY=low (Stream's host-fed mode, which also asks for 12 queues).
-//
-// The watchdog keeps either choice honest.  The first full-size batch calls of a context are bracketed by three events on
-// the main stream - start, "my own kernels are enqueued up to here" (just before the waits on the side streams' join
-// events) and end.  t(end) - t(own) is how long the main stream sat waiting for side work: 0.4 % of an 18 ms batch when
-// the side streams run freely, 5 % with yielding streams on four queues, 20 % when one of them is being starved.  A later
-// call reads the events once they are complete (hipEventQuery: nothing ever waits on the host).  Three measured calls with
-// a median lag above the level's limit (3 % at level 0, 10 % at level 1) start a TRIAL of the next level - same priority,
-// then no side streams at all (level 2) - and the trial is kept only if its fastest call beats the previous level's fastest
-// by 1 %; otherwise the context goes back.  Either way the watch ends after at most ten measured calls.  Off while a capture
-// is on, while the opt-in tuner is comparing pairs, and under VSLAM_JOIN_WATCH=0; VSLAM_JOIN_WATCH_LEVEL pins a level.
-// Results never depend on the level.
-struct JoinWatch {
-    static constexpr int RING = 4, NEED = 3;
-    hipEvent_t t0[RING] = {}, tm[RING] = {}, t1[RING] = {};
-    bool live[RING] = {};       // events of slot i are recorded and not yet read
-    int head = 0;               // next slot to record
-    int recording = -1;         // slot of the call being enqueued
-    int calls = 0;              // eligible calls at the current level (the first is not measured)
-    int n_meas = 0;             // measurements at the current level
-    float lag[NEED] = {}, best_total = 0.0f;
-    float level_best[3] = {0.0f, 0.0f, 0.0f};  // fastest measured call at each level tried
-    int level = 1;              // 0: low-priority (yielding) side streams, 1: the main stream's priority, 2: no side streams
-    int trial_from = -1;        // the level a running trial came from (-1: the current level is not a trial)
-    unsigned long long key = 0; // shape of the calls being measured (only calls of one shape are compared)
-    int restarts = 0;
-    bool done = false, disabled = false, pinned = false;
-    float last_lag_frac = -1.0f;
-    hipStream_t pair[2][2] = {};  // the side-stream pairs of levels 0 and 1 (both live until the context goes)
-};
-
-struct vslam_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
-    std::string err;
-    // bump workspace in HBM, grown between calls only (never inside a launch sequence)
-    char* ws = nullptr;
-    size_t ws_cap = 0, ws_off = 0;
-    std::map<std::pair<int, uint64_t>, uint16_t*> taps;  // device copies of quantised taps
-    std::map<std::pair<uint64_t, int>, StripTaps*> strip_taps;  // (sigma0 bits, octave) -> device tables
-    std::map<std::pair<uint64_t, int>, void*> tile_taps;        // (sigma0 bits, octave) -> PyrTaps<CFG>
-    // OPT-IN matrix-core form of the LDS-tiled octave kernels (VSLAM_MX=1 / vslam_ctx_set_matrix_path): never the default
-    bool mx = false;
-    bool orient_scalar_form = false;  // VSLAM_ORIENT_SCALAR=1: k_orient_survivors for every octave (the round-3 form, kept for comparison)
-    std::map<std::pair<uint64_t, int>, void*> mx_taps;          // (sigma0 bits, octave) -> MxTaps<CFG>
-    // auxiliary streams of the batched path: the HBM-bound chains (Harris; extrema + compaction)
-    // run beside the VALU-bound pyramid kernels; forked from / joined to `stream` by events
-    // aux[2] carries only the second-half upsample of a large batch (enqueue_dog): it must not queue behind
-    // the previous chunk's list chain on aux[1]
-    static constexpr int kAux = 3;
-    hipStream_t aux[kAux] = {nullptr, nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr, ev_join[kAux] = {nullptr, nullptr, nullptr}, ev_oct[VSLAM_MAX_OCTAVES] = {};
-    int prio_lo = 0;      // priority of the two side streams in use (0: the main stream's)
-    int prio_dev_lo = 0;  // the device's lowest stream priority (0: it has no priority levels)
-    StreamTuner tuner;    // which pair of side streams the batched path runs on (see StreamTuner)
-    JoinWatch watch;      // steps the side streams down when their join lags (see JoinWatch)
-    hipEvent_t ev_phase = nullptr;  // recorded by every vslam_detect_batch_dev call once its octave-0 kernels are enqueued (vslam_ctx_follow)
-    bool phase_marked = false;
-    hipEvent_t ev_up2 = nullptr;  // the second half of a batch has been upsampled (enqueue_dog)
-    hipEvent_t ev_chunk = nullptr;  // the main-stream kernels of a chunk (the readers of the octave bases) are enqueued up to here
-    // matrix path, fused lattice scan: the side stream's k_extrema_pack launches of a chunk have read the site / seam maps
-    // (the one scratch of the DoG path written on the main stream and read on a side stream: the next chunk's octave
-    // kernels wait for this before they overwrite it)
-    hipEvent_t ev_pack = nullptr;
-    bool pack_pending = false;
-    hipEvent_t ev_list0 = nullptr, ev_edge = nullptr;  // octave 0's part of the DoG list is written / its edge test is done
-    hipEvent_t ev_or_fork = nullptr, ev_or_join[2] = {nullptr, nullptr};  // the orientation launches spread over the idle side streams (enqueue_orient_batch)
-    // recycled pyramid blocks: a GaussPyramid per image would otherwise pay hipMalloc + hipFree of
-    // >100 MB each time (milliseconds, more than the kernels)
-    std::vector<std::pair<size_t, void*>> block_cache;
-    // kernels whose dynamic-LDS ceiling has been raised on this device (once, not per launch)
-    std::set<const void*> lds_raised;
-    float* loc_lut = nullptr;  // FeaturePointLocalization table (kernels_localize.hip.h), built on first use
-    uint8_t* dump = nullptr;   // 256 bytes nobody reads: where the Harris kernel's margin lanes store in its steady rows
-    std::map<std::pair<uint64_t, int>, float*> orient_taps;  // (sigma bits, kernel width) -> f32 Gaussian taps on the device
-    // bench timing hook
-    std::string timing_name;
-    int launch_tag = -1;  // octave of the launch being enqueued, for helpers that do not get it as an argument
-    int timing_tag = -1;  // "name@N": only launches tagged N (the octave)
-    std::deque<std::pair<hipEvent_t, hipEvent_t>> timing_ev;  // (a deque: a TimedScope keeps a pointer to its slot while later scopes append)
-    size_t timing_used = 0;
-};
 
 struct vslam_pyramid {
     vslam_ctx* ctx = nullptr;
@@ -154,26 +45,6 @@ struct vslam_pyramid {
     size_t base_off[VSLAM_MAX_OCTAVES] = {};
 };
 
-static int fail(vslam_ctx* c, int code, const std::string& msg) {
-    if (c) c->err = msg;
-    return code;
-}
-
-#define HIPCHK(ctx, expr)                                                                        \
-    do {                                                                                         \
-        hipError_t e_ = (expr);                                                                  \
-        if (e_ != hipSuccess)                                                                    \
-            return fail(ctx, e_ == hipErrorOutOfMemory ? VSLAM_ERR_NOMEM : VSLAM_ERR_HIP,        \
-                        std::string(#expr) + ": " + hipGetErrorString(e_));                     \
-    } while (0)
-
-#define ARGCHK(ctx, cond, msg) \
-    if (!(cond)) return fail(ctx, VSLAM_ERR_INVALID, msg)
-#define TRY(expr)              \
-    do {                       \
-        int rc_ = (expr);      \
-        if (rc_) return rc_;   \
-    } while (0)
 
 static const char* const kKernelNames =
     "k_resize_linear2x\nk_blur_h_generic\nk_blur_v_generic\n"
@@ -181,25 +52,6 @@ static const char* const kKernelNames =
     "k_gauss_v_strip\nk_gauss_h_strip\nk_gauss_band\nk_resize_linear2x_slide\nk_resize_nearest_half_v4\nk_extrema_w3\nk_extrema_dense\nk_localize_points\nk_orient_keypoints\nk_edge_response_windows\nk_level_gradients\nk_pack_rows\nk_edge_flags\nk_survivor_ranges\nk_orient_survivors\n"
     "k_extrema_pack\nk_harris_strip\nk_flag_count\nk_chunk_scan\nk_flag_scatter\nk_level_gradients\nk_sift_descriptors\nk_pack_offsets\nk_pack_copy\nk_count_totals";
 
-static std::pair<hipEvent_t, hipEvent_t>* timing_slot(vslam_ctx* c);
-
-// Brackets the launches made inside its scope with HIP events on the context stream when the
-// bench hook (vslam_kernel_timing_enable) names this kernel.
-struct TimedScope {
-    vslam_ctx* c;
-    std::pair<hipEvent_t, hipEvent_t>* ev;
-    hipStream_t st;
-    // `tag`: the octave of the launch (-1: none) - "name@2" times only the launches tagged 2; `stream`: where the launch
-    // goes when that is not the context's current stream (the scans go straight to the side stream)
-    TimedScope(vslam_ctx* ctx, const char* name, int tag = -1, hipStream_t stream = nullptr)
-        : c(ctx), ev(!ctx->timing_name.empty() && ctx->timing_name == name && (ctx->timing_tag < 0 || ctx->timing_tag == tag) ? timing_slot(ctx) : nullptr),
-          st(stream ? stream : ctx->stream) {
-        if (ev) (void)hipEventRecord(ev->first, st);
-    }
-    ~TimedScope() {
-        if (ev) (void)hipEventRecord(ev->second, st);
-    }
-};
 
 // Launch on the context stream (no dynamic LDS).
 #define LAUNCH(ctx, name, kern, grid, block, ...)                                 \
@@ -211,251 +63,9 @@ struct TimedScope {
         HIPCHK(ctx, hipGetLastError());                                           \
     } while (0)
 
-static std::pair<hipEvent_t, hipEvent_t>* timing_slot(vslam_ctx* c) {
-    if (c->timing_used == c->timing_ev.size()) {
-        if (c->timing_ev.size() >= 65536) return nullptr;
-        hipEvent_t a, b;
-        if (hipEventCreate(&a) != hipSuccess) return nullptr;
-        if (hipEventCreate(&b) != hipSuccess) {
-            (void)hipEventDestroy(a);
-            return nullptr;
-        }
-        c->timing_ev.emplace_back(a, b);
-    }
-    return &c->timing_ev[c->timing_used++];
-}
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-// ---- side-stream placement ---------------------------------------------------------------------------------------
-// HIP binds every stream to one of GPU_MAX_HW_QUEUES hardware queues per priority level, and the placement is not ours to
-// choose.  Measured: depending on the queue a LOW-priority side stream lands on, the batch runs up
-// to 20 % slower (the same binary: 11.4 k frames/s with 3 queues per level, 14.2 k with 12) - on one bad queue the side
-// kernels crawl while the main stream's queue sits on the barrier that waits for them.  A host that wants the library to
-// look for a better pair OPTS IN (vslam_ctx_tune_side_streams; `Stream --tuner`): the 2nd to 5th full-size batch
-// call of the context then run on three candidate pairs of side streams (the first pair twice), each call bracketed by two
-// events on the main stream, and the first later call that finds all of them complete (hipEventQuery: the entry point stays
-// asynchronous, nothing waits on the host) adopts the fastest pair - the first one unless another is at least 3 % faster.
-// Only calls of one shape are compared (calls of another shape, small or odd calls run on the pair in use and do not
-// disturb the comparison; a caller whose full-size shape keeps changing ends it on the first pair after three restarts);
-// nothing is timed while the stream is being captured.  Results never depend on the streams a call runs on.
-static int tuner_pair_of(int slot) { return slot == StreamTuner::K ? 0 : slot; }
-
-static int create_side_stream(vslam_ctx* c, int prio_lo, hipStream_t* out) {
-    if (prio_lo == 0 || hipStreamCreateWithPriority(out, hipStreamNonBlocking, prio_lo) != hipSuccess) {
-        (void)hipGetLastError();  // priorities are a speed matter only
-        HIPCHK(c, hipStreamCreateWithFlags(out, hipStreamNonBlocking));
-    }
-    return VSLAM_OK;
-}
-
-static void tuner_finish(vslam_ctx* c, int chosen) {
-    StreamTuner& t = c->tuner;
-    t.chosen = chosen;
-    t.done = true;
-    t.measuring = -1;
-    c->aux[0] = t.cand[chosen][0], c->aux[1] = t.cand[chosen][1];
-    for (int k = 0; k < StreamTuner::K; ++k) {
-        if (k == chosen) continue;
-        for (hipStream_t& st : t.cand[k])
-            if (st) (void)hipStreamSynchronize(st), (void)hipStreamDestroy(st), st = nullptr;
-    }
-    for (int m = 0; m < StreamTuner::M; ++m) {
-        if (t.t0[m]) (void)hipEventDestroy(t.t0[m]), t.t0[m] = nullptr;
-        if (t.t1[m]) (void)hipEventDestroy(t.t1[m]), t.t1[m] = nullptr;
-    }
-}
-
-// Before the fork of a batch call (ensure_aux has run): picks the pair of side streams this call uses.  Never blocks.
-static int tuner_before_call(vslam_ctx* c, unsigned long long key, bool eligible) {
-    StreamTuner& t = c->tuner;
-    if (t.done || !t.enabled || c->watch.level > 0) return VSLAM_OK;  // (the pairs it compares are low-priority ones)
-    if (c->prio_lo == 0) {  // no priority levels: one pair is as good as another
-        t.done = true;
-        return VSLAM_OK;
-    }
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(c->stream, &cap) != hipSuccess) (void)hipGetLastError();
-    if (cap != hipStreamCaptureStatusNone) return VSLAM_OK;  // a captured call records no timing events and runs on the pair in use
-    ++t.calls;
-    if (t.calls == 1 || !eligible) return VSLAM_OK;  // the first call pays one-time costs; small / odd calls are not what is being tuned
-    if (t.key == 0) t.key = key;
-    if (key != t.key) {  // another full-size shape: start over with it (the pairs created so far stay), but not for ever
-        if (++t.resets > 3) {
-            tuner_finish(c, 0);
-            return VSLAM_OK;
-        }
-        t.key = key;
-        t.measured = 0;
-        c->aux[0] = t.cand[0][0], c->aux[1] = t.cand[0][1];
-        return VSLAM_OK;
-    }
-    if (t.measured < StreamTuner::M) {
-        const int m = t.measured, k = tuner_pair_of(m);
-        for (hipStream_t& st : t.cand[k])
-            if (!st) TRY(create_side_stream(c, c->prio_lo, &st));  // created while the other pairs exist: binds to another queue
-        if (!t.t0[m]) HIPCHK(c, hipEventCreate(&t.t0[m]));
-        if (!t.t1[m]) HIPCHK(c, hipEventCreate(&t.t1[m]));
-        c->aux[0] = t.cand[k][0], c->aux[1] = t.cand[k][1];
-        HIPCHK(c, hipEventRecord(t.t0[m], c->stream));
-        t.measuring = m;
-        return VSLAM_OK;
-    }
-    // every candidate has been timed: decide once the last measured call has finished - until then on the first pair
-    c->aux[0] = t.cand[0][0], c->aux[1] = t.cand[0][1];
-    const hipError_t q = hipEventQuery(t.t1[StreamTuner::M - 1]);
-    if (q == hipErrorNotReady) {
-        (void)hipGetLastError();
-        return VSLAM_OK;
-    }
-    float ms[StreamTuner::M] = {};
-    bool ok = q == hipSuccess;
-    for (int m = 0; m < StreamTuner::M && ok; ++m) ok = hipEventElapsedTime(&ms[m], t.t0[m], t.t1[m]) == hipSuccess;
-    int best = 0;
-    if (ok) {
-        const float first = std::min(ms[0], ms[StreamTuner::K]);  // pair 0 was timed twice (the early calls run on cold clocks)
-        float best_ms = first;
-        for (int k = 1; k < StreamTuner::K; ++k)
-            if (ms[k] < 0.97f * first && ms[k] < best_ms) best = k, best_ms = ms[k];
-    } else {
-        (void)hipGetLastError();
-    }
-    tuner_finish(c, best);  // the discarded streams are idle (every measured call has joined them back): nothing to wait for
-    return VSLAM_OK;
-}
-
-static int tuner_after_call(vslam_ctx* c) {
-    StreamTuner& t = c->tuner;
-    if (t.measuring < 0) return VSLAM_OK;
-    HIPCHK(c, hipEventRecord(t.t1[t.measuring], c->stream));
-    t.measuring = -1;
-    ++t.measured;
-    return VSLAM_OK;
-}
-
-// Before the fork of a batch call: reads finished measurements, moves between the levels, starts this call's measurement.
-static int watch_set_level(vslam_ctx* c, int level) {
-    JoinWatch& w = c->watch;
-    for (bool& l : w.live) l = false;  // measurements in flight belong to the form being left
-    w.calls = w.n_meas = 0;
-    w.best_total = 0.0f;
-    w.level = level;
-    if (level <= 1) {
-        for (int i = 0; i < 2; ++i) {
-            if (!w.pair[level][i]) TRY(create_side_stream(c, level == 0 ? c->prio_dev_lo : 0, &w.pair[level][i]));
-            c->aux[i] = w.pair[level][i];  // the pair being left is idle: every call joins its side streams back
-        }
-        c->prio_lo = level == 0 ? c->prio_dev_lo : 0;
-    }
-    return VSLAM_OK;
-}
-
-static int watch_before_call(vslam_ctx* c, unsigned long long key, bool eligible, bool capturing) {
-    JoinWatch& w = c->watch;
-    w.recording = -1;
-    if (w.done || w.disabled || capturing || (c->tuner.enabled && !c->tuner.done)) return VSLAM_OK;
-    if (eligible && key != w.key) {  // calls of another shape: their times say nothing about the ones measured so far
-        for (bool& l : w.live) l = false;
-        w.calls = w.n_meas = 0;
-        w.best_total = 0.0f;
-        if (w.key != 0 && ++w.restarts > 3) {  // a caller whose shape keeps changing: stop watching (a running trial ends where it started)
-            if (w.trial_from >= 0) TRY(watch_set_level(c, w.trial_from));
-            w.trial_from = -1;
-            w.done = true;
-            return VSLAM_OK;
-        }
-        w.key = key;
-    }
-    if (w.level <= 1 && !w.pair[w.level][0]) w.pair[w.level][0] = c->aux[0], w.pair[w.level][1] = c->aux[1];
-    for (int i = 0; i < JoinWatch::RING; ++i) {
-        if (!w.live[i]) continue;
-        const hipError_t q = hipEventQuery(w.t1[i]);
-        if (q == hipErrorNotReady) {
-            (void)hipGetLastError();
-            continue;
-        }
-        w.live[i] = false;
-        float total = 0.0f, lag = 0.0f;
-        if (q != hipSuccess || hipEventElapsedTime(&total, w.t0[i], w.t1[i]) != hipSuccess || hipEventElapsedTime(&lag, w.tm[i], w.t1[i]) != hipSuccess || !(total > 0.0f)) {
-            (void)hipGetLastError();
-            continue;
-        }
-        w.last_lag_frac = lag / total;
-        if (w.n_meas < JoinWatch::NEED) {
-            w.lag[w.n_meas++] = lag / total;
-            w.best_total = (w.best_total == 0.0f || total < w.best_total) ? total : w.best_total;
-        }
-    }
-    if (w.n_meas >= JoinWatch::NEED) {
-        const float a = w.lag[0], b = w.lag[1], m = w.lag[2];
-        const float med = std::max(std::min(a, b), std::min(std::max(a, b), m));
-        w.level_best[w.level] = w.best_total;
-        bool keep = true;
-        if (w.trial_from >= 0 && !(w.best_total < 0.99f * w.level_best[w.trial_from])) {  // the trial did not pay: go back, stop
-            TRY(watch_set_level(c, w.trial_from));
-            w.trial_from = -1;
-            w.done = true;
-            keep = false;
-        }
-        if (keep) {
-            w.trial_from = -1;
-            const float limit = w.level == 0 ? 0.03f : 0.10f;
-            if (w.level < 2 && med > limit && (w.level == 1 || c->prio_dev_lo != 0)) {  // (level 0 without priority levels IS level 1)
-                const int from = w.level;
-                TRY(watch_set_level(c, from + 1));
-                w.trial_from = from;
-            } else
-                w.done = true;
-        }
-        if (w.done) return VSLAM_OK;
-    }
-    if (!eligible) return VSLAM_OK;
-    if (++w.calls == 1) return VSLAM_OK;  // the first call of a form pays one-time costs
-    const int slot = w.head;
-    if (w.live[slot]) return VSLAM_OK;  // the host is more than RING calls ahead: skip this one
-    if (!w.t0[slot]) {
-        HIPCHK(c, hipEventCreate(&w.t0[slot]));
-        HIPCHK(c, hipEventCreate(&w.tm[slot]));
-        HIPCHK(c, hipEventCreate(&w.t1[slot]));
-    }
-    HIPCHK(c, hipEventRecord(w.t0[slot], c->stream));
-    w.recording = slot;
-    w.head = (slot + 1) % JoinWatch::RING;
-    return VSLAM_OK;
-}
-
-static int ensure_aux(vslam_ctx* c) {
-    if (c->ev_fork) return VSLAM_OK;
-    int prio_lo = 0, prio_hi = 0;
-    if (hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess) {  // numerically: lowest priority, highest priority
-        (void)hipGetLastError();  // priorities are a speed matter only: do not leave the error for the next launch check
-        prio_lo = 0;
-    }
-    c->prio_dev_lo = prio_lo;
-    if (prio_lo == 0 && c->watch.level == 0) c->watch.level = 1;  // no priority levels on this device
-    c->prio_lo = c->watch.level >= 1 ? 0 : prio_lo;
-    for (int i = 0; i < vslam_ctx::kAux; ++i) {
-        // aux[0], aux[1] (Harris chain, scans and lists) yield to the octave kernels; aux[2] carries only the
-        // second-half upsample, which the main stream WAITS for: at low priority it was starved for the whole
-        // first-half octave kernel whenever its start slipped behind that kernel's (C++ host, 0.35 ms per step)
-        if (i == 2)
-            HIPCHK(c, hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking));
-        else
-            TRY(create_side_stream(c, c->prio_lo, &c->aux[i]));
-        HIPCHK(c, hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
-    }
-    c->tuner.cand[0][0] = c->aux[0], c->tuner.cand[0][1] = c->aux[1];
-    for (auto& e : c->ev_oct) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    HIPCHK(c, hipEventCreateWithFlags(&c->ev_up2, hipEventDisableTiming));
-    HIPCHK(c, hipEventCreateWithFlags(&c->ev_chunk, hipEventDisableTiming));
-    HIPCHK(c, hipEventCreateWithFlags(&c->ev_pack, hipEventDisableTiming));
-    HIPCHK(c, hipEventCreateWithFlags(&c->ev_list0, hipEventDisableTiming));
-    HIPCHK(c, hipEventCreateWithFlags(&c->ev_edge, hipEventDisableTiming));
-    HIPCHK(c, hipEventCreateWithFlags(&c->ev_or_fork, hipEventDisableTiming));
-    for (auto& e : c->ev_or_join) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-    return VSLAM_OK;
-}
 
 // Runs `body` with the context's launch stream temporarily replaced (LAUNCH uses ctx->stream).
 struct StreamSwap {
@@ -626,7 +236,7 @@ static OctPlan plan_octave(double sigma0, int o, int rows, int cols) {
         // step): the band's base rows fill the LDS, so one workgroup = 2 waves per SIMD runs per CU with three
         // barriers per level, and that costs more than the 15.5 MB per frame of scratch traffic it removes.
         static const bool use_band = [] {
-            const char* e = std::getenv("VSLAM_BAND_KERNEL");
+            const char* e = VSLAM_DIAG_ENV("VSLAM_BAND_KERNEL");
             return e && e[0] == '1';
         }();
         if (use_band && pl.path == OctPath::Strip) {
@@ -723,7 +333,7 @@ static int enqueue_strip_octave(vslam_ctx* c, double sigma0, int o, const OctPla
             return (double)((items + 63) / 64 * 64 - items) / (double)items;
         };
         static const int force_ri = [] {
-            const char* e = std::getenv("VSLAM_STRIP_RI");
+            const char* e = VSLAM_DIAG_ENV("VSLAM_STRIP_RI");
             return e ? std::atoi(e) : 0;
         }();
         int ri = 4;
@@ -985,7 +595,7 @@ static int enqueue_pyr_octave_mx(vslam_ctx* c, int cfg, double sigma0, int o, co
 // kernels then run beside this call's remaining, shorter kernels instead of beside its own octave 0).
 static int follow_octave() {
     static const int o = [] {
-        const char* e = getenv("VSLAM_FOLLOW_OCTAVE");
+        const char* e = VSLAM_DIAG_ENV("VSLAM_FOLLOW_OCTAVE");
         return e ? atoi(e) : 0;
     }();
     return o;
@@ -1105,7 +715,7 @@ static int enqueue_dog(vslam_ctx* c, const vslam_params& p, const vslam_batch_la
         // A 384 x 32 tile (1920 = 5 x 384) on 384-thread workgroups was measured in round 3: six waves per
         // workgroup sit 2-2-1-1 on the four SIMDs and meet at every barrier: 21.3 vs 18.3 ms per step.
         static const int force_shape = [] {
-            const char* e = std::getenv("VSLAM_TILE_SHAPE");  // A/B runs: 0 = 128 x 64 everywhere, 1 = 256 x 32 everywhere
+            const char* e = VSLAM_DIAG_ENV("VSLAM_TILE_SHAPE");  // A/B runs: 0 = 128 x 64 everywhere, 1 = 256 x 32 everywhere
             return e ? std::atoi(e) : -1;
         }();
         const int shape = force_shape >= 0 ? (force_shape ? 1 : 0)
@@ -1297,12 +907,6 @@ static int d2h(vslam_ctx* c, void* dst, size_t dpitch, const void* src, size_t s
 }
 
 
-static int bind_device(vslam_ctx* c) {
-    if (!c) return VSLAM_ERR_INVALID;
-    HIPCHK(c, hipSetDevice(c->device));
-    return VSLAM_OK;
-}
-
 extern "C" {
 
 // ------------------------------------------------------------------------------ lifecycle
@@ -1335,18 +939,9 @@ int vslam_ctx_create(int device, void* stream, vslam_ctx** out) {
     {
         const char* e = std::getenv("VSLAM_MX");
         c->mx = e && e[0] == '1';
-        const char* es = std::getenv("VSLAM_ORIENT_SCALAR");
+        const char* es = VSLAM_DIAG_ENV("VSLAM_ORIENT_SCALAR");
         c->orient_scalar_form = es && es[0] == '1';
-        const char* jw = std::getenv("VSLAM_JOIN_WATCH");
-        c->watch.disabled = jw && jw[0] == '0';
-        if (const char* sp = std::getenv("VSLAM_SIDE_PRIORITY")) c->watch.level = (sp[0] == 'l' || sp[0] == 'L') ? 0 : 1;  // low | main
-        if (std::getenv("VSLAM_FLAT_PRIORITY")) c->watch.level = 1;  // (rounds 3-4: the switch away from the then default)
-        if (const char* lv = std::getenv("VSLAM_JOIN_WATCH_LEVEL")) {  // tests / A-B runs: start (and stay) at a level
-            c->watch.level = std::min(2, std::max(0, std::atoi(lv)));
-            c->watch.done = c->watch.pinned = true;
-        }
-        const char* t = std::getenv("VSLAM_STREAM_TUNER");
-        c->tuner.enabled = t && t[0] == '1';
+        sched_init_from_env(c);
     }
     *out = c;
     return VSLAM_OK;
@@ -1370,27 +965,12 @@ int vslam_ctx_destroy(vslam_ctx* c) {
     for (auto& kv : c->strip_taps) (void)hipFree(kv.second);
     for (auto& kv : c->tile_taps) (void)hipFree(kv.second);
     for (auto& kv : c->mx_taps) (void)hipFree(kv.second);
-    for (auto& ev : c->timing_ev) {
-        (void)hipEventDestroy(ev.first);
-        (void)hipEventDestroy(ev.second);
-    }
     if (c->ws) (void)hipFree(c->ws);
     for (auto& b : c->block_cache) (void)hipFree(b.second);
     if (c->loc_lut) (void)hipFree(c->loc_lut);
     if (c->dump) (void)hipFree(c->dump);
     for (auto& kv : c->orient_taps) (void)hipFree(kv.second);
-    if (c->ev_fork && !c->tuner.done) tuner_finish(c, 0);  // candidate pairs of an unfinished comparison go first (aux = pair 0 again)
-    for (int i = 0; i < vslam_ctx::kAux; ++i) {
-        if (c->aux[i]) (void)hipStreamDestroy(c->aux[i]);
-        if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
-    }
-    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    for (int i = 0; i < JoinWatch::RING; ++i)
-        for (hipEvent_t e : {c->watch.t0[i], c->watch.tm[i], c->watch.t1[i]})
-            if (e) (void)hipEventDestroy(e);
-    for (auto& pr : c->watch.pair)
-        for (hipStream_t st : pr)
-            if (st && st != c->aux[0] && st != c->aux[1]) (void)hipStreamSynchronize(st), (void)hipStreamDestroy(st);
+    sched_destroy(c);
     for (hipEvent_t e : {c->ev_phase, c->ev_up2, c->ev_chunk, c->ev_pack, c->ev_list0, c->ev_edge, c->ev_or_fork, c->ev_or_join[0], c->ev_or_join[1]})
         if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ev_oct)
@@ -1409,32 +989,6 @@ int vslam_ctx_sync(vslam_ctx* c) {
 const char* vslam_last_error(const vslam_ctx* c) { return c ? c->err.c_str() : "null context"; }
 const char* vslam_kernel_names(void) { return kKernelNames; }
 
-int vslam_kernel_timing_enable(vslam_ctx* c, const char* name) {
-    if (!c) return VSLAM_ERR_INVALID;
-    c->timing_name = name ? name : "";
-    c->timing_tag = -1;
-    const size_t at = c->timing_name.find('@');  // "k_pyr_octave@1": the launches of octave 1 only
-    if (at != std::string::npos) {
-        c->timing_tag = std::atoi(c->timing_name.c_str() + at + 1);
-        c->timing_name.resize(at);
-    }
-    c->timing_used = 0;
-    return VSLAM_OK;
-}
-int vslam_kernel_timing_read(vslam_ctx* c, int* launches, double* total_ms) {
-    TRY(bind_device(c));
-    HIPCHK(c, hipStreamSynchronize(c->stream));  // every batch call joins its side streams back: their events are complete too
-    double tot = 0;
-    for (size_t i = 0; i < c->timing_used; ++i) {
-        float ms = 0;
-        HIPCHK(c, hipEventElapsedTime(&ms, c->timing_ev[i].first, c->timing_ev[i].second));
-        tot += ms;
-    }
-    if (launches) *launches = (int)c->timing_used;
-    if (total_ms) *total_ms = tot;
-    c->timing_used = 0;
-    return VSLAM_OK;
-}
 
 // ------------------------------------------------------------------- host-buffer primitives
 
@@ -2326,11 +1880,11 @@ int vslam_detect_batch_dev(vslam_ctx* c, const vslam_params* pp, const uint8_t* 
     // (11.2k vs 10.9k frames/s) -- small, because every kernel of the batch is VALU-issue-bound
     // rather than HBM-bound; per-kernel durations grow accordingly when kernels share the chip.
     static const bool use_aux = [] {
-        const char* e = std::getenv("VSLAM_AUX_STREAMS");
+        const char* e = VSLAM_DIAG_ENV("VSLAM_AUX_STREAMS");
         return !(e && e[0] == '0');
     }();
     static const bool orient_spread = [] {
-        const char* e = std::getenv("VSLAM_ORIENT_SPREAD");
+        const char* e = VSLAM_DIAG_ENV("VSLAM_ORIENT_SPREAD");
         return !(e && e[0] == '0');
     }();
     // Under stream capture (hipGraph) no two SIDE streams of the call may wait on each other's events.  The topology is legal
@@ -2354,7 +1908,7 @@ int vslam_detect_batch_dev(vslam_ctx* c, const vslam_params* pp, const uint8_t* 
         // diagnostic switch for tools/graph_try.py (the reproducer of that fault): leave the nested forks in while capturing
         // (1: both nested forks stay in, 2: only the early edge test's, 3: only the spread orientation launches')
         static const int nested_in_capture = [] {
-            const char* e = std::getenv("VSLAM_CAPTURE_NESTED_FORKS");
+            const char* e = VSLAM_DIAG_ENV("VSLAM_CAPTURE_NESTED_FORKS");
             return e ? std::atoi(e) : 0;
         }();
         cap_early = capturing && !(nested_in_capture == 1 || nested_in_capture == 2);
@@ -2379,14 +1933,14 @@ int vslam_detect_batch_dev(vslam_ctx* c, const vslam_params* pp, const uint8_t* 
                                         ((unsigned long long)(unsigned)p.n_octaves << 56) ^ ((unsigned long long)(c->mx ? 1 : 0) << 39);
     bool side_streams = use_aux;
     if (use_aux) {
-        TRY(ensure_aux(c));
+        TRY(sched_ensure_aux(c));
         // (calls of a few megapixels are dominated by launch latencies: their lag says nothing about starvation)
-        TRY(watch_before_call(c, call_key, dog && harris && n_frames >= 32 && (size_t)n_frames * N >= ((size_t)16 << 20), capturing));
+        TRY(sched_watch_before_call(c, call_key, dog && harris && n_frames >= 32 && (size_t)n_frames * N >= ((size_t)16 << 20), capturing));
         if (c->watch.level == 2) side_streams = false;  // the watchdog's last step: everything on the caller's stream
     }
     if (side_streams) {
         // the side-stream pair of this call (StreamTuner): only full-size batches with both paths are compared
-        TRY(tuner_before_call(c, call_key, dog && harris && n_frames >= 32));
+        TRY(sched_tuner_before_call(c, call_key, dog && harris && n_frames >= 32));
         HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
         for (int i = 0; i < vslam_ctx::kAux; ++i) HIPCHK(c, hipStreamWaitEvent(c->aux[i], c->ev_fork, 0));
         sh = c->aux[0];
@@ -2467,38 +2021,11 @@ int vslam_detect_batch_dev(vslam_ctx* c, const vslam_params* pp, const uint8_t* 
         c->watch.recording = -1;
     }
     if (!c->phase_marked) TRY(mark_phase(c));  // no DoG path in this call: its end is the mark
-    if (side_streams) TRY(tuner_after_call(c));
+    if (side_streams) TRY(sched_tuner_after_call(c));
     guard.armed = false;
     return VSLAM_OK;
 }
 
-int vslam_ctx_side_stream_report(const vslam_ctx* c, int* pair, int* state) {
-    if (!c) return VSLAM_ERR_INVALID;
-    if (pair) *pair = c->tuner.chosen;
-    if (state) *state = c->tuner.done ? 2 : ((c->tuner.enabled && c->tuner.calls > 1) ? 1 : 0);
-    return VSLAM_OK;
-}
-
-int vslam_ctx_set_side_stream_priority(vslam_ctx* c, int low) {
-    if (!c) return VSLAM_ERR_INVALID;
-    if (c->ev_fork) return fail(c, VSLAM_ERR_UNSUPPORTED, "set_side_stream_priority: the side streams exist already - call it before the context's first batch call");
-    if (!c->watch.pinned) c->watch.level = low ? 0 : 1;
-    return VSLAM_OK;
-}
-
-int vslam_ctx_join_watch_report(const vslam_ctx* c, int* level, int* done, float* last_lag_fraction) {
-    if (!c) return VSLAM_ERR_INVALID;
-    if (level) *level = c->watch.level;
-    if (done) *done = c->watch.done ? 1 : 0;
-    if (last_lag_fraction) *last_lag_fraction = c->watch.last_lag_frac;
-    return VSLAM_OK;
-}
-
-int vslam_ctx_tune_side_streams(vslam_ctx* c, int on) {
-    if (!c) return VSLAM_ERR_INVALID;
-    if (!c->tuner.done) c->tuner.enabled = on != 0;  // a finished comparison stays finished
-    return VSLAM_OK;
-}
 
 int vslam_ctx_follow(vslam_ctx* c, const vslam_ctx* leader) {
     TRY(bind_device(c));
