@@ -117,6 +117,9 @@ def lib():
         L.vo_sift_descriptors.argtypes = [C.POINTER(_Pyr), C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.vo_sift_descriptors.restype = C.c_size_t
         L.vo_baseline_frames.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_ulonglong)]
+        L.vo_set_fma_variant.argtypes = [C.c_int]
+        L.vo_set_fma_variant.restype = None
+        L.vo_get_fma_variant.restype = C.c_int
         _lib = L
     return _lib
 
@@ -293,6 +296,27 @@ def harris_keypoints(nms2_map) -> np.ndarray:
     if n:
         lib().vo_harris_keypoints(m.ctypes.data, *m.shape, m.strides[0], out.ctypes.data, n)
     return out
+
+
+class fma_variant:
+    """`with oracle.fma_variant(True):` runs the f32 stages (fastAtan2's polynomial, the separable f32 filter's two
+    passes) with fused multiply-adds, as OpenCV's AVX2 + FMA3 dispatch would; the default - and what the GPU kernels
+    compute - rounds every multiply and add (vslam_oracle.c: g_fma_variant).  `on`: True / False, or a mask (ATAN = 1,
+    FILTER = 2: the two OpenCV modules dispatch independently).  Restores the previous setting."""
+
+    ATAN, FILTER, BOTH = 1, 2, 3  # the mask's bits: fastAtan32f's polynomial; the f32 filter's row / column passes
+
+    def __init__(self, on):
+        self.mask = 3 if on is True else int(on) & 3
+
+    def __enter__(self):
+        self.prev = lib().vo_get_fma_variant()
+        lib().vo_set_fma_variant(self.mask)
+        return self
+
+    def __exit__(self, *exc):
+        lib().vo_set_fma_variant(self.prev)
+        return False
 
 
 def fast_atan2_deg(y: float, x: float) -> float:

@@ -500,7 +500,22 @@ vo_pyramid* vo_pyramid_build_u8(const uint8_t* img, int rows, int cols, size_t s
     return p;
 }
 
-/* cv::fastAtan2 / hal::fastAtan32f scalar form (OpenCV 4.x mathfuncs_core.simd.hpp). */
+/* ---- the one UNPINNED arithmetic choice of the f32 stages: contraction of a*b+c -------------------------------------
+ * The reference is compiled without -march flags, but OpenCV itself dispatches at run time: on an x86-64 with
+ * AVX2 + FMA3 its f32 row / column filters (filter.simd.hpp: RowVec_32f / SymmColumnVec_32f use v_muladd = v_fma) and
+ * hal::fastAtan32f (mathfuncs_core.simd.hpp: v_fma(v_fma(v_fma(cc, p7, p5), cc, p3), cc, p1) * c) run variants whose
+ * v_fma IS one fused instruction, where the SSE2 baseline rounds the product and the sum separately.  Which one a given
+ * OpenCV build runs cannot be known here (no OpenCV), so the oracle carries BOTH: variant 0 (default, what the GPU kernels
+ * compute: every op rounded) and the fused form in exactly these three places and nowhere else - a mask, because the two
+ * OpenCV modules dispatch independently: bit 0 = the arctangent polynomial, bit 1 = the filter's two passes (3 = both).
+ * tools/fma_risk_report.py runs rows (f)1 / (f)3 / (f)4 under both and counts what changes; tools/pin_with_opencv.sh
+ * tries both against a real OpenCV.  Test infrastructure only, like the rest of this file. */
+static int g_fma_variant = 0; /* bit 0: fastAtan32f's polynomial, bit 1: the separable f32 filter's row and column passes */
+void vo_set_fma_variant(int mask) { g_fma_variant = mask & 3; }
+int vo_get_fma_variant(void) { return g_fma_variant; }
+
+/* cv::fastAtan2 / hal::fastAtan32f (OpenCV 4.x mathfuncs_core.simd.hpp): scalar form, or with the polynomial's three
+ * multiply-adds fused (variant 1: the AVX2 / FMA3 dispatch of the vector loop). */
 float vo_fast_atan2_deg(float y, float x) {
     const float scale = (float)(180.0 / 3.14159265358979323846);
     const float p1 = 0.9997878412794807f * scale, p3 = -0.3258083974640975f * scale;
@@ -510,11 +525,11 @@ float vo_fast_atan2_deg(float y, float x) {
     if (ax >= ay) {
         c = ay / (ax + eps);
         c2 = c * c;
-        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+        a = (g_fma_variant & 1) ? fmaf(fmaf(fmaf(c2, p7, p5), c2, p3), c2, p1) * c : (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
     } else {
         c = ax / (ay + eps);
         c2 = c * c;
-        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+        a = 90.f - ((g_fma_variant & 1) ? fmaf(fmaf(fmaf(c2, p7, p5), c2, p3), c2, p1) * c : (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c);
     }
     if (x < 0) a = 180.f - a;
     if (y < 0) a = 360.f - a;
@@ -639,7 +654,7 @@ float vo_compute_edge_response(const float* gx, const float* gy, int rows, int c
  * window come from the parent and reflect-101 applies at the PARENT's edges.  Separable f32
  * filter in OpenCV's order: row filter s = k[0]*S[0]; s += k[i]*S[i] left to right; symmetric
  * column filter s = k[c]*S[0]; s += k[c+i]*(S[+i] + S[-i]) (mul and add rounded separately: SSE
- * baseline; an AVX2/FMA3 dispatch would fuse them - unverifiable here). */
+ * baseline; variant 1 - vo_set_fma_variant - fuses each multiply-add as the AVX2/FMA3 dispatch does). */
 static int blur_f32_roi(const float* parent, int prows, int pcols, int x0, int y0, int w, int h, const float* k,
                         int n, float* dst) {
     const int R = n / 2;
@@ -655,14 +670,20 @@ static int blur_f32_roi(const float* parent, int prows, int pcols, int x0, int y
         const float* S = parent + (size_t)vo_reflect101(y0 + rr - R, prows) * pcols;
         for (int c = 0; c < w; c++) {
             float s0 = k[0] * S[cx[c]];
-            for (int i = 1; i < n; i++) s0 += k[i] * S[cx[c + i]];
+            if (g_fma_variant & 2)
+                for (int i = 1; i < n; i++) s0 = fmaf(S[cx[c + i]], k[i], s0);
+            else
+                for (int i = 1; i < n; i++) s0 += k[i] * S[cx[c + i]];
             rb[(size_t)rr * w + c] = s0;
         }
     }
     for (int r = 0; r < h; r++)
         for (int c = 0; c < w; c++) {
             float s0 = k[R] * rb[(size_t)(r + R) * w + c];
-            for (int i = 1; i <= R; i++) s0 += k[R + i] * (rb[(size_t)(r + R + i) * w + c] + rb[(size_t)(r + R - i) * w + c]);
+            if (g_fma_variant & 2)
+                for (int i = 1; i <= R; i++) s0 = fmaf(rb[(size_t)(r + R + i) * w + c] + rb[(size_t)(r + R - i) * w + c], k[R + i], s0);
+            else
+                for (int i = 1; i <= R; i++) s0 += k[R + i] * (rb[(size_t)(r + R + i) * w + c] + rb[(size_t)(r + R - i) * w + c]);
             dst[(size_t)r * w + c] = s0;
         }
     free(rb);

@@ -190,6 +190,14 @@ size_t vo_sift_descriptors(const vo_pyramid* p, int octave, const vo_point* kps,
 int vo_baseline_frames(const uint8_t* frames, int n, int rows, int cols, int n_octaves, int threads,
                        unsigned long long* keypoints);
 
+/* The f32 stages' one unpinned arithmetic choice (see the comment at g_fma_variant in vslam_oracle.c): 0 (default) rounds every
+ * multiply and add separately - OpenCV's SSE2 baseline code, and what the GPU kernels compute; 1 fuses the multiply-adds of
+ * hal::fastAtan32f's polynomial and of the separable f32 filter's row / column passes, as OpenCV's AVX2 + FMA3 dispatch does.
+ * A mask (the two OpenCV modules dispatch independently): bit 0 = the arctangent polynomial, bit 1 = the filter passes.
+ * Process-wide; not for use while another thread runs the f32 stages. */
+void vo_set_fma_variant(int mask);
+int vo_get_fma_variant(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -26,24 +26,22 @@
 #include <opencv2/core.hpp>
 #include <opencv2/imgproc.hpp>
 
+#include "pin_io.hpp"  // the OpenCV-free half: raw files, argument parsing (checked in the CPU suite by pin_io_check.cpp)
+
 static std::vector<float> read_f32(const char* path, size_t n) {
-    std::vector<float> v(n);
-    FILE* f = std::fopen(path, "rb");
-    if (!f || std::fread(v.data(), 4, n, f) != n) {
+    std::vector<float> v;
+    if (!pin::read_f32(path, n, &v)) {
         std::fprintf(stderr, "cannot read %zu floats from %s\n", n, path);
         std::exit(2);
     }
-    std::fclose(f);
     return v;
 }
 
 static void write_all(const char* path, const void* p, size_t bytes) {
-    FILE* f = std::fopen(path, "wb");
-    if (!f || std::fwrite(p, 1, bytes, f) != bytes) {
+    if (!pin::write_all(path, p, bytes)) {
         std::fprintf(stderr, "cannot write %s\n", path);
         std::exit(2);
     }
-    std::fclose(f);
 }
 
 int main(int argc, char** argv) {
@@ -56,27 +54,34 @@ int main(int argc, char** argv) {
         std::printf("%s\n", CV_VERSION);
         return 0;
     }
-    if (cmd == "roi_blur" && argc >= 9 && (argc - 6) % 3 == 0) {
-        const int rows = std::atoi(argv[3]), cols = std::atoi(argv[4]);
-        std::vector<float> data = read_f32(argv[2], (size_t)rows * cols);
-        cv::Mat parent(rows, cols, CV_32F, data.data());
-        std::vector<float> out;
-        for (int a = 6; a + 2 < argc; a += 3) {
-            const int x = std::atoi(argv[a]), y = std::atoi(argv[a + 1]);
-            const double sigma = std::atof(argv[a + 2]);
-            cv::Mat win(parent, cv::Rect(x, y, 16, 16));
-            cv::Mat blurred;
-            cv::GaussianBlur(win, blurred, cv::Size(0, 0), sigma, 0, cv::BORDER_DEFAULT);
-            for (int r = 0; r < 16; ++r)
-                for (int c = 0; c < 16; ++c) out.push_back(blurred.at<float>(r, c));
+    if (cmd == "roi_blur") {
+        pin::RoiBlurArgs a;
+        if (!pin::parse_roi_blur(argc, argv, &a)) {
+            std::fprintf(stderr, "bad arguments for roi_blur\n");
+            return 2;
         }
-        write_all(argv[5], out.data(), out.size() * 4);
+        std::vector<float> data = read_f32(a.parent.c_str(), (size_t)a.rows * a.cols);
+        cv::Mat parent(a.rows, a.cols, CV_32F, data.data());
+        std::vector<float> out;
+        for (const auto& c : a.cases) {
+            cv::Mat win(parent, cv::Rect(c.x, c.y, 16, 16));
+            cv::Mat blurred;
+            cv::GaussianBlur(win, blurred, cv::Size(0, 0), c.sigma, 0, cv::BORDER_DEFAULT);
+            for (int r = 0; r < 16; ++r)
+                for (int cc = 0; cc < 16; ++cc) out.push_back(blurred.at<float>(r, cc));
+        }
+        write_all(a.out.c_str(), out.data(), out.size() * 4);
         return 0;
     }
-    if (cmd == "det_trace" && argc == 7) {
-        const size_t n = (size_t)std::atoll(argv[4]);
-        const float k = (float)std::atof(argv[5]);
-        const std::vector<float> ix = read_f32(argv[2], n), iy = read_f32(argv[3], n);
+    if (cmd == "det_trace") {
+        pin::DetTraceArgs a;
+        if (!pin::parse_det_trace(argc, argv, &a)) {
+            std::fprintf(stderr, "bad arguments for det_trace\n");
+            return 2;
+        }
+        const size_t n = a.n;
+        const float k = a.k;
+        const std::vector<float> ix = read_f32(a.ix.c_str(), n), iy = read_f32(a.iy.c_str(), n);
         std::vector<float> out(3 * n);
         for (size_t i = 0; i < n; ++i) {
             cv::Mat M = cv::Mat::zeros(2, 2, CV_32F);
@@ -89,28 +94,32 @@ int main(int argc, char** argv) {
             float response = det - k * (tr * tr);
             out[3 * i] = det, out[3 * i + 1] = tr, out[3 * i + 2] = response;
         }
-        write_all(argv[6], out.data(), out.size() * 4);
+        write_all(a.out.c_str(), out.data(), out.size() * 4);
         return 0;
     }
-    if (cmd == "mat_at" && argc >= 8 && (argc - 6) % 2 == 0) {
-        const int rows = std::atoi(argv[2]), cols = std::atoi(argv[3]), pad = std::atoi(argv[4]);
-        cv::Mat img(rows, cols, CV_8U);
-        for (int r = 0; r < rows; ++r)
-            for (int c = 0; c < cols; ++c) img.at<uchar>(r, c) = (uchar)((r * 131 + c * 7 + (r * c) % 13) & 255);
+    if (cmd == "mat_at") {
+        pin::MatAtArgs a;
+        if (!pin::parse_mat_at(argc, argv, &a)) {
+            std::fprintf(stderr, "bad arguments for mat_at\n");
+            return 2;
+        }
+        cv::Mat img(a.rows, a.cols, CV_8U);
+        for (int r = 0; r < a.rows; ++r)
+            for (int c = 0; c < a.cols; ++c) img.at<uchar>(r, c) = pin::mat_at_pixel(r, c);
         cv::Mat padded;
-        cv::copyMakeBorder(img, padded, pad, pad, pad, pad, cv::BORDER_REPLICATE);
+        cv::copyMakeBorder(img, padded, a.pad, a.pad, a.pad, a.pad, cv::BORDER_REPLICATE);
         if (!padded.isContinuous()) {
             std::fprintf(stderr, "padded Mat is not continuous: the linear-addressing rule does not apply\n");
             return 3;
         }
         std::vector<uchar> out;
         try {
-            for (int a = 6; a + 1 < argc; a += 2) out.push_back(padded.at<uchar>(std::atoi(argv[a]), std::atoi(argv[a + 1])));
+            for (const auto& xy : a.at) out.push_back(padded.at<uchar>(xy.first, xy.second));
         } catch (const cv::Exception& e) {
             std::fprintf(stderr, "Mat::at asserted (debug build of OpenCV): %s\n", e.what());
             return 4;
         }
-        write_all(argv[5], out.data(), out.size());
+        write_all(a.out.c_str(), out.data(), out.size());
         return 0;
     }
     std::fprintf(stderr, "bad arguments for %s\n", cmd.c_str());

@@ -3,6 +3,7 @@
 # the GPU box, so this has never run there; it is for the first machine that has one (C++ dev files and/or python cv2).
 #
 #   tools/pin_with_opencv.sh            # build the C++ harness, run the cross-check, report
+#   tools/pin_with_opencv.sh --help     # this text
 #   tools/pin_with_opencv.sh --regen    # ... and, when every check passes, regenerate tests/golden/*.npz with the
 #                                       #     OpenCV-made planes and an `opencv_version` stamp
 #
@@ -15,6 +16,10 @@
 set -euo pipefail
 cd "$(dirname "$0")/.."
 regen=0
+if [ "${1:-}" = "--help" ] || [ "${1:-}" = "-h" ]; then
+    sed -n '2,15p' "$0" | sed 's/^# \{0,1\}//'
+    exit 0
+fi
 [ "${1:-}" = "--regen" ] && regen=1
 
 cxxflags="${OPENCV_CXXFLAGS:-}"
@@ -39,9 +44,12 @@ if ! python -c 'import cv2; print("OpenCV (python):", cv2.__version__)'; then
     echo "python has no cv2: nothing to pin against" >&2
     exit 3
 fi
-python -m pytest tests/test_opencv_crosscheck.py -q -rs
+# the f32 checks try BOTH arithmetic variants of the oracle (every op rounded / fused multiply-add: oracle.fma_variant) and
+# print which one this OpenCV build computes as an OPENCV_F32_VARIANT line (-s lets it through)
+python -m pytest tests/test_opencv_crosscheck.py -q -rs -s
 if [ "$regen" = 1 ]; then
     python tests/golden/make_golden.py --opencv
     python -m pytest tests/test_golden_cpu.py -q
 fi
-echo "oracle pinned against this OpenCV: record the version lines above in DESIGN.md (Oracle) and drop 'parity unpinned'"
+echo "oracle pinned against this OpenCV: record the version lines and the OPENCV_F32_VARIANT line above in DESIGN.md (Oracle) and drop 'parity unpinned'"
+echo "(OPENCV_F32_VARIANT ... 1: this build fuses its f32 multiply-adds - rows (f)1/(f)3/(f)4 then hold within BASELINE.md section 5's tolerance: profiles/r06_fma_risk.json)"
