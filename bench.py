@@ -205,18 +205,23 @@ def cxx_host_runs(rows, cols, n, octaves, rank=0, world=1, local_rank=0):
     if os.environ.get("VSLAM_BENCH_SHARE_GPU") == "1":  # rehearsal on one GPU (tests/test_bench_ranks.py): RCCL refuses two ranks per device
         env["VSLAM_COUNT_BACKEND"] = "tcp"
     res = {}
-    for mode in (("device", "hostfed") if world == 1 else ("device",)):
+    # hostfed: the lists reach the host as packed 16-byte records (vslam_point16); hostfed_expanded: the same run with 8 host
+    # threads rebuilding every frame's 24-byte SLAM::point records inside the timed loop (what a consumer of the
+    # reference's std::vector<SLAM::point> gets)
+    for key in (("device", "hostfed", "hostfed_expanded") if world == 1 else ("device",)):
+        mode = "hostfed" if key.startswith("hostfed") else key
+        extra = ["--expand", "8"] if key == "hostfed_expanded" else []
         try:
-            r = subprocess.run([exe, "--mode", mode, "--frames", str(n), "--batches", ("30" if mode == "device" else "40") if world == 1 else "12", "--warmup", "6", "--rows", str(rows), "--cols", str(cols),
+            r = subprocess.run([exe, *extra, "--mode", mode, "--frames", str(n), "--batches", ("30" if mode == "device" else "40") if world == 1 else "12", "--warmup", "6", "--rows", str(rows), "--cols", str(cols),
                                 "--octaves", str(octaves)], capture_output=True, text=True, timeout=600 if world == 1 else 45, env=env)
             if r.returncode != 0:
-                res[mode] = {"error": (r.stdout + r.stderr)[-400:]}
+                res[key] = {"error": (r.stdout + r.stderr)[-400:]}
             elif rank == 0:
-                res[mode] = json.loads(r.stdout.strip().splitlines()[-1])
+                res[key] = json.loads(r.stdout.strip().splitlines()[-1])
             else:
-                res[mode] = {"rank": rank, "ok": True}
+                res[key] = {"rank": rank, "ok": True}
         except Exception as e:
-            res[mode] = {"error": repr(e)}
+            res[key] = {"error": repr(e)}
     return res
 
 

@@ -338,6 +338,13 @@ def test_stream_two_ranks_on_one_gpu_with_the_rehearsal_exchange(built, tmp_path
     by_rank = line["counts_by_rank"]
     assert len(by_rank) == world and by_rank[0] != by_rank[1]  # different camera streams
     assert line["keypoints_per_batch"] == {"harris": by_rank[0][0] + by_rank[1][0], "dog": by_rank[0][1] + by_rank[1][1]}
+    # every rank prints where it put itself - {rank, gpu, PCI address, NUMA node, CPUs} - before it
+    # allocates its pinned staging buffers (gpu_locality.hpp; no flag needed); rank 0's is also in the job's line
+    for r in range(world):
+        pl = [json.loads(l.split("placement ", 1)[1]) for l in outs[r][1].splitlines() if l.startswith("Stream: placement ")]
+        assert len(pl) == 1 and pl[0]["rank"] == r and pl[0]["gpu"] == 0 and pl[0]["n_cpus"] >= 1 and len(pl[0]["pci_bus_id"]) >= 7, outs[r][1]
+        assert pl[0]["bound"] == (pl[0]["numa_node"] >= 0 and "stay on the GPU's node" in pl[0]["note"])
+    assert line["placement"]["rank"] == 0 and line["placement"]["pci_bus_id"]
     for r in range(world):
         gr, gc, frames = _read_dump(tmp_path / f"lists{r}.bin")
         assert (gr, gc, len(frames)) == (rows, cols, n)

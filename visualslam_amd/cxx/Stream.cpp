@@ -5,6 +5,8 @@
 //
 //   Stream [--mode device|hostfed] [--frames 256] [--batches 8] [--warmup 2] [--rows 1080 --cols 1920]
 //          [--octaves 4] [--source synth|<file of raw 8-bit frames>] [--dump <file>] [--rdv-selftest] [--pipelines 1]
+//          [--compact 0|1] [--expand N]   (host-fed: 16-byte records over PCIe; N host threads rebuild SLAM::point in the timed loop)
+//          [--numa 0|1]   (default 1: threads + pinned staging buffers on the NUMA node of the rank's GPU, gpu_locality.hpp)
 //          [--lists candidates|localize|orient|describe]   (how much of the DoG executable runs per frame:
 //           the contrast-8 candidate list, + FeaturePointLocalization, + filterKeypoints, + SIFT descriptors)
 //
@@ -36,6 +38,7 @@
 
 #include "batch_detector.hpp"
 #include "count_exchange.hpp"
+#include "gpu_locality.hpp"
 #include "imgio.hpp"
 #include "vslam_cxx.hpp"
 
@@ -48,6 +51,14 @@ struct Args {
     int hw_queues = 0;
     std::string side_priority;  // "" = by mode: host-fed low (with its 12 queues), device-resident the library's default (main)
     int compact = 1;  // host-fed: SLAM::point lists cross PCIe as 16-byte records (BatchDetector::Options::compact_points)
+    // host-fed + compact: threads that rebuild every frame's 24-byte SLAM::point records from the 16-byte ones INSIDE the timed
+    // loop (what a consumer of the reference's std::vector<SLAM::point> needs; 0 = the packed records are the delivered form)
+    int expand = 0;
+    // 1 (default): the rank's threads and pinned staging buffers go to the NUMA node of its GPU (gpu_locality.hpp); 0: left alone
+    int numa = 1;
+    // --numa-probe: no GPU - resolve --bdf under --sysfs, print the placement (report only unless --numa-bind), exit
+    bool numa_probe = false, numa_bind = false;
+    std::string sysfs = "/sys", bdf;
 };
 
 Args parse(int argc, char** argv) {
@@ -70,6 +81,12 @@ Args parse(int argc, char** argv) {
         else if (k == "--dump") a.dump = val();
         else if (k == "--lists") a.lists = val();  // candidates (default) | localize | orient | describe: how much of the DoG executable runs per frame
         else if (k == "--compact") a.compact = std::stoi(val());  // 0: 24-byte SLAM::point records on the wire (the round-4 form)
+        else if (k == "--expand") a.expand = std::stoi(val());  // N host threads re-expand every collected batch to SLAM::point inside the timed loop
+        else if (k == "--numa") a.numa = std::stoi(val());
+        else if (k == "--numa-probe") a.numa_probe = true;
+        else if (k == "--numa-bind") a.numa_bind = true;
+        else if (k == "--sysfs") a.sysfs = val();
+        else if (k == "--bdf") a.bdf = val();
         else if (k == "--rdv-selftest") a.rdv_selftest = true;
         else if (k == "--no-allgather") a.no_allgather = true;  // diagnosis only: the per-step collective left out
         else if (k == "--no-tuner") a.no_tuner = true;          // (the default since round 5)
@@ -168,9 +185,30 @@ int main(int argc, char** argv) {
             std::printf("{\"exe\": \"Stream\", \"rdv_selftest\": true, \"rank\": %d, \"world\": %d, \"id_hash\": %u}\n", env.rank, env.world, sum);
             return 0;
         }
+        if (a.numa_probe) {  // the sysfs side of the placement alone (no GPU): tests/test_gpu_locality_cpu.py feeds it a fake tree
+            const vslam::locality::Placement pl = vslam::locality::place_near_pci(env.rank, env.local_rank, a.bdf, a.numa_bind, a.sysfs);
+            const std::vector<int> now = vslam::locality::current_affinity();
+            std::printf("{\"exe\": \"Stream\", \"numa_probe\": true, \"placement\": %s, \"affinity_after\": \"%s\"}\n", pl.json().c_str(),
+                        vslam::locality::format_cpulist(now).c_str());
+            return 0;
+        }
         int ndev = 0;
         if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) throw std::runtime_error("no HIP device: the product has no CPU fallback");
         const int device = env.local_rank % ndev;
+        // BEFORE the detector allocates its pinned staging buffers and before any worker thread exists: this thread - and so
+        // every thread created from here on - moves to the CPUs of the GPU's NUMA node (gpu_locality.hpp)
+        vslam::locality::Placement placement;
+        placement.rank = env.rank, placement.gpu = device, placement.cpus = vslam::locality::current_affinity();
+        placement.note = "--numa 0";
+        if (a.numa) {
+            char bdf[64] = {};
+            if (hipDeviceGetPCIBusId(bdf, (int)sizeof(bdf), device) == hipSuccess)
+                placement = vslam::locality::place_near_pci(env.rank, device, bdf, true, a.sysfs);
+            else
+                placement.note = "hipDeviceGetPCIBusId failed";
+        }
+        if (env.world > 1 || std::getenv("VSLAM_PRINT_PLACEMENT"))  // one line per rank on stderr (rank 0's is also in the JSON line)
+            std::fprintf(stderr, "Stream: placement %s\n", placement.json().c_str());
         const size_t N = (size_t)a.rows * a.cols;
         const bool hostfed = a.mode == "hostfed";
 
@@ -305,15 +343,35 @@ int main(int argc, char** argv) {
                 if (!a.no_allgather) gather_counts();
             };
             std::vector<double> t_collect;
+            // --expand N: the consumer's side of compact_points - every frame's DoG records back to SLAM::point (24 bytes), N
+            // threads over the frames of the batch, into buffers that are reused (the cost of delivering the reference's record
+            // form on the host; ADVICE r5: the default figure delivers the packed form and says so)
+            std::vector<std::vector<vslam_point>> xbuf((size_t)std::max(0, a.expand));
+            unsigned long long expanded_records = 0;
+            auto expand_all = [&](const vslam::BatchResult& r) {
+                if (a.expand <= 0 || !r.dog16) return;
+                std::vector<std::thread> th;
+                for (int t = 0; t < a.expand; ++t)
+                    th.emplace_back([&, t] {
+                        for (int f = t; f < r.n_frames; f += a.expand) {
+                            const uint64_t d0 = std::min(r.dog_offsets[f], r.dog_records), d1 = std::min(r.dog_offsets[f + 1], r.dog_records);
+                            if (xbuf[t].size() < d1 - d0) xbuf[t].resize(d1 - d0);
+                            vslam_points16_expand(r.dog16 + d0, (size_t)(d1 - d0), xbuf[t].data());
+                        }
+                    });
+                for (auto& t : th) t.join();
+                expanded_records += std::min(r.dog_offsets[r.n_frames], r.dog_records);
+            };
             auto run = [&](int nb) {
                 int sub = 0;
                 t_collect.clear();
                 for (; sub < std::min(depth, nb); ++sub) submit();
                 for (int k = 0; k < nb; ++k) {
                     const vslam::BatchResult& r = det.collect();
-                    t_collect.push_back(now_s());
                     truncated |= r.truncated;
-                    if (sub < nb) submit(), ++sub;
+                    if (sub < nb) submit(), ++sub;  // the next batch is on its way before this one is consumed
+                    expand_all(r);
+                    t_collect.push_back(now_s());
                     last = &r;
                 }
             };
@@ -367,12 +425,14 @@ int main(int argc, char** argv) {
                         "\"batches\": %d, \"warmup\": %d, \"rows\": %d, \"cols\": %d, \"octaves\": %d, \"frames_per_sec\": %.2f, \"ms_per_batch\": %.4f, "
                         "\"keypoints_per_batch\": {\"harris\": %llu, \"dog\": %llu}, \"keypoints_per_sec\": %.1f, \"rank0_counts\": [%llu, %llu], "
                         "\"steady_ms_per_batch\": %.4f, \"steady_frames_per_sec\": %.2f, \"counts_by_rank\": %s, \"lists\": \"%s\", \"oriented_points_rank0_last_batch\": %llu, \"pipelines\": %d, \"side_stream_pair\": %d, \"side_stream_tuner\": %d, "
-                        "\"join_watch\": {\"level\": %d, \"done\": %d, \"last_lag_fraction\": %.4f}, \"compact_points\": %d, \"gpu_max_hw_queues\": \"%s\"}\n",
+                        "\"join_watch\": {\"level\": %d, \"done\": %d, \"last_lag_fraction\": %.4f}, \"compact_points\": %d, \"expand_threads\": %d, \"delivered_records\": \"%s\", \"gpu_max_hw_queues\": \"%s\", \"placement\": %s}\n",
                         a.no_rccl ? "no communicator (--no-rccl)" : tcp ? "TCP rehearsal exchange (VSLAM_COUNT_BACKEND=tcp)" : "RCCL ncclAllGather", a.mode.c_str(),
                         env.world, a.frames, a.batches, a.warmup, a.rows, a.cols, det.params().n_octaves, fps, dt_max / a.batches * 1e3,
                         (unsigned long long)gh, (unsigned long long)gd, (double)(gh + gd) * a.batches / dt_max, (unsigned long long)all[0],
                         (unsigned long long)all[1], steady_ms, steady_ms > 0 ? a.frames * 1e3 / steady_ms * env.world : 0.0, by_rank.c_str(), a.lists.c_str(), oriented_rank, det.pipelines(), probe_replaced, probe_flat,
-                        jw_level, jw_done, (double)jw_lag, (int)(hostfed && a.compact != 0), hwq ? hwq : "default");
+                        jw_level, jw_done, (double)jw_lag, (int)(hostfed && a.compact != 0), hostfed ? a.expand : 0,
+                        !hostfed ? "device lists (SLAM::point, 24 B)" : (a.compact == 0 ? "SLAM::point (24 B) over PCIe" : (a.expand > 0 ? "16-byte records over PCIe, re-expanded to SLAM::point (24 B) on the host inside the timed loop" : "packed 16-byte vslam_point16 records (vslam_points16_expand not timed)")),
+                        hwq ? hwq : "default", placement.json().c_str());
         }
         vslam::BatchDetector::free_pinned(h_frames);
         return 0;
