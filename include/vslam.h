@@ -137,6 +137,19 @@ int vslam_ctx_follow(vslam_ctx* ctx, const vslam_ctx* leader);
  * the default, and everything bench.py reports as `value` / `roofline`, stays on the dot kernels. */
 int vslam_ctx_set_matrix_path(vslam_ctx* ctx, int on);
 int vslam_ctx_get_matrix_path(const vslam_ctx* ctx);
+/* Which OpenCV the f32 stages reproduce bit for bit.  The reference's f32 arithmetic runs inside OpenCV: cv::phase
+ * (GaussPyramid.cpp:96) and GaussianBlur on CV_32F windows (Diff_of_Gauss.cpp:348, :616-618).  OpenCV dispatches both at run
+ * time: its SSE2 baseline rounds every product and sum, its AVX2 + FMA3 code fuses the multiply-adds of fastAtan32f's
+ * polynomial and of the separable filter's row / column passes.  on = 0 (default): the baseline; on = 1 (environment:
+ * VSLAM_F32_FUSED=1 for contexts created afterwards): the fused form - in vslam_pyramid_get_gradients' orientation image,
+ * vslam_filter_keypoints, vslam_sift_descriptors and the batched orient / descriptor stages.  The CPU oracle carries the same
+ * switch (vo_set_fma_variant) and the parity tests hold bit for bit under either; which one a given OpenCV build computes is
+ * what tools/pin_with_opencv.sh reports.  Between the two (profiles/r06_fma_risk.json, and on the GPU at scale
+ * tests/test_gpu_f32_variant.py): orientation values differ by at most one unit in the last place, no histogram bin and no
+ * oriented point changes, descriptor entries differ by at most 5e-7.  The integer rows (Harris, pyramid, DoG, extrema,
+ * localization) do not depend on it. */
+int vslam_ctx_set_f32_fused(vslam_ctx* ctx, int on);
+int vslam_ctx_get_f32_fused(const vslam_ctx* ctx);
 const char* vslam_last_error(const vslam_ctx* ctx);
 
 /* ------------------------------------------ host-side parameter helpers (no GPU) */

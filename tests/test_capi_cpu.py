@@ -36,14 +36,14 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
     assert b"k_harris_strip" in lib.vslam_kernel_names()
 
 
-def test_shipped_library_reads_four_environment_variables_only(lib):
+def test_shipped_library_reads_five_environment_variables_only(lib):
     # the A/B and fault-reproducer switches of rounds 3-5 are compiled out of the shipped library
     # (-DVSLAM_DIAGNOSTICS builds lib/libvslam_diag.so with them); INTEGRATION.md section 5 lists both sets
     def env_names(path):
         data = open(path, "rb").read()
         return sorted(set(m.decode() for m in re.findall(rb"VSLAM_[A-Z0-9_]+", data)))
 
-    assert env_names(capi.LIB_PATH) == ["VSLAM_JOIN_WATCH", "VSLAM_MX", "VSLAM_SIDE_PRIORITY", "VSLAM_STREAM_TUNER"]
+    assert env_names(capi.LIB_PATH) == ["VSLAM_F32_FUSED", "VSLAM_JOIN_WATCH", "VSLAM_MX", "VSLAM_SIDE_PRIORITY", "VSLAM_STREAM_TUNER"]
     diag = env_names(capi.DIAG_LIB_PATH)
     assert "VSLAM_CAPTURE_NESTED_FORKS" in diag and "VSLAM_TILE_SHAPE" in diag and "VSLAM_AUX_STREAMS" in diag and len(diag) >= 12
     doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()

@@ -68,6 +68,27 @@ def test_fma_variant_touches_the_three_f32_primitives_only():
     p1.close()
 
 
+def test_no_histogram_bin_depends_on_the_arctangent_variant():
+    # every integer gradient pair a Sobel(ksize 1) of u8 data can produce, both variants of fastAtan32f's polynomial: the
+    # values differ in the last bit for ~2 % of the pairs, the 36-bin (Diff_of_Gauss.cpp:126, :352) and 8-bin (:631) indices
+    # never - which is why only the kernel that RETURNS the angle (k_level_gradients) carries the switch
+    L = oracle.lib()
+    v = np.arange(-255, 256, dtype=np.float32)
+
+    def table(mask):
+        L.vo_set_fma_variant(mask)
+        try:
+            return np.array([[L.vo_fast_atan2_deg(float(y), float(x)) for x in v] for y in v], np.float32)
+        finally:
+            L.vo_set_fma_variant(0)
+
+    a, b = table(0), table(1)
+    assert 0 < (a != b).sum() < 0.03 * a.size and np.abs(a - b).max() <= 2 ** -15
+    for nb in (36, 8):
+        k = np.float32(nb / 360.0)
+        assert ((a * k).astype(np.int32) == (b * k).astype(np.int32)).all()
+
+
 def test_committed_fma_report_is_reproducible_and_backs_the_stated_tolerance(tmp_path):
     # profiles/r06_fma_risk.json (tools/fma_risk_report.py, the four reference images + a 1080p noise frame): the numbers
     # BASELINE.md section 5 / DESIGN section 3 quote.  The quick form (blox + a small noise frame) is re-run here.

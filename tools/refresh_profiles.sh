@@ -13,7 +13,7 @@ B=$GRAFT_REPO_ROOT/bench.py
 python3 $B > $OUT/bench_default.json 2> $OUT/bench.err
 python3 $B --cpu-sample 0 --modes 0 --octaves 0 --kernel k_harris_strip --mx 0 > $OUT/bench_harris.json 2>> $OUT/bench.err
 Q="--cpu-sample 0 --modes 0 --mx 0 --cxx-host 0 --live-traffic 0"
-S="--frames 64 --steps 1 --warmup 1 $Q"
+S="--frames 64 --steps 1 --warmup 1 --roofline-pass 0 $Q"  # exactly two batch calls per PMC pass (tools/make_traffic.py divides by them)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o runc -- python3 $B $Q > $OUT/prof.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $OUT/pmcA -o r -- python3 $B $S > $OUT/pmcA.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmcB -o r -- python3 $B $S > $OUT/pmcB.log 2>&1

@@ -136,6 +136,8 @@ SIGNATURES = {
     "vslam_ctx_tune_side_streams": (_I, [_P, _I]),
     "vslam_ctx_join_watch_report": (_I, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_float)]),
     "vslam_ctx_set_side_stream_priority": (_I, [_P, _I]),
+    "vslam_ctx_set_f32_fused": (_I, [_P, _I]),
+    "vslam_ctx_get_f32_fused": (_I, [_P]),
     "vslam_ctx_set_join_watch": (_I, [_P, _I]),
     "vslam_ctx_pin_side_streams": (_I, [_P, _I]),
     "vslam_detect_batch_host": (_I, [_P, C.POINTER(Params), _P, _Z, _I, C.POINTER(HostLists)]),
@@ -523,6 +525,14 @@ class Context:
 
     def matrix_path(self) -> bool:
         return bool(lib().vslam_ctx_get_matrix_path(self._h))
+
+    def set_f32_fused(self, on: bool):
+        """vslam_ctx_set_f32_fused: the f32 stages with fused multiply-adds (an OpenCV that dispatches AVX2 + FMA3) instead of
+        every product and sum rounded (its SSE2 baseline, the default); oracle.fma_variant is the checker's side of it."""
+        self._chk(lib().vslam_ctx_set_f32_fused(self._h, 1 if on else 0), "vslam_ctx_set_f32_fused")
+
+    def get_f32_fused(self) -> bool:
+        return bool(lib().vslam_ctx_get_f32_fused(self._h))
 
     def set_join_watch(self, on: bool):
         """vslam_ctx_set_join_watch: False = this context takes no more join-lag measurements (stays at its level)."""

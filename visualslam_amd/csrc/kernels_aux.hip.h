@@ -264,6 +264,21 @@ __global__ __launch_bounds__(256) void k_extrema_w3(const uint8_t* __restrict__ 
 // = OpenCV's fastAtan2 polynomial.  Materialised on demand (96 bytes per pyramid pixel if all
 // levels were kept); any output pointer may be null.  One thread per pixel; every f32 operation
 // is individually rounded (-ffp-contract=off) so the result equals the oracle's bit for bit.
+// One f32 multiply-add of the two stages that run inside OpenCV's run-time-dispatched SIMD code (fastAtan32f's polynomial, the
+// separable f32 filter's passes).  FMA = false: product and sum rounded separately - OpenCV's SSE2 baseline, the default, the
+// oracle's variant 0.  FMA = true: one fused operation - its AVX2 + FMA3 dispatch, oracle.fma_variant (vslam_ctx_set_f32_fused;
+// profiles/r06_fma_risk.json: what changes between the two).  The file is compiled with -ffp-contract=off, so a * b + c stays two
+// operations.
+template <bool FMA>
+__device__ __forceinline__ float mad_f32(float a, float b, float c) {
+    if constexpr (FMA) return __builtin_fmaf(a, b, c);
+    else return a * b + c;
+}
+
+// FMA: the polynomial's three multiply-adds fused (its last bit only: for integer gradients in [-255, 255] NO 36-bin or 8-bin
+// histogram index depends on it - tests/test_pin_readiness_cpu.py checks all 511 x 511 pairs - so the kernels that only BIN the
+// angle call the default form; k_level_gradients, which returns the angle itself, carries the switch)
+template <bool FMA = false>
 __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
     const float scale = (float)(180.0 / 3.14159265358979323846);
     const float p1 = 0.9997878412794807f * scale, p3 = -0.3258083974640975f * scale;
@@ -273,16 +288,17 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
     float a;
     if (ax >= ay) {
         const float c = ay / (ax + eps), c2 = c * c;
-        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+        a = mad_f32<FMA>(mad_f32<FMA>(mad_f32<FMA>(p7, c2, p5), c2, p3), c2, p1) * c;
     } else {
         const float c = ax / (ay + eps), c2 = c * c;
-        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+        a = 90.f - mad_f32<FMA>(mad_f32<FMA>(mad_f32<FMA>(p7, c2, p5), c2, p3), c2, p1) * c;
     }
     if (x < 0) a = 180.f - a;
     if (y < 0) a = 360.f - a;
     return a;
 }
 
+template <bool FMA>
 __global__ __launch_bounds__(256) void k_level_gradients(const uint8_t* __restrict__ g, int gpitch, int rows, int cols,
                                                           float* __restrict__ gx, float* __restrict__ gy,
                                                           float* __restrict__ mag, float* __restrict__ orient) {
@@ -299,7 +315,7 @@ __global__ __launch_bounds__(256) void k_level_gradients(const uint8_t* __restri
         const float xx = x * x, yy = y * y;
         mag[o] = sqrt_rn_small_nr(xx + yy);  // IEEE-correct f32 square root (the bare v_sqrt_f32 is not)
     }
-    if (orient) orient[o] = fast_atan2_deg(y, x);
+    if (orient) orient[o] = fast_atan2_deg<FMA>(y, x);
 }
 
 }  // namespace vslam

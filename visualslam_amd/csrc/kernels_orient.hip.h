@@ -67,7 +67,8 @@ __device__ __forceinline__ void bin_masks_to_lanes(int mybin, unsigned int& lo, 
     }
 }
 
-// grid = (keypoints), 256 threads, dynamic LDS = orient_lds_bytes(max R).
+// grid = (keypoints), 256 threads, dynamic LDS = orient_lds_bytes(max R).  FMA: the filter's multiply-adds fused (mad_f32).
+template <bool FMA>
 __global__ __launch_bounds__(256) void k_orient_keypoints(const vslam_point* __restrict__ kps, int n, OrientLevels lv, int gpitch, int rows, int cols,
                                                            unsigned long long* __restrict__ masks) {
     extern __shared__ __attribute__((aligned(16))) float orient_smem[];
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(256) void k_orient_keypoints(const vslam_point* __r
         const float* __restrict__ S = M + (size_t)sy * cols;
         float s0 = kl[0] * S[cx[c]];
 #pragma unroll 4
-        for (int i = 1; i < kn; ++i) s0 += kl[i] * S[cx[c + i]];
+        for (int i = 1; i < kn; ++i) s0 = mad_f32<FMA>(kl[i], S[cx[c + i]], s0);
         rb[it] = s0;
     }
     __syncthreads();
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(256) void k_orient_keypoints(const vslam_point* __r
         const int i = threadIdx.x >> 4, j = threadIdx.x & 15;
         float s0 = kl[R] * rb[(i + R) * OR_WIN + j];
 #pragma unroll 4
-        for (int t = 1; t <= R; ++t) s0 += kl[R + t] * (rb[(i + R + t) * OR_WIN + j] + rb[(i + R - t) * OR_WIN + j]);
+        for (int t = 1; t <= R; ++t) s0 = mad_f32<FMA>(kl[R + t], rb[(i + R + t) * OR_WIN + j] + rb[(i + R - t) * OR_WIN + j], s0);
         mw[threadIdx.x] = s0;
         const float reductionCoeff = (float)OR_BINS / 360.0f;  // :114
         const float o = lv.orient[level][(size_t)clampi(y + i - OR_PAD, 0, rows - 1) * cols + clampi(x + j - OR_PAD, 0, cols - 1)];

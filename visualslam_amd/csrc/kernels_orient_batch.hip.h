@@ -116,7 +116,8 @@ __global__ __launch_bounds__(128) void k_survivor_ranges(const vslam_point* __re
 }
 
 // grid = (G, frames), 256 threads, dynamic LDS = lds_floats * 4 bytes (row / column maps + taps + strip + region + patch);
-// the survivors of octave `oct` (ranges, k_survivor_ranges).
+// the survivors of octave `oct` (ranges, k_survivor_ranges).  FMA: the filter's multiply-adds fused (mad_f32, kernels_aux.hip.h).
+template <bool FMA>
 __global__ __launch_bounds__(256) void k_orient_survivors(const vslam_point* __restrict__ pts, unsigned int cap,
                                                            const unsigned int* __restrict__ surv, const unsigned int* __restrict__ ranges,
                                                            unsigned int scap, const uint8_t* __restrict__ pyr, size_t pframe,
@@ -203,14 +204,14 @@ __global__ __launch_bounds__(256) void k_orient_survivors(const vslam_point* __r
                 const float* __restrict__ S = M + rr * span + c;
                 float s0 = kl[0] * S[0];
 #pragma unroll 4
-                for (int i = 1; i < kn; ++i) s0 += kl[i] * S[i];
+                for (int i = 1; i < kn; ++i) s0 = mad_f32<FMA>(kl[i], S[i], s0);
                 rb[it] = s0;
             }
         } else {
             for (int it = threadIdx.x; it < span * OR_WIN; it += 256) {
                 const int rr = it >> 4, c = it & 15;
                 float s0 = kl[0] * magnitude_at(G, gpitch, rows, cols, ry[rr], cx[c]);
-                for (int i = 1; i < kn; ++i) s0 += kl[i] * magnitude_at(G, gpitch, rows, cols, ry[rr], cx[c + i]);
+                for (int i = 1; i < kn; ++i) s0 = mad_f32<FMA>(kl[i], magnitude_at(G, gpitch, rows, cols, ry[rr], cx[c + i]), s0);
                 rb[it] = s0;
             }
         }
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(256) void k_orient_survivors(const vslam_point* __r
             const int i = threadIdx.x >> 4, j = threadIdx.x & 15;
             float s0 = kl[R] * rb[(i + R) * OR_WIN + j];
 #pragma unroll 4
-            for (int t = 1; t <= R; ++t) s0 += kl[R + t] * (rb[(i + R + t) * OR_WIN + j] + rb[(i + R - t) * OR_WIN + j]);
+            for (int t = 1; t <= R; ++t) s0 = mad_f32<FMA>(kl[R + t], rb[(i + R + t) * OR_WIN + j] + rb[(i + R - t) * OR_WIN + j], s0);
             mw[threadIdx.x] = s0;
             float gx, gy;
             if (patch) {  // interior survivor: the window's pixels and their Sobel neighbours are in the staged patch

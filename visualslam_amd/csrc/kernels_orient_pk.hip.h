@@ -52,6 +52,24 @@ __device__ __forceinline__ vslam_f2 tap_mul(const vslam_f4& a, const vslam_f4& b
     else if constexpr (E < 6) return pk_mul_splat<E & 1>(vslam_f2{b.x, b.y}, w);
     else return pk_mul_splat<E & 1>(vslam_f2{b.z, b.w}, w);
 }
+// acc + tap E * w (FMA = false: v_pk_mul_f32 + v_pk_add_f32, each rounded) or fma(tap E, w, acc) (FMA = true: one v_pk_fma_f32)
+template <int SEL>
+__device__ __forceinline__ vslam_f2 pk_fma_splat(vslam_f2 k, vslam_f2 w, vslam_f2 acc) {
+    vslam_f2 r;
+    if constexpr (SEL == 0)
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(r) : "s"(k), "v"(w), "v"(acc));
+    else
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(r) : "s"(k), "v"(w), "v"(acc));
+    return r;
+}
+template <int E, bool FMA>
+__device__ __forceinline__ vslam_f2 tap_mac(const vslam_f4& a, const vslam_f4& b, vslam_f2 w, vslam_f2 acc) {
+    if constexpr (!FMA) return acc + tap_mul<E>(a, b, w);
+    else if constexpr (E < 2) return pk_fma_splat<E & 1>(vslam_f2{a.x, a.y}, w, acc);
+    else if constexpr (E < 4) return pk_fma_splat<E & 1>(vslam_f2{a.z, a.w}, w, acc);
+    else if constexpr (E < 6) return pk_fma_splat<E & 1>(vslam_f2{b.x, b.y}, w, acc);
+    else return pk_fma_splat<E & 1>(vslam_f2{b.z, b.w}, w, acc);
+}
 // {x.hi - y.lo, y.hi - x.lo}: the vertical differences of a row pair from {row, row + 1} and {row - 1, row + 2}
 __device__ __forceinline__ vslam_f2 pk_cross_diff(vslam_f2 x, vslam_f2 y) {
     vslam_f2 r;
@@ -99,7 +117,7 @@ __host__ __device__ inline int orient_pk_lds_floats(int span) {
 // the default pyramid's octave 0 are instantiated: loop bounds, guards and LDS offsets fold), 0 = read it from g.
 // At least six waves per SIMD (<= 85 vector registers): the unrolled instantiations otherwise take 90 - 124 and the registers, not
 // the LDS, would bound the workgroups per CU (28.7 -> 28.2 ms per dense step).
-template <int KN>
+template <int KN, bool FMA>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_orient_survivors_pk(const vslam_point* __restrict__ pts, unsigned int cap,
                                                               const unsigned int* __restrict__ surv, const unsigned int* __restrict__ ranges,
                                                               unsigned int scap, const uint8_t* __restrict__ pyr, size_t pframe,
@@ -271,10 +289,12 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
                     // all four words of the chunk at once (inside the region's allocation whatever nsteps is: column < MP);
                     // the ones past the row are not used
                     const vslam_f2 W0 = wb[w0], W1 = wb[w0 + 1], W2 = wb[w0 + 2], W3 = wb[w0 + 3];
-                    a0 += tap_mul<3>(ta, tb, W0), a1 += tap_mul<2>(ta, tb, W0), a2 += tap_mul<1>(ta, tb, W0), a3 += tap_mul<0>(ta, tb, W0);
-                    if (w0 + 1 < nsteps) a0 += tap_mul<4>(ta, tb, W1), a1 += tap_mul<3>(ta, tb, W1), a2 += tap_mul<2>(ta, tb, W1), a3 += tap_mul<1>(ta, tb, W1);
-                    if (w0 + 2 < nsteps) a0 += tap_mul<5>(ta, tb, W2), a1 += tap_mul<4>(ta, tb, W2), a2 += tap_mul<3>(ta, tb, W2), a3 += tap_mul<2>(ta, tb, W2);
-                    if (w0 + 3 < nsteps) a0 += tap_mul<6>(ta, tb, W3), a1 += tap_mul<5>(ta, tb, W3), a2 += tap_mul<4>(ta, tb, W3), a3 += tap_mul<3>(ta, tb, W3);
+                    // (a zero tap contributes +0 to a sum that never is -0 - the same value with or without fusing; the first
+                    // non-zero tap of an accumulator lands on 0: k * w + 0 = fma(k, w, 0) = the rounded product, as the reference's s0 = k[0] * S[0])
+                    a0 = tap_mac<3, FMA>(ta, tb, W0, a0), a1 = tap_mac<2, FMA>(ta, tb, W0, a1), a2 = tap_mac<1, FMA>(ta, tb, W0, a2), a3 = tap_mac<0, FMA>(ta, tb, W0, a3);
+                    if (w0 + 1 < nsteps) a0 = tap_mac<4, FMA>(ta, tb, W1, a0), a1 = tap_mac<3, FMA>(ta, tb, W1, a1), a2 = tap_mac<2, FMA>(ta, tb, W1, a2), a3 = tap_mac<1, FMA>(ta, tb, W1, a3);
+                    if (w0 + 2 < nsteps) a0 = tap_mac<5, FMA>(ta, tb, W2, a0), a1 = tap_mac<4, FMA>(ta, tb, W2, a1), a2 = tap_mac<3, FMA>(ta, tb, W2, a2), a3 = tap_mac<2, FMA>(ta, tb, W2, a3);
+                    if (w0 + 3 < nsteps) a0 = tap_mac<6, FMA>(ta, tb, W3, a0), a1 = tap_mac<5, FMA>(ta, tb, W3, a1), a2 = tap_mac<4, FMA>(ta, tb, W3, a2), a3 = tap_mac<3, FMA>(ta, tb, W3, a3);
                 }
                 float* d0 = rb + (2 * rp) * OR_WIN + 4 * cg;
                 *reinterpret_cast<vslam_f4*>(d0) = vslam_f4{a0.x, a1.x, a2.x, a3.x};
@@ -293,19 +313,19 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
                 const vslam_f4 ta = kc4[(t0 - 1) >> 2];  // k[R + t0 .. R + t0 + 3]
                 {
                     const vslam_f2 s2 = rc[t0 * 8] + rc[-t0 * 8];
-                    acc += tap_mul<0>(ta, ta, s2);
+                    acc = tap_mac<0, FMA>(ta, ta, s2, acc);
                 }
                 if (t0 + 1 <= R) {
                     const vslam_f2 s2 = rc[(t0 + 1) * 8] + rc[-(t0 + 1) * 8];
-                    acc += tap_mul<1>(ta, ta, s2);
+                    acc = tap_mac<1, FMA>(ta, ta, s2, acc);
                 }
                 if (t0 + 2 <= R) {
                     const vslam_f2 s2 = rc[(t0 + 2) * 8] + rc[-(t0 + 2) * 8];
-                    acc += tap_mul<2>(ta, ta, s2);
+                    acc = tap_mac<2, FMA>(ta, ta, s2, acc);
                 }
                 if (t0 + 3 <= R) {
                     const vslam_f2 s2 = rc[(t0 + 3) * 8] + rc[-(t0 + 3) * 8];
-                    acc += tap_mul<3>(ta, ta, s2);
+                    acc = tap_mac<3, FMA>(ta, ta, s2, acc);
                 }
             }
             *reinterpret_cast<vslam_f2*>(mw + i * OR_WIN + 2 * jp) = acc;

@@ -62,6 +62,7 @@ struct SiftShared {
     int badw[4];  // per wave: one of its 64 sample points lies outside the padded Mat
 };
 
+template <bool FMA>
 __device__ __forceinline__ void sift_one_keypoint(SiftShared& sh, const vslam_point kp, const float2 a, const uint8_t* __restrict__ G,
                                                   int gpitch, int rows, int cols, const float* __restrict__ k, int kn,
                                                   float* __restrict__ desc, uint8_t* __restrict__ defined) {
@@ -145,7 +146,7 @@ __device__ __forceinline__ void sift_one_keypoint(SiftShared& sh, const vslam_po
             const float* S = sh.ext + i * span + j;
             float s0 = ks[0] * S[0];
 #pragma unroll 4
-            for (int m = 1; m < kn; ++m) s0 += ks[m] * S[m];
+            for (int m = 1; m < kn; ++m) s0 = mad_f32<FMA>(ks[m], S[m], s0);
             // its value stands at every extended row position that reflects onto row i: R + i + 30 z and R - i + 30 z
             for (int p = (R + i) % PER; p < span; p += PER) sh.extc[p * SIFT_WIN + j] = s0;
             if (i != 0 && i != SIFT_WIN - 1) {
@@ -159,7 +160,7 @@ __device__ __forceinline__ void sift_one_keypoint(SiftShared& sh, const vslam_po
             const float* C = sh.extc + (R + i) * SIFT_WIN + j;
             float s0 = ks[R] * C[0];
 #pragma unroll 4
-            for (int m = 1; m <= R; ++m) s0 += ks[R + m] * (C[m * SIFT_WIN] + C[-m * SIFT_WIN]);
+            for (int m = 1; m <= R; ++m) s0 = mad_f32<FMA>(ks[R + m], C[m * SIFT_WIN] + C[-m * SIFT_WIN], s0);
             sh.mw[t] = s0;
         }
     } else if (kn <= SIFT_KMAX) {
@@ -177,7 +178,7 @@ __device__ __forceinline__ void sift_one_keypoint(SiftShared& sh, const vslam_po
 #pragma unroll 4
             for (int m = 1; m < kn; ++m) {
                 q = q + 1 == PER ? 0 : q + 1;
-                s0 += sh.kt[m] * S[q < SIFT_WIN ? q : PER - q];
+                s0 = mad_f32<FMA>(sh.kt[m], S[q < SIFT_WIN ? q : PER - q], s0);
             }
             sh.rowf[t] = s0;
         }
@@ -189,7 +190,7 @@ __device__ __forceinline__ void sift_one_keypoint(SiftShared& sh, const vslam_po
             for (int m = 1; m <= R; ++m) {
                 qp = qp + 1 == PER ? 0 : qp + 1;
                 qm = qm == 0 ? PER - 1 : qm - 1;
-                s0 += sh.kt[R + m] * (sh.rowf[(qp < SIFT_WIN ? qp : PER - qp) * SIFT_WIN + j] + sh.rowf[(qm < SIFT_WIN ? qm : PER - qm) * SIFT_WIN + j]);
+                s0 = mad_f32<FMA>(sh.kt[R + m], sh.rowf[(qp < SIFT_WIN ? qp : PER - qp) * SIFT_WIN + j] + sh.rowf[(qm < SIFT_WIN ? qm : PER - qm) * SIFT_WIN + j], s0);
             }
             sh.mw[t] = s0;
         }
@@ -197,14 +198,14 @@ __device__ __forceinline__ void sift_one_keypoint(SiftShared& sh, const vslam_po
         {
             const float* S = sh.mag + i * SIFT_WIN;
             float s0 = k[0] * S[reflect101(j - R, SIFT_WIN)];
-            for (int m = 1; m < kn; ++m) s0 += k[m] * S[reflect101(j + m - R, SIFT_WIN)];
+            for (int m = 1; m < kn; ++m) s0 = mad_f32<FMA>(k[m], S[reflect101(j + m - R, SIFT_WIN)], s0);
             sh.rowf[t] = s0;
         }
         __syncthreads();
         {
             float s0 = k[R] * sh.rowf[i * SIFT_WIN + j];
             for (int m = 1; m <= R; ++m)
-                s0 += k[R + m] * (sh.rowf[reflect101(i + m, SIFT_WIN) * SIFT_WIN + j] + sh.rowf[reflect101(i - m, SIFT_WIN) * SIFT_WIN + j]);
+                s0 = mad_f32<FMA>(k[R + m], sh.rowf[reflect101(i + m, SIFT_WIN) * SIFT_WIN + j] + sh.rowf[reflect101(i - m, SIFT_WIN) * SIFT_WIN + j], s0);
             sh.mw[t] = s0;
         }
     }
@@ -247,6 +248,7 @@ __device__ __forceinline__ void sift_one_keypoint(SiftShared& sh, const vslam_po
 }
 
 // Per-image entry point: grid = (keypoints), block = 256.  cs[q] = (cos, sin) of keypoint q's angle.
+template <bool FMA>  // the f32 filter's multiply-adds fused (mad_f32, kernels_aux.hip.h)
 __global__ __launch_bounds__(256) void k_sift_descriptors(const vslam_point* __restrict__ kps, const float2* __restrict__ cs, int n, SiftLevels lv,
                                                            int gpitch, int rows, int cols, float* __restrict__ desc,
                                                            uint8_t* __restrict__ defined) {
@@ -254,7 +256,7 @@ __global__ __launch_bounds__(256) void k_sift_descriptors(const vslam_point* __r
     const int q = blockIdx.x;
     const vslam_point kp = kps[q];
     const int level = __builtin_amdgcn_readfirstlane(kp.level);
-    sift_one_keypoint(sh, kp, cs[q], lv.gauss[level], gpitch, rows, cols, lv.kern[level], lv.kn[level],
+    sift_one_keypoint<FMA>(sh, kp, cs[q], lv.gauss[level], gpitch, rows, cols, lv.kern[level], lv.kn[level],
                       desc + (size_t)q * SIFT_DESC, defined ? defined + q : nullptr);
 }
 
@@ -273,6 +275,7 @@ struct SiftBatchGeom {
 
 // Eight workgroups per CU (the wave limit): 16.8 KB of LDS each - the two filter forms share their arrays - and at most 64
 // vector registers (57 used, nothing spilled); with 20.3 KB and 73 registers it was seven, and 8.4 ms per dense step against 7.1.
+template <bool FMA>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_sift_descriptors_batch(const vslam_point* __restrict__ oriented, const unsigned int* __restrict__ counts,
                                                                  unsigned int cap, const uint8_t* __restrict__ pyr, size_t pframe,
                                                                  SiftBatchGeom g, float* __restrict__ desc, uint8_t* __restrict__ defined) {
@@ -287,7 +290,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         const int o = __builtin_amdgcn_readfirstlane(kp.octave), level = __builtin_amdgcn_readfirstlane(kp.level);  // one record per workgroup: scalar
         const uint8_t* G = pyr + f * pframe + g.oct_off[o] + (size_t)level * g.rows[o] * g.pitch[o];
         const unsigned int b = (unsigned int)__builtin_amdgcn_readfirstlane(kp.value) / 10u;
-        sift_one_keypoint(sh, kp, g.cs36[b < 36u ? b : 0u], G, g.pitch[o], g.rows[o], g.cols[o], g.kern[o][level], g.kn[o][level],
+        sift_one_keypoint<FMA>(sh, kp, g.cs36[b < 36u ? b : 0u], G, g.pitch[o], g.rows[o], g.cols[o], g.kern[o][level], g.kn[o][level],
                           desc + ((size_t)f * cap + q) * SIFT_DESC, defined ? defined + (size_t)f * cap + q : nullptr);
     }
 }

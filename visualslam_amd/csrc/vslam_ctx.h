@@ -95,6 +95,10 @@ struct vslam_ctx {
     std::map<std::pair<uint64_t, int>, void*> tile_taps;        // (sigma0 bits, octave) -> PyrTaps<CFG>
     // OPT-IN matrix-core form of the LDS-tiled octave kernels (VSLAM_MX=1 / vslam_ctx_set_matrix_path): never the default
     bool mx = false;
+    // vslam_ctx_set_f32_fused / VSLAM_F32_FUSED=1: the f32 stages (separable f32 filter of filterKeypoints / SIFT, the arctangent of
+    // processGradients) with fused multiply-adds, as an OpenCV that dispatches its AVX2 + FMA3 code computes them (default: every
+    // product and sum rounded, OpenCV's SSE2 baseline)
+    bool f32_fused = false;
     bool orient_scalar_form = false;  // VSLAM_ORIENT_SCALAR=1: k_orient_survivors for every octave (the round-3 form, kept for comparison)
     std::map<std::pair<uint64_t, int>, void*> mx_taps;          // (sigma0 bits, octave) -> MxTaps<CFG>
     // auxiliary streams of the batched path: the HBM-bound chains (Harris; extrema + compaction)
@@ -110,6 +114,7 @@ struct vslam_ctx {
     JoinWatch watch;      // steps the side streams down when their join lags (see JoinWatch)
     hipEvent_t ev_phase = nullptr;  // recorded by every vslam_detect_batch_dev call once its octave-0 kernels are enqueued (vslam_ctx_follow)
     bool phase_marked = false;
+    int batch_calls = 0;  // vslam_detect_batch_dev calls so far
     hipEvent_t ev_up2 = nullptr;  // the second half of a batch has been upsampled (enqueue_dog)
     hipEvent_t ev_chunk = nullptr;  // the main-stream kernels of a chunk (the readers of the octave bases) are enqueued up to here
     // matrix path, fused lattice scan: the side stream's k_extrema_pack launches of a chunk have read the site / seam maps

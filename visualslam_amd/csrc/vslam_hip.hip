@@ -607,6 +607,24 @@ static int mark_phase(vslam_ctx* c) {
     return VSLAM_OK;
 }
 
+// Diagnostics build only: VSLAM_DIAG_SKIP_SCAN="<octave mask>,<n>" leaves the plain lattice scan (k_extrema_w3) of the octaves in
+// the mask out of every batch call of a context after its n-th - a TIMING knock-out (profiles/r06_scan_knockout.txt: the upper
+// bound of what folding that scan into the octave kernel could win).  The list kernels then compact the flag words the earlier
+// calls left, so their work is unchanged when the frames are.  Never in the shipped library.
+static bool diag_skip_scan(const vslam_ctx* c, int octave) {
+    static const std::pair<unsigned, int> cfg = [] {
+        const char* e = VSLAM_DIAG_ENV("VSLAM_DIAG_SKIP_SCAN");
+        unsigned mask = 0;
+        int after = 0;
+        if (e) {
+            mask = (unsigned)std::strtoul(e, nullptr, 0);
+            if (const char* comma = std::strchr(e, ',')) after = std::atoi(comma + 1);
+        }
+        return std::make_pair(mask, after);
+    }();
+    return cfg.first && ((cfg.first >> octave) & 1u) && c->batch_calls > cfg.second;
+}
+
 static int dog_side_gate(const vslam_params& p, const vslam_batch_layout& L, int nf) {
     int gate = -1;
     if (nf >= 32)
@@ -813,6 +831,8 @@ static int enqueue_dog(vslam_ctx* c, const vslam_params& p, const vslam_batch_la
                     HIPCHK(c, hipEventRecord(c->ev_pack, es));
                     c->pack_pending = true;
                 }
+            } else if (p.extrema_window == 3 && diag_skip_scan(c, o)) {
+                // (diagnostics build, VSLAM_DIAG_SKIP_SCAN: timing knock-out - the flag words keep what an earlier call wrote)
             } else if (p.extrema_window == 3) {
                 const dim3 eg((L.lat_words[o] + 3) / 4, L.lat_rows[o], nf);
                 TimedScope ts(c, "k_extrema_w3", o, es);
@@ -939,6 +959,8 @@ int vslam_ctx_create(int device, void* stream, vslam_ctx** out) {
     {
         const char* e = std::getenv("VSLAM_MX");
         c->mx = e && e[0] == '1';
+        const char* ff = std::getenv("VSLAM_F32_FUSED");
+        c->f32_fused = ff && ff[0] == '1';
         const char* es = VSLAM_DIAG_ENV("VSLAM_ORIENT_SCALAR");
         c->orient_scalar_form = es && es[0] == '1';
         sched_init_from_env(c);
@@ -954,6 +976,14 @@ int vslam_ctx_set_matrix_path(vslam_ctx* c, int on) {
 }
 
 int vslam_ctx_get_matrix_path(const vslam_ctx* c) { return c && c->mx ? 1 : 0; }
+
+int vslam_ctx_set_f32_fused(vslam_ctx* c, int on) {
+    if (!c) return VSLAM_ERR_INVALID;
+    c->f32_fused = on != 0;
+    return VSLAM_OK;
+}
+
+int vslam_ctx_get_f32_fused(const vslam_ctx* c) { return c && c->f32_fused ? 1 : 0; }
 
 int vslam_ctx_destroy(vslam_ctx* c) {
     if (!c) return VSLAM_ERR_INVALID;
@@ -1324,8 +1354,10 @@ int vslam_pyramid_get_gradients(const vslam_pyramid* py, int octave, int level, 
     }
     const int pitch = py->layout.pitch[octave];
     const uint8_t* g = py->d_block + py->layout.octave_offset[octave] + (size_t)level * rows * pitch;
-    LAUNCH(c, "k_level_gradients", k_level_gradients, grid_rows(cols, rows), dim3(256), g, pitch, rows, cols, dev[0], dev[1], dev[2],
-           dev[3]);
+    if (c->f32_fused)
+        LAUNCH(c, "k_level_gradients", k_level_gradients<true>, grid_rows(cols, rows), dim3(256), g, pitch, rows, cols, dev[0], dev[1], dev[2], dev[3]);
+    else
+        LAUNCH(c, "k_level_gradients", k_level_gradients<false>, grid_rows(cols, rows), dim3(256), g, pitch, rows, cols, dev[0], dev[1], dev[2], dev[3]);
     for (int i = 0; i < 4; ++i)
         if (host[i]) TRY(d2h(c, host[i], dst_step, dev[i], 4 * (size_t)cols, 4 * (size_t)cols, rows));
     return vslam_ctx_sync(c);
@@ -1489,7 +1521,8 @@ int vslam_filter_keypoints(vslam_ctx* c, const vslam_pyramid* py, int octave, co
         float* d_ori = ws_take<float>(c, P);
         const uint8_t* g = py->d_block + py->layout.octave_offset[octave] + (size_t)l * rows * pitch;
         // processGradients for the level (GaussPyramid.cpp:65-104): magnitude and orientation only
-        LAUNCH(c, "k_level_gradients", k_level_gradients, grid_rows(cols, rows), dim3(256), g, pitch, rows, cols, (float*)nullptr,
+        // (the orientation image is only BINNED here: no bin depends on the arctangent's variant, kernels_aux.hip.h)
+        LAUNCH(c, "k_level_gradients", k_level_gradients<false>, grid_rows(cols, rows), dim3(256), g, pitch, rows, cols, (float*)nullptr,
                (float*)nullptr, d_mag, d_ori);
         HIPCHK(c, hipMemcpyAsync(d_taps + toff, taps[l].data(), 4 * taps[l].size(), hipMemcpyHostToDevice, c->stream));
         lv.gauss[l] = g;
@@ -1499,10 +1532,11 @@ int vslam_filter_keypoints(vslam_ctx* c, const vslam_pyramid* py, int octave, co
         lv.kn[l] = (int)taps[l].size();
         toff += align_up(taps[l].size(), 64);
     }
-    TRY(raise_dyn_lds(c, reinterpret_cast<const void*>(&k_orient_keypoints)));
+    const auto k_orient = c->f32_fused ? k_orient_keypoints<true> : k_orient_keypoints<false>;
+    TRY(raise_dyn_lds(c, reinterpret_cast<const void*>(k_orient)));
     {
         TimedScope ts(c, "k_orient_keypoints");
-        hipLaunchKernelGGL(k_orient_keypoints, dim3((unsigned)n), dim3(256), lds, c->stream, d_kps, (int)n, lv, pitch, rows, cols, d_masks);
+        hipLaunchKernelGGL(k_orient, dim3((unsigned)n), dim3(256), lds, c->stream, d_kps, (int)n, lv, pitch, rows, cols, d_masks);
     }
     HIPCHK(c, hipGetLastError());
     OrientEntries ent{d_masks, d_kps, n, d_out};
@@ -1563,7 +1597,10 @@ int vslam_sift_descriptors(vslam_ctx* c, const vslam_pyramid* py, int octave, co
         lv.kn[l] = (int)taps[l].size();
         toff += align_up(taps[l].size(), 64);
     }
-    LAUNCH(c, "k_sift_descriptors", k_sift_descriptors, dim3((unsigned)n), dim3(256), d_kps, d_cs, (int)n, lv, pitch, rows, cols, d_desc, d_def);
+    if (c->f32_fused)
+        LAUNCH(c, "k_sift_descriptors", k_sift_descriptors<true>, dim3((unsigned)n), dim3(256), d_kps, d_cs, (int)n, lv, pitch, rows, cols, d_desc, d_def);
+    else
+        LAUNCH(c, "k_sift_descriptors", k_sift_descriptors<false>, dim3((unsigned)n), dim3(256), d_kps, d_cs, (int)n, lv, pitch, rows, cols, d_desc, d_def);
     std::vector<uint8_t> h_def(n);
     HIPCHK(c, hipMemcpyAsync(desc, d_desc, sizeof(float) * 128 * n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(h_def.data(), d_def, n, hipMemcpyDeviceToHost, c->stream));
@@ -1737,7 +1774,8 @@ static int enqueue_orient_batch(vslam_ctx* c, const vslam_params& p, const vslam
     SurvivorEntries se{s.flags, fw, s.surv};
     TRY(enqueue_compaction(c, se, fw, nf, s.cws, (unsigned int)scap, s.scounts, 0));
     LAUNCH(c, "k_survivor_ranges", k_survivor_ranges, dim3(nf), dim3(128), points, p.dog_cap, s.surv, s.scounts, (unsigned int)scap, L.n_octaves, s.ranges);
-    TRY(raise_dyn_lds(c, reinterpret_cast<const void*>(&k_orient_survivors)));
+    const auto k_surv = c->f32_fused ? k_orient_survivors<true> : k_orient_survivors<false>;
+    TRY(raise_dyn_lds(c, reinterpret_cast<const void*>(k_surv)));
     const int gwg = (int)std::min<long>(1024, std::max<long>(16, 8192 / nf));
     // The launches below are independent (each takes its own survivors, each writes its own mask words) and every one ends
     // on a tail of half-empty CUs: with two idle side streams at hand (the Harris chain's and the upsample's: both are
@@ -1758,19 +1796,23 @@ static int enqueue_orient_batch(vslam_ctx* c, const vslam_params& p, const vslam
                 // launch ended on a long tail of half-empty CUs: 9.0 ms of these launches per 256-frame step against 8.4
                 constexpr int pk_mult = 8;
                 for (int l = 1; l <= 3; ++l) {
-                    auto kfn = k_orient_survivors_pk<0>;
-                    switch (g.kn[o][l]) {  // the default pyramid's octave 0 (sigma0 = 1.6) with its tap counts compiled in: 6.85 -> 6.5 ms per step
-                        case 25: kfn = k_orient_survivors_pk<25>; break;
-                        case 31: kfn = k_orient_survivors_pk<31>; break;
-                        case 39: kfn = k_orient_survivors_pk<39>; break;
-                        default: break;
+                    auto kfn = k_orient_survivors_pk<0, false>;
+                    if (c->f32_fused) {  // (vslam_ctx_set_f32_fused: the multiply-adds of the blur as v_pk_fma_f32; the generic tap count serves every level)
+                        kfn = k_orient_survivors_pk<0, true>;
+                    } else {
+                        switch (g.kn[o][l]) {  // the default pyramid's octave 0 (sigma0 = 1.6) with its tap counts compiled in: 6.85 -> 6.5 ms per step
+                            case 25: kfn = k_orient_survivors_pk<25, false>; break;
+                            case 31: kfn = k_orient_survivors_pk<31, false>; break;
+                            case 39: kfn = k_orient_survivors_pk<39, false>; break;
+                            default: break;
+                        }
                     }
                     hipLaunchKernelGGL(kfn, dim3(pk_mult * gwg, nf), dim3(128), (size_t)orient_pk_lds_floats(OR_WIN + 2 * (g.kn[o][l] / 2)) * 4,
                                        lanes[next++ % 3], points, p.dog_cap, s.surv, s.ranges, (unsigned int)scap, pyr, pframe, g, o, l, s.masks);
                 }
                 continue;
             }
-            hipLaunchKernelGGL(k_orient_survivors, dim3(gwg, nf), dim3(256), (size_t)pl.need[o] * 4, lanes[next++ % 3], points, p.dog_cap, s.surv, s.ranges,
+            hipLaunchKernelGGL(k_surv, dim3(gwg, nf), dim3(256), (size_t)pl.need[o] * 4, lanes[next++ % 3], points, p.dog_cap, s.surv, s.ranges,
                                (unsigned int)scap, pyr, pframe, g, pl.need[o], o, s.masks);
         }
     }
@@ -1804,8 +1846,10 @@ static int enqueue_sift_batch(vslam_ctx* c, const vslam_params& p, const vslam_b
     // 8 x 32 workgroups per frame at 256 frames (~120 points each on a dense frame): with 32 the launch ended on a tail of
     // half-empty CUs (11.3 ms per 256-frame step against 10.1)
     const int gwg = 8 * (int)std::min<long>(1024, std::max<long>(16, 8192 / nf));
-    LAUNCH(c, "k_sift_descriptors", k_sift_descriptors_batch, dim3(gwg, nf), dim3(256), oriented, ocounts, p.oriented_cap, pyr, pframe, g, desc,
-           defined);
+    if (c->f32_fused)
+        LAUNCH(c, "k_sift_descriptors", k_sift_descriptors_batch<true>, dim3(gwg, nf), dim3(256), oriented, ocounts, p.oriented_cap, pyr, pframe, g, desc, defined);
+    else
+        LAUNCH(c, "k_sift_descriptors", k_sift_descriptors_batch<false>, dim3(gwg, nf), dim3(256), oriented, ocounts, p.oriented_cap, pyr, pframe, g, desc, defined);
     return VSLAM_OK;
 }
 
@@ -1864,6 +1908,7 @@ int vslam_detect_batch_dev(vslam_ctx* c, const vslam_params* pp, const uint8_t* 
                 ws_need(4 * compaction_ws_elems(harris_flag_words(p.rows, p.cols), chunk));
     if (orient) need += orient_scratch_bytes(p, chunk);
     c->phase_marked = false;
+    ++c->batch_calls;
     c->pack_pending = false;  // the previous call joined its side streams back
     TRY(ws_reserve(c, need));
     DogScratch s;
