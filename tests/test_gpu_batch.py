@@ -882,6 +882,27 @@ def test_matrix_core_octave_kernel_matches_oracle():
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
 
+def test_matrix_path_on_16x16x64_tiles_matches_oracle():
+    # round 6: the second MFMA shape of octaves 0-1 (kernels_pyramid_mx16.hip.h: v_mfma_i32_16x16x64_i8, four accumulator registers,
+    # <= 128 vector registers, the operand fragments in LDS) - at parity with the 32-wide form, so it lives in the diagnostics build
+    # only (VSLAM_MX_FORM=16).  One child process runs every test that is parametrised over the two kernel families, the reference
+    # images and the per-image pyramid tests under it: the same oracle comparisons, bit for bit.
+    import os
+    import subprocess
+    import sys
+
+    if os.environ.get("VSLAM_MX_FORM") == "16":
+        pytest.skip("already inside the 16-wide run")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VSLAM_MX="1", VSLAM_MX_FORM="16", VSLAM_LIBRARY=capi.DIAG_LIB_PATH)
+    sel = "mx or matrix_kernel_is_dispatched or batch_on_the_reference_images or pyramid or golden_fixtures or two_chunks"
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_batch.py"),
+                        os.path.join(root, "tests", "test_gpu_ref_images.py"), os.path.join(root, "tests", "test_gpu_parity.py"),
+                        os.path.join(root, "tests", "test_gpu_large.py"), "-m", "gpu", "-q", "-x", "-k", sel],
+                       capture_output=True, text=True, timeout=1500, env=env, cwd=root)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 def test_matrix_kernel_is_dispatched_when_asked_for(env):
     import os
 

@@ -51,6 +51,7 @@ __device__ __forceinline__ uint32_t mx_pk_sub_sat_u16(uint32_t a, uint32_t b) { 
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(mx_us2, a), __builtin_bit_cast(mx_us2, b)));
 }
 
+constexpr int MX_SITE_PAIRS_32 = 6;  // 11 lattice rows per 32-row strip, two per register
 typedef int mx_v4i __attribute__((ext_vector_type(4)));
 typedef int mx_v16i __attribute__((ext_vector_type(16)));
 
@@ -60,6 +61,7 @@ struct MxCfg {
     // 1: separate LDS buffers for a level's G and D strips; 0: one buffer, D waits in registers and follows G through it
     // (same box, octaves 0 + 1 of 256 x 1080p alone: 8.0 ms per step with two buffers, 9.35 ms with one - two where they fit)
     static constexpr int DBUF = DBUF_;
+    static constexpr int SITE_PAIRS = MX_SITE_PAIRS_32;  // the fused scan: 11 lattice rows per 32-row strip, two per register
     static constexpr int SW = TW / NWX;   // columns of a wave's strip
     static constexpr int NWY = TH / 32;
     static constexpr int NW = NWX * NWY, NT = 64 * NW;
@@ -246,11 +248,13 @@ __device__ __forceinline__ uint32_t mx_up_pixel(const uint8_t* __restrict__ s, i
 // (thread = row segment * (RW / 8) + column group): a sliding pass down 8 source rows (+ one above, one below) where the
 // item's rows and columns lie inside the upsampled image; row by row (two source rows recomputed per base row) where some of
 // its rows are BORDER_REFLECT_101 images of rows inside; pixel by pixel where its columns are.
-template <int TW, int TH, int R, int RWP, int NT>
+// QU: unroll factor of the sliding pass over an item's four row quads (4: the 250-register kernels; 1: kernels held to 128 registers)
+// SQ: row quads per staging item (4: items of 16 rows; 2: items of 8 rows - twice the items, for workgroups of 512 threads)
+template <int TW, int TH, int R, int RWP, int NT, int QU = 4, int SQ = 4>
 __device__ __forceinline__ void mx_stage_tile_up2(const uint8_t* __restrict__ s, int sstep, int rows_s, int cols_s, int tile_x0, int tile_y0,
                                                   uint32_t* __restrict__ rp, uint32_t bias) {
-    constexpr int RW = TW + 2 * R, RH = TH + 2 * R, NG = RW / 8, NSEG = RH / 16;
-    static_assert(RW % 8 == 0 && RH % 16 == 0, "16 x 8 staging items");
+    constexpr int RW = TW + 2 * R, RH = TH + 2 * R, NG = RW / 8, NSEG = RH / (4 * SQ);
+    static_assert(RW % 8 == 0 && RH % (4 * SQ) == 0 && (SQ == 2 || SQ == 4), "staging items of 4 SQ rows x 8 columns");
     const int H2 = 2 * rows_s, W2 = 2 * cols_s;
     // Items whose eight columns lie wholly left or right of the image are BORDER_REFLECT_101 images of columns this tile
     // stages anyway: they are skipped here and filled afterwards by dword copies inside LDS (a column of the byte-transposed
@@ -262,7 +266,7 @@ __device__ __forceinline__ void mx_stage_tile_up2(const uint8_t* __restrict__ s,
     const bool mir_r = x_hi > W2 && 2 * (W2 - 1) - (x_hi - 1) >= max(x_lo, 0);
     for (int it = threadIdx.x; it < NSEG * NG; it += NT) {
         const int seg = it / NG, g = it - seg * NG;
-        const int by = tile_y0 - R + 16 * seg, bx = tile_x0 - R + 8 * g;  // both even
+        const int by = tile_y0 - R + 4 * SQ * seg, bx = tile_x0 - R + 8 * g;  // both even
         if ((mir_l && bx + 7 < 0) || (mir_r && bx >= W2)) continue;
         // four base rows of the item (8 columns each): two 4 x 4 byte transposes, 8 columns x 4 vertical pixels = two 16-byte LDS stores
         auto put_quad = [&](int q, const uint2& a0, const uint2& a1, const uint2& a2, const uint2& a3) {
@@ -276,20 +280,20 @@ __device__ __forceinline__ void mx_stage_tile_up2(const uint8_t* __restrict__ s,
                 t.y = __builtin_amdgcn_perm(p23l, p01l, 0x07060302) ^ bias;
                 t.z = __builtin_amdgcn_perm(p23h, p01h, 0x05040100) ^ bias;
                 t.w = __builtin_amdgcn_perm(p23h, p01h, 0x07060302) ^ bias;
-                *reinterpret_cast<uint4*>(rp + (4 * seg + q) * RWP + 8 * g + 4 * hh) = t;
+                *reinterpret_cast<uint4*>(rp + (SQ * seg + q) * RWP + 8 * g + 4 * hh) = t;
             }
         };
         if (bx >= 0 && bx + 7 < W2) {
             const int c0 = bx >> 1;
-            if (by >= 0 && by + 15 < H2) {
+            if (by >= 0 && by + 4 * SQ - 1 < H2) {
                 const int m0 = by >> 1;
                 uint32_t Ap[4], Ac[4], An[4], Xp[4], Yc[4], Xc[4];
                 mx_up_hrow(s, sstep, rows_s, cols_s, m0 - 1, c0, Ap);
                 mx_up_hrow(s, sstep, rows_s, cols_s, m0, c0, Ac);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) Xp[i] = mx_pk_lshr2_u16(Ap[i]), Xc[i] = mx_pk_lshr2_u16(Ac[i]), Yc[i] = mx_pk_lshr2_u16(Ac[i] + (Ac[i] << 1));
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
+#pragma unroll QU
+                for (int q = 0; q < SQ; ++q) {
                     uint2 row[4];
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
@@ -306,7 +310,7 @@ __device__ __forceinline__ void mx_stage_tile_up2(const uint8_t* __restrict__ s,
                 }
             } else {
 #pragma unroll 1
-                for (int q = 0; q < 4; ++q) {
+                for (int q = 0; q < SQ; ++q) {
                     uint2 row[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -326,9 +330,19 @@ __device__ __forceinline__ void mx_stage_tile_up2(const uint8_t* __restrict__ s,
                     put_quad(q, row[0], row[1], row[2], row[3]);
                 }
             }
+        } else if constexpr (QU < 4) {
+            // (a 128-register kernel: the unrolled form below keeps 32 pixel evaluations in flight and took 114 registers more than
+            // there are; this branch runs for the few items that straddle an image edge - byte by byte into the transposed tile)
+#pragma unroll 1
+            for (int rr = 0; rr < 4 * SQ; ++rr) {
+                const int yr = mx_reflect101(by + rr, H2);
+                uint8_t* dst = reinterpret_cast<uint8_t*>(rp + (SQ * seg + (rr >> 2)) * RWP + 8 * g) + (rr & 3);
+#pragma unroll 1
+                for (int k = 0; k < 8; ++k) dst[4 * k] = (uint8_t)(mx_up_pixel(s, sstep, rows_s, cols_s, yr, mx_reflect101(bx + k, W2)) ^ (bias & 0xffu));
+            }
         } else {
 #pragma unroll 1
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < SQ; ++q) {
                 uint2 row[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -391,9 +405,10 @@ __device__ __forceinline__ uint32_t mx_pk_sub_u16(uint32_t a, uint32_t b) {
     return __builtin_bit_cast(uint32_t, __builtin_bit_cast(mx_us2b, a) - __builtin_bit_cast(mx_us2b, b));
 }
 
-constexpr int MX_SITE_PAIRS = 6;  // 11 lattice rows per 32-row strip, two per register
+constexpr int MX_SITE_PAIRS = MX_SITE_PAIRS_32;
 
-struct MxSites {
+template <int PAIRS>
+struct MxSitesT {
     const uint8_t* slr;   // LDS: this lane's dword of column 3b-1 in row r0 of the wave's D buffer (r0 = image row 3 a_first - 1, may be -1)
     const uint8_t* sla0;  // ... in row max(r0, 0): the upper row of the strip's first lattice row
     uint32_t sel;         // v_perm selector: (column 3b-1, 0, column 3b, 0) of a dword pair
@@ -405,18 +420,19 @@ struct MxSites {
     uint32_t clevel;      // bytes per level of the seam map
     uint32_t mc2;         // min_contrast in both 16-bit lanes
     // 2 x 2 minima, maxima and centre values of the two previous DoG levels (slot = level % 2), two lattice rows per register
-    uint32_t mn[2][MX_SITE_PAIRS], mx[2][MX_SITE_PAIRS], sf[2][MX_SITE_PAIRS], out[MX_SITE_PAIRS];
+    uint32_t mn[2][PAIRS], mx[2][PAIRS], sf[2][PAIRS], out[PAIRS];
 };
+using MxSites = MxSitesT<MX_SITE_PAIRS>;
 
 // DoG level l of the strip is in the wave's D buffer: the 2 x 2 minimum, maximum and the centre value of every owned site;
 // from level 2 on, with the two levels before it, the candidate and list bits of centre level c = l - 1 (bits 2(c-1),
 // 2(c-1)+1 of the site's byte); then level l takes the place of level l - 2.
 template <class CFG, int l>
-__device__ __forceinline__ void mx_sites_level(MxSites& st) {
+__device__ __forceinline__ void mx_sites_level(MxSitesT<CFG::SITE_PAIRS>& st) {
     constexpr int RB = CFG::OBP * 4;  // bytes per buffered row
     constexpr int old = l % 2, mid = (l + 1) % 2;  // slots of levels l - 2 and l - 1
 #pragma unroll
-    for (int p = 0; p < MX_SITE_PAIRS; ++p) {
+    for (int p = 0; p < CFG::SITE_PAIRS; ++p) {
         uint32_t lo[2], hi[2], v1[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -448,10 +464,11 @@ __device__ __forceinline__ void mx_sites_level(MxSites& st) {
     }
 }
 
-__device__ __forceinline__ void mx_sites_store(const MxSites& st) {
+template <int PAIRS>
+__device__ __forceinline__ void mx_sites_store(const MxSitesT<PAIRS>& st) {
     if (!st.smap) return;
 #pragma unroll
-    for (int p = 0; p < MX_SITE_PAIRS; ++p) {
+    for (int p = 0; p < PAIRS; ++p) {
         if (2 * p < st.nk) st.smap[(size_t)(2 * p) * st.mpitch] = (uint8_t)st.out[p];
         if (2 * p + 1 < st.nk) st.smap[(size_t)(2 * p + 1) * st.mpitch] = (uint8_t)(st.out[p] >> 16);
     }

@@ -707,6 +707,7 @@ static int enqueue_dog(vslam_ctx* c, const vslam_params& p, const vslam_batch_la
         HIPCHK(c, hipEventRecord(c->ev_up2, c->stream));
     }
     bool fused[VSLAM_MAX_OCTAVES] = {};
+    int fused_rows[VSLAM_MAX_OCTAVES] = {};  // rows of a wave's strip in the octave kernel that ran the fused scan (32, or 16 for the 16 x 16 x 64 form)
     // a later chunk reuses the site / seam maps: its octave kernels (main stream) must not overwrite them while the previous
     // chunk's k_extrema_pack launches (side stream, low priority, possibly on a slow hardware queue) are still reading
     if (later_chunk && c->pack_pending) {
@@ -747,6 +748,7 @@ static int enqueue_dog(vslam_ctx* c, const vslam_params& p, const vslam_batch_la
             scan = MxScan{s.sitemap + s.site_off[o], s.site_frame, L.lat_rows[o], L.lat_cols[o], s.site_pitch[o], p.min_contrast,
                           s.colmap + s.col_off[o], s.col_frame, mx_seams(cols)};
         fused[o] = fused_scan;
+        fused_rows[o] = fused_scan ? mx_strip_rows(mx_config_for(pl.ke)) : 0;
         // frames [f_lo, f_lo + n) of this octave through the LDS-tiled kernel
         auto tiled = [&](int f_lo, int n) -> int {
             const uint8_t* b = base + (size_t)f_lo * s.bases_frame;
@@ -818,15 +820,16 @@ static int enqueue_dog(vslam_ctx* c, const vslam_params& p, const vslam_batch_la
                 {
                     TimedScope ts(c, "k_extrema_pack", o, es);
                     HIPCHK(c, mx_launch_pack(es, sc, L.rows[o], L.lat_words[o], nf, bits ? bits + L.bits_offset[o] : nullptr, s.lflags + L.bits_offset[o],
-                                             L.bits_frame_words));
+                                             L.bits_frame_words, fused_rows[o]));
                 }
-                // the lattice rows whose windows straddle a strip's first image row (every 32nd: a = 32, 64, ...) are not in
-                // the site map: the plain scan kernel runs on exactly those rows
-                const int n_straddle = (L.lat_rows[o] - 1) / 32;
+                // the lattice rows whose windows straddle a strip's first image row (3a a multiple of the strip's rows, a power of two:
+                // a = 32, 64, ... or 16, 32, ...) are not in the site map: the plain scan kernel runs on exactly those rows
+                const int sr = fused_rows[o];
+                const int n_straddle = (L.lat_rows[o] - 1) / sr;
                 TimedScope ts(c, "k_extrema_w3", o, es);
                 if (n_straddle > 0)
                     hipLaunchKernelGGL(k_extrema_w3<false>, dim3((L.lat_words[o] + 3) / 4, n_straddle, nf), dim3(256), 0, es, pyr, pframe, g, o, bits, s.lflags,
-                                       L.bits_frame_words, 32, 32);
+                                       L.bits_frame_words, sr, sr);
                 if (es != c->stream) {  // the maps' reader is on another stream than their writer: mark its end for the next chunk
                     HIPCHK(c, hipEventRecord(c->ev_pack, es));
                     c->pack_pending = true;
@@ -959,6 +962,7 @@ int vslam_ctx_create(int device, void* stream, vslam_ctx** out) {
     {
         const char* e = std::getenv("VSLAM_MX");
         c->mx = e && e[0] == '1';
+        if (const char* mf = VSLAM_DIAG_ENV("VSLAM_MX_FORM")) mx_set_form(std::atoi(mf));  // diagnostics build: A/B of the two MFMA shapes
         const char* ff = std::getenv("VSLAM_F32_FUSED");
         c->f32_fused = ff && ff[0] == '1';
         const char* es = VSLAM_DIAG_ENV("VSLAM_ORIENT_SCALAR");

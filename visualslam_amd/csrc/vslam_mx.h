@@ -11,6 +11,11 @@ namespace vslam {
 
 // Which matrix-core configuration runs an octave with these zero-trimmed kernel widths: 0 = none.
 int mx_config_for(const int ke[6]);
+// Rows of a wave's strip in configuration `cfg` (32: the 32 x 32 x 32 kernels; 16: the diagnostics build's 16 x 16 x 64 kernels): the
+// lattice rows a fused scan leaves to k_extrema_w3 are the multiples of it.
+int mx_strip_rows(int cfg);
+// 32 (default) or - diagnostics build only - 16: which MFMA shape mx_config_for hands out for octaves 0-1 (process-wide; VSLAM_MX_FORM)
+void mx_set_form(int form);
 // Bytes of the device table of configuration `cfg`; mx_pack fills a host copy (false: a tap does not fit a signed byte).
 size_t mx_taps_bytes(int cfg);
 bool mx_pack(int cfg, const uint16_t* const taps[6], void* host_table);
@@ -38,6 +43,6 @@ hipError_t mx_launch(int cfg, hipStream_t stream, const void* d_table, const uin
 bool mx_up2_supported(int cfg);
 // bits / lflags: word 0 of frame 0's octave (bits may be nullptr).
 hipError_t mx_launch_pack(hipStream_t stream, const MxScan& scan, int rows, int wpr, int nf, unsigned long long* bits, unsigned long long* lflags,
-                          size_t bframe);
+                          size_t bframe, int strip_rows);
 
 }  // namespace vslam

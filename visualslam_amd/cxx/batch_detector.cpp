@@ -99,6 +99,7 @@ void BatchDetector::init(const Options& opt) {
         if (rc != VSLAM_OK) throw Error(rc, std::string("vslam_ctx_create: ") + vslam_status_string(rc) + " (no usable HIP device: there is no CPU fallback)");
         if (opt.yielding_side_streams || opt.tune_side_streams) (void)vslam_ctx_set_side_stream_priority(pp.ctx, 1);  // (the tuner compares low-priority pairs)
         (void)vslam_ctx_tune_side_streams(pp.ctx, opt.tune_side_streams ? 1 : 0);
+        if (opt.f32_fused) (void)vslam_ctx_set_f32_fused(pp.ctx, 1);  // (VSLAM_F32_FUSED=1 sets it for every context of the process)
     }
     if (opt.host_fed) {
         HIPX(hipStreamCreateWithFlags(&us, hipStreamNonBlocking));

@@ -101,6 +101,9 @@ public:
         bool custom_params = false;      // false: vslam_params_default(rows, cols)
         vslam_params params{};
         int slots = 3;                   // host-fed batches in flight (>= 1); device buffers of frames + lists per slot
+        // vslam_ctx_set_f32_fused on every pipeline's context: the f32 stages (orient / describe) with fused multiply-adds, as an
+        // OpenCV that dispatches its AVX2 + FMA3 code computes them (include/vslam.h); default: every product and sum rounded
+        bool f32_fused = false;
         bool tune_side_streams = false;  // vslam_ctx_tune_side_streams on every pipeline's context (include/vslam.h; Stream --tuner)
         // vslam_ctx_set_side_stream_priority(ctx, 1): the library's side streams at the lowest priority (they yield to the octave
         // kernels).  For a host that controls its hardware-queue layout (GPU_MAX_HW_QUEUES >= the streams of the process): +2-3 %;
