@@ -290,6 +290,8 @@ def main():
                          "in config.matrix_path and is not the headline.  The default run reports that path beside `value` as `mx_path`.")
     ap.add_argument("--mx", type=int, default=1, help="1: also time the opt-in matrix-core path (the `mx_path` object; never `value`)")
     ap.add_argument("--secondary-at-scale", type=int, default=0, help="1: run `modes` / `two_in_flight` / `mx_path` also at N > 1 (default: N = 1 only)")
+    ap.add_argument("--side-level", type=int, default=-1,
+                    help="A/B: pin the library's side-stream level (vslam_ctx_pin_side_streams: 0 yielding, 1 the context stream's priority, 2 no side streams); -1 = the library's default + watchdog")
     ap.add_argument("--stream", choices=["side", "null"], default="side",
                     help="stream of the whole job: a torch side stream (default) or torch's default (NULL) stream")
     args = ap.parse_args()
@@ -367,6 +369,8 @@ def main():
     torch.cuda.set_stream(job_stream)
     ctx = capi.Context(local_rank_dev, torch.cuda.current_stream().cuda_stream)
     ctx.set_matrix_path(bool(args.matrix_path))  # the headline runs on the default (MFMA-free) kernels whatever VSLAM_MX says
+    if args.side_level >= 0:
+        ctx.pin_side_streams(args.side_level)
     wall = {}  # seconds per leg of this script (rank 0's clock)
     t_leg = [time.perf_counter()]
 
@@ -816,7 +820,7 @@ def main():
                 "workload": f"batch of {n} synthetic {cols}x{rows} frames per GPU, Harris(k=0.04)+NMS and DoG pyramid "
                             f"{args.octaves} octaves x (6 Gaussian, 5 DoG) + extrema, fused (BASELINE config 4)",
                 "frames_per_gpu": n, "rows": rows, "cols": cols, "octaves": args.octaves, "localize": p.localize, "orient": args.orient,
-                "matrix_path": bool(args.matrix_path),
+                "matrix_path": bool(args.matrix_path), "side_level_pinned": args.side_level if args.side_level >= 0 else None,
                 "parallelism": f"frames sharded 1 stream/GPU x{world}; RCCL all-gather of counts only",
             },
             "distributed": {"initialized": bool(use_dist), "world_size": dist.get_world_size() if use_dist else 1,

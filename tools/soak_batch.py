@@ -1,6 +1,8 @@
 """One-off randomized parity soak of the batched path (not part of the test suite).
 
-    [VSLAM_MX=1] python tools/soak_batch.py <seed> <seconds> [big|deep]
+    [VSLAM_MX=1] [VSLAM_SOAK_F32_FUSED=1] python tools/soak_batch.py <seed> <seconds> [big|deep]
+VSLAM_SOAK_F32_FUSED=1 (round 6): the f32 stages with fused multiply-adds on both sides (vslam_ctx_set_f32_fused against
+oracle.fma_variant); with VSLAM_LIBRARY=lib/libvslam_diag.so VSLAM_MX=1 VSLAM_MX_FORM=16 the matrix path runs its 16 x 16 x 64 kernels.
 `deep` (round 5): 1..6 octaves whatever the frame size (the reference's constructor takes any count) - octaves 4 and 5 run
 kernels of hundreds of taps on images of a few pixels (strip kernels up to 2047 taps, repeated BORDER_REFLECT_101).
 `big`: frames up to 400 x 700 in batches of 1-9 (octave 0 up to 800 x 1400: several seams and straddling lattice rows of the
@@ -12,6 +14,12 @@ from tests.test_gpu_batch import run_batch, check_frame
 from visualslam_amd import capi, synth
 capi.build()
 ctx = capi.Context(0)
+fused = os.environ.get("VSLAM_SOAK_F32_FUSED") == "1"
+if fused:
+    import oracle as _o
+    ctx.set_f32_fused(True)
+    _o.lib().vo_set_fma_variant(3)
+last_print = time.time()
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 t0 = time.time(); it = 0
 while time.time() - t0 < (float(sys.argv[2]) if len(sys.argv) > 2 else 120):
@@ -69,6 +77,8 @@ while time.time() - t0 < (float(sys.argv[2]) if len(sys.argv) > 2 else 120):
             want = np.concatenate([out[key][f][: m[f]] for f in range(n)]).reshape(-1)
             assert rec.view(np.int32).reshape(-1).tobytes() == want.astype(np.int32).tobytes()
     it += 1
-    if it % (25 if big else 500) == 0:
+    if time.time() - last_print > 45:
         print(f"... {it} cases, {time.time() - t0:.0f} s", flush=True)  # gpurun takes a silent run for a hung one
-print("soak ok", it, "cases", "(matrix path)" if ctx.matrix_path() else "(default path)")
+        last_print = time.time()
+print("soak ok", it, "cases", "(matrix path" + (", form " + os.environ.get("VSLAM_MX_FORM", "32") if ctx.matrix_path() else "") + ")" if ctx.matrix_path() else "(default path)",
+      "f32 fused" if fused else "f32 rounded", sys.argv[3] if len(sys.argv) > 3 else "")
