@@ -83,6 +83,22 @@ def test_plain_bench_command_forms_its_ranks_itself():
     assert d["keypoints_per_step"]["dog"] != 2 * d1["keypoints_per_step"]["dog"] or d["keypoints_per_step"]["harris"] != 2 * d1["keypoints_per_step"]["harris"]
 
 
+@pytest.mark.gpu
+def test_plain_bench_command_with_four_ranks():
+    # the same launcher at N = 4 (four ranks on the one GPU of the test box: within the box's six-process limit): every rank
+    # is counted, every rank's camera stream is in the totals, the C++ children of the four ranks meet too
+    env = dict(os.environ, VSLAM_BENCH_BACKEND="gloo", VSLAM_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--frames", "2", "--rows", "120", "--cols", "160", "--steps", "2",
+                        "--warmup", "1", "--cpu-sample", "0", "--live-traffic", "0", "--cxx-host", "0"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 4 and d["distributed"]["ranks_gathered"] == 4 and sorted(m["rank"] for m in d["distributed"]["members"]) == [0, 1, 2, 3]
+    assert d["config"]["frames_per_gpu"] == 2 and d["value"] > 0
+    assert "x4" in d["config"]["parallelism"]
+
+
 def test_plain_bench_command_with_ranks_fails_loudly_without_gpus():
     # the launcher itself on the CPU box: the child job starts (two ranks under torch.distributed.run), every rank refuses to
     # run without a GPU, the launcher hands the failure on instead of printing a one-GPU line
