@@ -326,9 +326,36 @@ __global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(4, 4)))
     const int tile_x0 = bx * CFG::TW, tile_y0 = by * CFG::TH;
 
 #if !(VSLAM_MX16_KO & 2)
-    if constexpr (UP2)
-        mx_stage_tile_up2<CFG::TW, CFG::TH, CFG::R, CFG::RWP, CFG::NT, 2, 2>(base + fz * bframe, sstep, rows / 2, cols / 2, tile_x0, tile_y0, smem, 0x80808080u);
-    else
+    if constexpr (UP2) {
+        // The fused upsample reads ~10 source rows per staging item through dependent, clamped 4-byte loads, and while the other
+        // workgroups' plane stores fill the memory pipeline every one of them takes microseconds (staging: 0.8 ms of the kernel with
+        // the stores in, 0.5 without).  Interior tiles therefore fetch the source rectangle they need ONCE, as 16-byte chunks by all
+        // threads (one round trip), into the output buffers' LDS (idle until the levels start), and the upsample runs out of LDS.
+        constexpr int SRC_ROWS = (CFG::TH + 2 * CFG::R) / 2 + 2, SRC_CH = ((CFG::TW + 2 * CFG::R) / 2 + 2 + 15 + 15) / 16, SRC_PITCH = 16 * SRC_CH;
+        static_assert(SRC_ROWS * SRC_PITCH <= CFG::NW * 2 * CFG::OBUF * 4, "the source rectangle fits the output buffers");
+        const int rows_s = rows / 2, cols_s = cols / 2;
+        const uint8_t* src = base + fz * bframe;
+        const int m_lo = (tile_y0 - CFG::R) / 2 - 1, c_lo = (((tile_x0 - CFG::R) / 2 - 1) & ~15);
+        const bool src_interior = tile_y0 - CFG::R >= 2 && tile_x0 - CFG::R >= 2 && m_lo + SRC_ROWS <= rows_s && c_lo + SRC_PITCH <= cols_s && c_lo >= 0 &&
+                                  (sstep & 15) == 0 && ((bframe | reinterpret_cast<uintptr_t>(base)) & 15) == 0;  // block-uniform
+#if VSLAM_MX16_KO & 16
+        if (false) {
+#else
+        if (src_interior) {
+#endif
+            uint32_t* lsrc = smem + CFG::STAGE_DWORDS;  // (the output buffers)
+            for (int it = threadIdx.x; it < SRC_ROWS * SRC_CH; it += CFG::NT) {
+                const int rr = it / SRC_CH, ch = it - rr * SRC_CH;
+                *reinterpret_cast<uint4*>(lsrc + rr * (SRC_PITCH / 4) + 4 * ch) = *reinterpret_cast<const uint4*>(src + (size_t)(m_lo + rr) * sstep + c_lo + 16 * ch);
+            }
+            __syncthreads();
+            // the same staging code on a "frame" whose rows m_lo .. and columns c_lo .. live in LDS (no clamp is active on an interior tile)
+            const uint8_t* vsrc = reinterpret_cast<const uint8_t*>(lsrc) - ((ptrdiff_t)m_lo * SRC_PITCH + c_lo);
+            mx_stage_tile_up2<CFG::TW, CFG::TH, CFG::R, CFG::RWP, CFG::NT, 2, 2>(vsrc, SRC_PITCH, rows_s, cols_s, tile_x0, tile_y0, smem, 0x80808080u);
+        } else {
+            mx_stage_tile_up2<CFG::TW, CFG::TH, CFG::R, CFG::RWP, CFG::NT, 2, 2>(src, sstep, rows_s, cols_s, tile_x0, tile_y0, smem, 0x80808080u);
+        }
+    } else
         mx_stage_tile<CFG::TW, CFG::TH, CFG::R, CFG::RWP, CFG::NT>(base + fz * bframe, rows, cols, pitch, tile_x0, tile_y0, smem, 0x80808080u);
 #endif
     if constexpr (CFG::PAIRED) {  // the operand fragments of levels 1..5 into LDS: [level - 1][b1, a2, a2o][lane]
