@@ -71,11 +71,16 @@ static int run(int rows, int cols, int kind) {
 
 int main(void) {
     const int shapes[][2] = {{17, 23}, {33, 47}, {64, 64}, {61, 130}, {97, 75}};
-    for (unsigned i = 0; i < sizeof(shapes) / sizeof(shapes[0]); ++i)
-        for (int kind = 0; kind < 2; ++kind) {
-            const int rc = run(shapes[i][0], shapes[i][1], kind);
-            if (rc) { fprintf(stderr, "step %d failed at %dx%d\n", rc, shapes[i][0], shapes[i][1]); return rc; }
-        }
+    for (int variant = 0; variant < 4; variant += 3) {  /* the f32 stages rounded (0) and with fused multiply-adds (3): vo_set_fma_variant */
+        vo_set_fma_variant(variant);
+        if (vo_get_fma_variant() != variant) return 9;
+        for (unsigned i = 0; i < sizeof(shapes) / sizeof(shapes[0]); ++i)
+            for (int kind = 0; kind < 2; ++kind) {
+                const int rc = run(shapes[i][0], shapes[i][1], kind);
+                if (rc) { fprintf(stderr, "step %d failed at %dx%d (f32 variant %d)\n", rc, shapes[i][0], shapes[i][1], variant); return rc; }
+            }
+    }
+    vo_set_fma_variant(0);
     puts("sanitized oracle ok");
     return 0;
 }
